@@ -1,0 +1,184 @@
+"""Generate tests/golden/*.npz from the REAL reference (build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+Imports the reference's python modules from /root/reference (read-only mount; never
+copied), loads the deterministic weights of mdfnet_hip.synth.seeded_state_dict into the
+reference's `config.model`, runs reference operators / the full model on seeded
+synthetic inputs and stores inputs that cannot be regenerated + all expected outputs.
+The fixtures are data only; /root/reference does not exist on the GPU box.
+"""
+import io
+import os
+import sys
+import contextlib
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("MDF_REFERENCE", "/root/reference")
+sys.path.insert(0, os.path.join(ROOT, "mdf-net_amd"))
+from mdfnet_hip import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def load_reference():
+    cwd = os.getcwd()
+    os.chdir("/tmp")  # reference Args classes makedirs('pth') relative to cwd; keep the repo clean
+    sys.path.insert(0, REF)
+    with contextlib.redirect_stdout(io.StringIO()):
+        import config as ref_config  # builds config.model (config.py:186-218)
+    from net.unit import base, homoaggregate, regress, depthhypos, scale  # noqa
+    from net import loss as ref_loss
+    os.chdir(cwd)
+    sys.path.remove(REF)
+    return ref_config, base, homoaggregate, regress, depthhypos, scale, ref_loss
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def main():
+    torch.set_num_threads(8)
+    os.makedirs(OUT, exist_ok=True)
+    cfg, base, agg, regress, dh, scale, ref_loss = load_reference()
+    model = cfg.model
+    sd = synth.seeded_state_dict(model.state_dict(), seed=1)
+    model.load_state_dict(sd)
+    model.eval()
+    meta = {k: list(v.shape) for k, v in model.state_dict().items()}
+    np.savez(os.path.join(OUT, "state_dict_meta.npz"),
+             keys=np.array(list(meta.keys())), shapes=np.array([str(s) for s in meta.values()]),
+             dtypes=np.array([str(v.dtype) for v in model.state_dict().values()]),
+             nparams=np.array(sum(p.numel() for p in model.parameters())))
+
+    # ------------------------------------------------------------------ operator level (ops.npz)
+    g = {}
+    torch.manual_seed(1234)
+    W, H, V = 96, 64, 3
+    imgs, extr, intr, dr = synth.make_scene(W, H, V, batch=2, rot_deg=4.0, seed=5)
+    with torch.no_grad():
+        # a2 scale_cam
+        for st in range(3):
+            rp, sps = scale.scale_cam(intr, extr, st)
+            g[f"scale_ref{st}"] = npy(rp)
+            g[f"scale_src{st}"] = npy(torch.stack(sps))
+        # a4 homo_warping: stage-0-like (shared hypotheses) and stage-1-like (per-pixel hypotheses)
+        rp, sps = scale.scale_cam(intr, extr, 0)
+        h8, w8 = H // 8, W // 8
+        fea0 = torch.randn(2, 64, h8, w8)
+        hyp0 = dh.HyposByFit(48, None, 0.0)(None, dr, None, None)
+        g["warp0_src"] = npy(fea0)
+        g["warp0_hyp"] = npy(hyp0[:, ::4])
+        g["warp0_out"] = npy(base.homo_warping(fea0, sps[0], rp, hyp0[:, ::4]))
+        rp1, sps1 = scale.scale_cam(intr, extr, 1)
+        h4, w4 = H // 4, W // 4
+        fea1 = torch.randn(2, 32, h4, w4)
+        hyp1 = (425 + 510 * torch.rand(2, 1, h4, w4)) + torch.linspace(-20, 20, 8).reshape(1, 8, 1, 1)
+        g["warp1_src"] = npy(fea1)
+        g["warp1_hyp"] = npy(hyp1)
+        g["warp1_out"] = npy(base.homo_warping(fea1, sps1[1], rp1, hyp1))
+        # H4: plane behind the source camera (z<0) and z==0 (kept separate)
+        hyp_neg = torch.full((2, 2, 1, 1), -300.0)
+        hyp_neg[:, 1] = 0.0
+        g["warpneg_hyp"] = npy(hyp_neg)
+        g["warpneg_out"] = npy(base.homo_warping(fea0, sps[0], rp, hyp_neg))
+        p_zero = rp.clone()
+        src_zero = sps[0].clone()
+        src_zero[:, 2, :] = 0.0  # forces z == 0 for every pixel -> inf/nan coordinates
+        g["warpz0_srcproj"] = npy(src_zero)
+        g["warpz0_out"] = npy(base.homo_warping(fea0, src_zero, p_zero, hyp0[:, :3]))
+        # a5 VectorAggregate (eval), all three stage shapes, and a5' variance
+        feas = [[torch.randn(2, c, H // s, W // s) for _ in range(V)] for c, s in ((64, 8), (32, 4), (16, 2))]
+        hyps = [hyp0,
+                (425 + 510 * torch.rand(2, 1, h4, w4)) + torch.linspace(-30, 30, 24).reshape(1, 24, 1, 1),
+                (425 + 510 * torch.rand(2, 1, H // 2, W // 2)) + torch.linspace(-6, 6, 8).reshape(1, 8, 1, 1)]
+        for st in range(3):
+            rp_s, sps_s = scale.scale_cam(intr, extr, st)
+            g[f"agg{st}_feas"] = npy(torch.stack(feas[st]))
+            g[f"agg{st}_hyp"] = npy(hyps[st])
+            g[f"agg{st}_cost"] = npy(model.Homoaggre[st](feas[st], rp_s, sps_s, hyps[st]))
+        g["var0_cost"] = npy(agg.homo_aggregate_by_variance(feas[0], rp, sps, hyp0[:, ::4]))
+        g["var2_cost"] = npy(agg.homo_aggregate_by_variance(feas[2], *scale.scale_cam(intr, extr, 2), hyps[2][:, ::2]))
+        # a6/a7 regularisers (on the aggregated costs above) + a9/a10
+        for st in range(3):
+            cost = torch.from_numpy(g[f"agg{st}_cost"])
+            prob = model.Regular[st](cost)
+            g[f"reg{st}_prob"] = npy(prob)
+            g[f"reg{st}_depth"] = npy(regress.depth_regression(prob, hyps[st]))
+        g["conf2"] = npy(regress.confidence_regress(torch.from_numpy(g["reg2_prob"])))
+        # a3 HyposByFit: stage-1 module on stage-0 outputs, stage-2 module on stage-1 outputs
+        p0, d0 = torch.from_numpy(g["reg0_prob"]), torch.from_numpy(g["reg0_depth"])
+        g["hyp1_out"] = npy(model.Depth_hypos[1](d0, dr, p0, hyp0, upsample=True))
+        g["hyp1_s"] = npy(model.Depth_hypos[1]._gauss_fitting1(d0, p0, hyp0))
+        p1, d1 = torch.from_numpy(g["reg1_prob"]), torch.from_numpy(g["reg1_depth"])
+        g["hyp2_out"] = npy(model.Depth_hypos[2](d1, dr, p1, hyps[1], upsample=True))
+        g["hyp2_s"] = npy(model.Depth_hypos[2]._laplace_fitting(d1, p1, hyps[1]))
+        # flat probability volume (H3: ill-conditioned gauss fit; recorded, compared loosely)
+        pflat = torch.softmax(0.05 * torch.randn(2, 48, h8, w8), 1)
+        g["hyp1flat_prob"] = npy(pflat)
+        g["hyp1flat_s"] = npy(model.Depth_hypos[1]._gauss_fitting1(d0, pflat, hyp0))
+        # a11 backbone, a12 refine
+        f8, f4, f2 = model.Backbone(imgs[:, 0])
+        g["fpn_f8"], g["fpn_f4"], g["fpn_f2"] = npy(f8), npy(f4), npy(f2)
+        g["refine_out"] = npy(model.Refine(torch.from_numpy(g["reg2_depth"]), dr))
+    np.savez_compressed(os.path.join(OUT, "ops.npz"), **g)
+
+    # ------------------------------------------------------------------ end-to-end goldens
+    def e2e(name, w, h, v, batch, rot, seed, keep):
+        imgs, extr, intr, dr = synth.make_scene(w, h, v, batch=batch, rot_deg=rot, seed=seed)
+        tr = {}
+        hooks = []
+        if keep:
+            for st in range(3):
+                hooks.append(model.Homoaggre[st].register_forward_hook(
+                    lambda m, i, o, st=st: tr.__setitem__(f"cost{st}", npy(o))))
+                hooks.append(model.Regular[st].register_forward_hook(
+                    lambda m, i, o, st=st: tr.__setitem__(f"prob{st}", npy(o))))
+                hooks.append(model.Depth_hypos[st].register_forward_hook(
+                    lambda m, i, o, st=st: tr.__setitem__(f"hypos{st}", npy(o))))
+        with torch.no_grad():
+            out = model(imgs, extr, intr, dr)
+        for hk in hooks:
+            hk.remove()
+        tr["depth"], tr["confidence"] = npy(out["depth"]), npy(out["confidence"])
+        tr["cfg"] = np.array([w, h, v, batch, rot, seed], dtype=np.float64)
+        np.savez_compressed(os.path.join(OUT, name), **tr)
+        print(name, "depth mean", float(out["depth"].mean()), "conf mean", float(out["confidence"].mean()))
+
+    e2e("e2e_tiny.npz", 96, 64, 3, 1, 3.0, 11, True)
+    e2e("e2e_cfg1.npz", 160, 128, 3, 1, 0.0, 0, False)       # BASELINE config 1 shape
+    e2e("e2e_5view.npz", 320, 256, 5, 1, 5.0, 21, False)
+
+    # ------------------------------------------------------------------ training-mode golden
+    model.train()
+    model.load_state_dict(sd)
+    imgs, extr, intr, dr = synth.make_scene(96, 64, 3, batch=2, rot_deg=3.0, seed=31)
+    rng = np.random.RandomState(7)
+    gt = {k: torch.from_numpy((425 + 510 * rng.rand(2, 64 // s, 96 // s)).astype(np.float32))
+          for k, s in (("3", 8), ("2", 4), ("1", 2), ("0", 1))}
+    gt["3"][:, :2] = 0.0  # masked-out region (gt <= depth_min)
+    out = model(imgs, extr, intr, dr)
+    loss = ref_loss.Loss()(out, gt, dr)
+    loss.backward()
+    tg = {"loss": npy(loss)}
+    for i, d in enumerate(out["depth"]):
+        tg[f"depth{i}"] = npy(d)
+    params = dict(model.named_parameters())
+    for k in ("Backbone.conv01.0.conv.weight", "Homoaggre.0.depth_weight.0.conv.weight",
+              "Homoaggre.2.depth_weight.1.bias", "Regular.2.prob.weight", "Regular.0.conv01.0.conv.weight",
+              "Refine.conv2.2.weight"):
+        tg["grad:" + k] = npy(params[k].grad)
+    for k in gt:
+        tg["gt" + k] = npy(gt[k])
+    np.savez_compressed(os.path.join(OUT, "train_tiny.npz"), **tg)
+    print("train loss", float(loss))
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

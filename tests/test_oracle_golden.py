@@ -1,0 +1,164 @@
+"""CPU: pin the oracle (oracle/mvs_oracle.py) against goldens produced by the real reference
+(oracle/gen_golden.py).  Tolerances: ops that are the same ATen calls in the same order are
+compared bit-exactly; restated arithmetic within a stated fp tolerance."""
+import numpy as np
+import pytest
+import torch
+
+from mdfnet_hip import synth
+from oracle import mvs_oracle as O
+
+T = torch.from_numpy
+
+
+def _scene_ops():
+    return synth.make_scene(96, 64, 3, batch=2, rot_deg=4.0, seed=5)
+
+
+def sub(sd, pre):
+    return {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+
+
+def test_state_dict_contract(golden, seeded_sd):
+    meta = golden("state_dict_meta.npz")
+    assert len(meta["keys"]) == 290 and int(meta["nparams"]) == 1206380
+    assert len(seeded_sd) == 290
+
+
+def test_scale_cam(golden):
+    g = golden("ops.npz")
+    _, extr, intr, _ = _scene_ops()
+    e0, k0 = extr.clone(), intr.clone()
+    for st in range(3):
+        rp, sps = O.scale_cam(intr, extr, st)
+        assert np.array_equal(rp.numpy(), g[f"scale_ref{st}"])
+        assert np.array_equal(torch.stack(sps).numpy(), g[f"scale_src{st}"])
+    assert torch.equal(e0, extr) and torch.equal(k0, intr)  # inputs not mutated (scale.py:14)
+
+
+@pytest.mark.parametrize("case,stage,view", [("warp0", 0, 0), ("warp1", 1, 1)])
+def test_homo_warping_golden_and_explicit_bitwise(golden, case, stage, view):
+    g = golden("ops.npz")
+    _, extr, intr, _ = _scene_ops()
+    rp, sps = O.scale_cam(intr, extr, stage)
+    src, hyp = T(g[case + "_src"]), T(g[case + "_hyp"])
+    out = O.homo_warping(src, sps[view], rp, hyp)
+    assert np.array_equal(out.numpy(), g[case + "_out"])            # same ATen calls -> bit exact
+    exp = O.homo_warping_explicit(src, sps[view], rp, hyp)
+    assert np.array_equal(exp.numpy(), g[case + "_out"])            # explicit index arithmetic -> bit exact
+
+
+def test_warp_degenerate_planes(golden):
+    """H4: plane behind the camera gives finite mirrored samples; z == 0 gives NaN (not zero)."""
+    g = golden("ops.npz")
+    _, extr, intr, _ = _scene_ops()
+    rp, sps = O.scale_cam(intr, extr, 0)
+    src = T(g["warp0_src"])
+    hyp = T(g["warpneg_hyp"])
+    for fn in (O.homo_warping, O.homo_warping_explicit):
+        out = fn(src, sps[0], rp, hyp).numpy()
+        assert np.array_equal(out, g["warpneg_out"], equal_nan=True)
+    z0 = O.homo_warping_explicit(src, T(g["warpz0_srcproj"]), rp, T(golden("ops.npz")["warp0_hyp"])[:, :3] * 0 + 500.0)
+    assert np.isnan(g["warpz0_out"]).all() and torch.isnan(z0).all()
+
+
+@pytest.mark.parametrize("stage", [0, 1, 2])
+def test_vector_aggregate(golden, seeded_sd, stage):
+    g = golden("ops.npz")
+    _, extr, intr, _ = _scene_ops()
+    rp, sps = O.scale_cam(intr, extr, stage)
+    feas = list(T(g[f"agg{stage}_feas"]))
+    hyp = T(g[f"agg{stage}_hyp"])
+    p = sub(seeded_sd, f"Homoaggre.{stage}.")
+    cost = O.vector_aggregate(feas, rp, sps, hyp, synth.NGROUPS[stage], p)
+    np.testing.assert_allclose(cost.numpy(), g[f"agg{stage}_cost"], rtol=0, atol=2e-7)
+    cost2 = O.vector_aggregate(feas, rp, sps, hyp, synth.NGROUPS[stage], p, warp=O.homo_warping_explicit)
+    np.testing.assert_allclose(cost2.numpy(), g[f"agg{stage}_cost"], rtol=0, atol=2e-7)
+
+
+def test_variance_aggregate(golden):
+    g = golden("ops.npz")
+    _, extr, intr, _ = _scene_ops()
+    rp, sps = O.scale_cam(intr, extr, 0)
+    hyp0 = O.uniform_hypos(_scene_ops()[3], 48)
+    v0 = O.variance_aggregate(list(T(g["agg0_feas"])), rp, sps, hyp0[:, ::4])
+    np.testing.assert_allclose(v0.numpy(), g["var0_cost"], rtol=0, atol=1e-6)
+    rp2, sps2 = O.scale_cam(intr, extr, 2)
+    v2 = O.variance_aggregate(list(T(g["agg2_feas"])), rp2, sps2, T(g["agg2_hyp"])[:, ::2])
+    np.testing.assert_allclose(v2.numpy(), g["var2_cost"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("stage", [0, 1, 2])
+def test_regular_and_regress(golden, seeded_sd, stage):
+    g = golden("ops.npz")
+    prob = O.regular(T(g[f"agg{stage}_cost"]), sub(seeded_sd, f"Regular.{stage}."))
+    np.testing.assert_allclose(prob.numpy(), g[f"reg{stage}_prob"], rtol=1e-5, atol=1e-7)
+    d = O.depth_regression(T(g[f"reg{stage}_prob"]), T(g[f"agg{stage}_hyp"]))
+    assert np.array_equal(d.numpy(), g[f"reg{stage}_depth"])
+
+
+def test_confidence(golden):
+    g = golden("ops.npz")
+    c = O.confidence_regress(T(g["reg2_prob"]))
+    np.testing.assert_allclose(c.numpy(), g["conf2"], rtol=0, atol=1e-7)
+    idx = O.confidence_index(T(g["reg2_prob"]))
+    assert idx.dtype == torch.int64 and int(idx.min()) >= 0 and int(idx.max()) <= 7
+
+
+def test_hypos_by_fit(golden):
+    g = golden("ops.npz")
+    dr = _scene_ops()[3]
+    hyp0 = O.hypos_by_fit(None, dr, None, None, 48, None, 0.0)
+    assert hyp0.shape == (2, 48, 1, 1)
+    assert np.array_equal(hyp0[:, ::4].numpy(), g["warp0_hyp"])
+    p0, d0 = T(g["reg0_prob"]), T(g["reg0_depth"])
+    assert np.array_equal(O.gauss1_fit(p0, hyp0).numpy(), g["hyp1_s"])
+    h1 = O.hypos_by_fit(d0, dr, p0, hyp0, 24, "gauss1", 0.95)
+    assert np.array_equal(h1.numpy(), g["hyp1_out"])
+    p1, d1 = T(g["reg1_prob"]), T(g["reg1_depth"])
+    assert np.array_equal(O.laplace_fit(d1, p1, T(g["agg1_hyp"])).numpy(), g["hyp2_s"])
+    h2 = O.hypos_by_fit(d1, dr, p1, T(g["agg1_hyp"]), 8, "laplace", 1e-5)
+    assert np.array_equal(h2.numpy(), g["hyp2_out"])
+    assert np.array_equal(O.gauss1_fit(T(g["hyp1flat_prob"]), hyp0).numpy(), g["hyp1flat_s"])
+
+
+def test_backbone_refine(golden, seeded_sd):
+    g = golden("ops.npz")
+    imgs, _, _, dr = _scene_ops()
+    f8, f4, f2 = O.fpn_4scales(imgs[:, 0], sub(seeded_sd, "Backbone."))
+    for a, k in ((f8, "fpn_f8"), (f4, "fpn_f4"), (f2, "fpn_f2")):
+        np.testing.assert_allclose(a.numpy(), g[k], rtol=1e-5, atol=1e-6)
+    r = O.refine_net2(T(g["reg2_depth"]), dr, sub(seeded_sd, "Refine."))
+    np.testing.assert_allclose(r.numpy(), g["refine_out"], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["e2e_tiny.npz", "e2e_cfg1.npz", "e2e_5view.npz"])
+def test_core_forward_end_to_end(golden, seeded_sd, name):
+    g = golden(name)
+    w, h, v, b, rot, seed = g["cfg"]
+    imgs, extr, intr, dr = synth.make_scene(int(w), int(h), int(v), batch=int(b), rot_deg=float(rot), seed=int(seed))
+    out, tr = O.core_forward(seeded_sd, imgs, extr, intr, dr, keep=True)
+    # mean |delta depth| <= 1e-3 is BASELINE's tolerance; the oracle restatement is far inside it
+    assert float(np.abs(out["depth"].numpy() - g["depth"]).mean()) <= 1e-4
+    np.testing.assert_allclose(out["confidence"].numpy(), g["confidence"], rtol=0, atol=1e-5)
+    if "cost0" in g:
+        for st in range(3):
+            np.testing.assert_allclose(tr[f"cost{st}"].numpy(), g[f"cost{st}"], rtol=0, atol=1e-6)
+            np.testing.assert_allclose(tr[f"hypos{st}"].numpy(), g[f"hypos{st}"], rtol=0, atol=2e-3)
+
+
+def test_training_forward_backward(golden, seeded_sd):
+    g = golden("train_tiny.npz")
+    imgs, extr, intr, dr = synth.make_scene(96, 64, 3, batch=2, rot_deg=3.0, seed=31)
+    sd = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v)
+          for k, v in seeded_sd.items()}
+    out = O.core_forward(sd, imgs, extr, intr, dr, training=True)
+    gt = {k: T(g["gt" + k]) for k in ("3", "2", "1", "0")}
+    loss = O.mvs_loss(out["depth"], gt, dr)
+    np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=1e-5)
+    loss.backward()
+    for k in g:
+        if k.startswith("grad:"):
+            ref = g[k]
+            got = sd[k[5:]].grad.numpy()
+            np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-4 * float(np.abs(ref).max() + 1e-12))
