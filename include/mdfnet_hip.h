@@ -1,0 +1,135 @@
+/*
+ * mdfnet_hip.h -- C ABI of the MI355X (gfx950) kernels behind MDF-Net's multi-stage MVS hot path.
+ *
+ * The reference (zongh5a/MDF-Net) has no FFI on this path: every operator is a chain of stock
+ * PyTorch ops.  Each entry point below replaces one such chain; the reference interface it
+ * replaces is cited as file:line (paths relative to the reference root).
+ *
+ * Conventions (all entry points)
+ *   - Plain pointers and sizes only.  Every `const float*` / `float*` is DEVICE memory unless the
+ *     parameter comment says HOST.  The caller (PyTorch) owns every buffer; the library never
+ *     allocates, frees or retains device memory.
+ *   - Asynchronous: work is enqueued on `stream` (a hipStream_t passed as void*); no implicit
+ *     synchronisation.  Re-entrant; callable from several host threads / one process per GPU.
+ *   - Return 0 on success; <0 on failure: MDF_EARG (-1) bad argument/shape, MDF_EUNSUPPORTED (-2)
+ *     configuration not built, MDF_EHIP (-3) HIP runtime error.  mdf_last_error() returns a
+ *     thread-local message valid until the next call on that thread.  Never aborts.
+ *   - fp32 everywhere.  "Bit-exact" below means bit-identical to torch-2.10 CPU on the same inputs.
+ */
+#ifndef MDFNET_HIP_H
+#define MDFNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDF_ABI_VERSION 1
+
+#define MDF_OK 0
+#define MDF_EARG (-1)
+#define MDF_EUNSUPPORTED (-2)
+#define MDF_EHIP (-3)
+
+/* feature-map layouts ([B,C,h,w] logical) */
+#define MDF_FEA_NCHW 0
+#define MDF_FEA_NHWC 1
+/* volume layouts ([B,C,D,h,w] logical) */
+#define MDF_VOL_NCDHW 0
+#define MDF_VOL_NDHWC 1
+
+#define MDF_MAX_SRC_VIEWS 16
+
+int mdf_abi_version(void);
+const char* mdf_last_error(void);
+
+/* ---- a4  homo_warping (net/unit/base.py:85-126) ---------------------------------------------
+ * Plane-sweep homography warp of ONE source feature map; bilinear, zero padding, the reference's
+ * mixed align_corners convention (ix = px*w/(w-1) - 0.5).  Output values are bit-exact.
+ *   src_fea  [B,h,w,C] (MDF_FEA_NHWC) ; C in {16,32,64}
+ *   proj     [B,12]  rows of (src_proj @ inverse(ref_proj))[:3,:4], computed by the host with the
+ *            same torch call as base.py:98 so kernel and oracle consume identical floats
+ *   hypos    [B,D] (hypos_per_pixel=0; reference shape [B,D,1,1]) or [B,D,h,w] (=1)
+ *   out      [B,C,D,h,w] (MDF_VOL_NCDHW) or [B,D,h,w,C] (MDF_VOL_NDHWC)                         */
+int mdf_homo_warp_fwd(const float* src_fea, int fea_layout, const float* proj, const float* hypos,
+                      int hypos_per_pixel, float* out, int out_layout, int B, int C, int D, int h, int w,
+                      void* stream);
+
+/* Test hook for "indexing bit-exact": integer corner (floor) of every sample position.
+ *   x0y0 [B,D,h,w,2] int32 = (floor(ix), floor(iy)); INT32_MIN for non-finite positions,
+ *   clamped to +-2^30.  Same device function as the kernels above/below.                        */
+int mdf_warp_corner_indices(const float* proj, const float* hypos, int hypos_per_pixel, int32_t* x0y0,
+                            int B, int D, int h, int w, void* stream);
+
+/* ---- a5  VectorAggregate.forward, eval mode (net/unit/homoaggregate.py:25-46) ----------------
+ * Fused warp + group softmax + similarity + learned view weight + weighted mean over views.
+ * Fills CoreNet's Homoaggre[s] slot (net/core.py:58).  C/G must be 2 (config.py:196,205).
+ *   ref_fea   [B,h,w,C] NHWC
+ *   src_feas  HOST array of n_src DEVICE pointers, each [B,h,w,C] NHWC
+ *   proj      [n_src,B,12]
+ *   w_params  [G+4] = depth_weight.0.conv.weight[G], alpha, beta, w2, b2 where BatchNorm3d(1) is
+ *             folded as ATen does in eval: alpha = gamma/sqrt(var+eps), beta = bias - mean*alpha
+ *   cost      [B,G,D,h,w] (NCDHW) or [B,D,h,w,G] (NDHWC)                                         */
+int mdf_warp_aggregate_vec_fwd(const float* ref_fea, const float* const* src_feas, int fea_layout,
+                               const float* proj, const float* hypos, int hypos_per_pixel,
+                               const float* w_params, float* cost, int cost_layout, int B, int C, int G,
+                               int D, int h, int w, int n_src, void* stream);
+
+/* ---- a5' homo_aggregate_by_variance (net/unit/homoaggregate.py:49-69) ------------------------
+ * var = E[x^2] - E[x]^2 over {ref, softmax_C(warped src_v)}.  cost has C channels.               */
+int mdf_warp_aggregate_var_fwd(const float* ref_fea, const float* const* src_feas, int fea_layout,
+                               const float* proj, const float* hypos, int hypos_per_pixel, float* cost,
+                               int cost_layout, int B, int C, int D, int h, int w, int n_src, void* stream);
+
+/* ---- a6/a7/a8  3-D convolution layers of the regularisers (net/unit/regular.py:9-133,
+ *      net/unit/base.py:50-68): Conv3d / ConvTranspose3d, k=3, pad=1, (output_padding=1), no bias,
+ *      optional folded BatchNorm3d (alpha,beta per output channel), ReLU and residual add, in that
+ *      order:  y = [res +] [relu] (conv(x) * alpha + beta).  fp32 MFMA (exact f32 fma chain).
+ *   x        [B,Di,Hi,Wi,Cin]  NDHWC
+ *   wpack    weights pre-packed by mdf_conv3d_pack_weights (device)
+ *   alpha,beta [Cout] or NULL (no BN);  res [B,Do,Ho,Wo,Cout] or NULL
+ *   y        [B,Do,Ho,Wo,Cout] NDHWC.   stride in {1,2}; transposed in {0,1} (transposed => stride 2)
+ *   Cin,Cout in {8,16,32,64}                                                                      */
+int mdf_conv3d_fwd(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
+                   float* y, int B, int Di, int Hi, int Wi, int Cin, int Cout, int stride, int transposed,
+                   int relu, void* stream);
+
+/* Packed-weight size in floats for a (Cin,Cout) k=3 layer. */
+int64_t mdf_conv3d_packed_size(int Cin, int Cout);
+/* Re-order torch weights into the MFMA B-fragment order (device -> device, on `stream`).
+ *   w: Conv3d [Cout,Cin,3,3,3] (transposed=0) or ConvTranspose3d [Cin,Cout,3,3,3] (transposed=1). */
+int mdf_conv3d_pack_weights(const float* w, float* wpack, int Cin, int Cout, int transposed, void* stream);
+
+/* `prob` head: Conv3d(Cin->1,k3,p1,no bias) + softmax over D [+ soft-argmin]  (regular.py:43,69 /
+ * :110,133 and net/unit/regress.py:5-7).  x NDHWC [B,D,h,w,Cin]; w [Cin*27] torch order [1,Cin,3,3,3];
+ *   prob [B,D,h,w]; depth [B,h,w] or NULL; hypos as above (may be NULL when depth is NULL).       */
+int mdf_prob_softmax_regress_fwd(const float* x, const float* w, const float* hypos, int hypos_per_pixel,
+                                 float* prob, float* depth, int B, int D, int h, int wd, int Cin, void* stream);
+
+/* ---- a9  depth_regression (net/unit/regress.py:5-7): depth = sum_d prob*hypos ----------------- */
+int mdf_depth_regress_fwd(const float* prob, const float* hypos, int hypos_per_pixel, float* depth, int B, int D,
+                          int h, int w, void* stream);
+
+/* ---- a10 confidence_regress (net/unit/regress.py:9-25), n=4, pad=(1,2) ------------------------
+ *   conf [B,h,w] = sum prob[idx-1..idx+2], idx = (int64) trunc(sum_d prob_d*d); idx_out int64 or NULL */
+int mdf_confidence_fwd(const float* prob, float* conf, int64_t* idx_out, int B, int D, int h, int w, void* stream);
+
+/* ---- a3  HyposByFit.forward (net/unit/depthhypos.py:27-76) -------------------------------------
+ * mode 1 = gauss1 (depthhypos.py:169-215) with hypotheses shared by all pixels: `fit_row` is
+ *          row 0 of (X^T X)^-1 X^T, [B,D], computed by the host with the reference's own torch
+ *          calls (the 3x3 normal matrix has cond ~1e14 in fp32);
+ * mode 2 = laplace (depthhypos.py:78-125), per-pixel or shared hypotheses.
+ * Step 1: s [B,h,w].  Step 2: bilinear x2 upsample of s and depth (align_corners=False), range
+ * from the curve, clamps, D_out hypotheses per pixel -> hypos_out [B,D_out,2h,2w].
+ *   range [B,2] = (depth_min, depth_max) as float32;  log_thresh = f32 ln(prob_thresh), computed by
+ *   the host with torch.log (depthhypos.py:55,57) so it carries the reference's rounding.          */
+int mdf_hypos_fit_fwd(int mode, const float* prob, const float* depth, const float* hypos, int hypos_per_pixel,
+                      const float* fit_row, float* s_out, int B, int D, int h, int w, void* stream);
+int mdf_hypos_from_fit_fwd(int mode, const float* s, const float* depth, const float* range, float log_thresh,
+                           float* hypos_out, int B, int D_out, int h, int w, int upsample, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDFNET_HIP_H */

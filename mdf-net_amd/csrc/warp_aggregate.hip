@@ -1,0 +1,403 @@
+// Fused plane-sweep warp + cost-volume aggregation for gfx950 (MI355X).
+//
+// Replaces, per stage, the reference's chain  homo_warping (net/unit/base.py:85-126) ->
+// softmax -> mul -> sum -> depth_weight -> accumulate (net/unit/homoaggregate.py:25-46), which
+// materialises a [B,C,D,h,w] warped volume per source view and makes ~10 passes over it.
+// Here one kernel reads the V feature maps and writes only the [B,G,D,h,w] cost volume.
+//
+// Data layout: features are NHWC so one bilinear tap of a pixel is C contiguous floats; a lane
+// owns 4 consecutive channels (= 2 groups of C/G = 2) and fetches each tap with one 16-byte load,
+// so the C/4 lanes of a pixel read a tap as one contiguous C*4-byte segment.
+//
+// Per block (256 threads, PPB = 256/(C/4) pixels) and per chunk of depth planes:
+//   phase A  every thread computes whole sample positions (one per (pixel, plane, view)): the
+//            homography, 4 IEEE divides, floor, bilinear weights, bounds -> an LDS table entry
+//            {4 tap offsets, 4 weights}.  This arithmetic is done ONCE per sample instead of once
+//            per lane, and follows the rounding order of torch's CPU path exactly (see
+//            warp_position), so the warped values are bit-identical to the reference's.
+//   phase B  the C/4 lanes of a pixel read the entry (LDS broadcast), gather 4x16 B per view,
+//            blend, form the group similarities in registers, reduce the view-weight dot product
+//            across the pixel's lanes with wavefront shuffles, and accumulate over views.
+//
+// Compile with -ffp-contract=off: every fused multiply-add below is explicit.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct Geom {
+  float half_w, half_h;  // f32((w-1)/2), f32((h-1)/2)       base.py:117-118
+  float sw, sh;          // f32(w/2), f32(h/2)               ATen unnormalise scale
+  int w, h;
+};
+
+// Sample position in source pixel units.  Rounding order == torch 2.10 CPU (verified bitwise by
+// tests/test_oracle_golden.py against the real reference):
+//   rot_xyz_i = fma(r_i2, 1, fma(r_i1, y, r_i0*x))      base.py:110 (MKL sgemm, K = 3)
+//   P = rot_xyz*depth ; P += t ; px = Px/Pz ; py = Py/Pz  base.py:112-115 (no z>0 test)
+//   xn = px / f32((w-1)/2) - 1                             base.py:117 (true divide)
+//   ix = fma(xn + 1, w/2, -0.5)                            grid_sample(align_corners=False), FMA-contracted
+__device__ __forceinline__ void warp_position(const float* __restrict__ m, float x, float y, float dep,
+                                              const Geom& g, float& ix, float& iy) {
+  const float q0 = __fadd_rn(m[2], __fmaf_rn(m[1], y, __fmul_rn(m[0], x)));
+  const float q1 = __fadd_rn(m[6], __fmaf_rn(m[5], y, __fmul_rn(m[4], x)));
+  const float q2 = __fadd_rn(m[10], __fmaf_rn(m[9], y, __fmul_rn(m[8], x)));
+  const float X = __fadd_rn(__fmul_rn(q0, dep), m[3]);
+  const float Y = __fadd_rn(__fmul_rn(q1, dep), m[7]);
+  const float Z = __fadd_rn(__fmul_rn(q2, dep), m[11]);
+  const float px = __fdiv_rn(X, Z);
+  const float py = __fdiv_rn(Y, Z);
+  const float xn = __fsub_rn(__fdiv_rn(px, g.half_w), 1.0f);
+  const float yn = __fsub_rn(__fdiv_rn(py, g.half_h), 1.0f);
+  ix = __fmaf_rn(__fadd_rn(xn, 1.0f), g.sw, -0.5f);
+  iy = __fmaf_rn(__fadd_rn(yn, 1.0f), g.sh, -0.5f);
+}
+
+struct __attribute__((aligned(16))) TapEntry {
+  int off[4];   // float offsets of the nw, ne, sw, se taps inside one [h,w,C] map (clamped in range)
+  float wt[4];  // bilinear weights; 0 for out-of-bounds taps, NaN for non-finite positions
+};
+
+__device__ __forceinline__ void make_taps(float ix, float iy, const Geom& g, int C, TapEntry& t) {
+  const float x0f = floorf(ix), y0f = floorf(iy);
+  const float fw = __fsub_rn(ix, x0f), fe = __fsub_rn(1.0f, fw);
+  const float fn = __fsub_rn(iy, y0f), fs = __fsub_rn(1.0f, fn);
+  const float wnw = __fmul_rn(fs, fe), wne = __fmul_rn(fs, fw), wsw = __fmul_rn(fn, fe), wse = __fmul_rn(fn, fw);
+  const float x1f = x0f + 1.0f, y1f = y0f + 1.0f;
+  const float mw = (float)(g.w - 1), mh = (float)(g.h - 1);
+  const bool bx0 = (x0f >= 0.0f) && (x0f <= mw), bx1 = (x1f >= 0.0f) && (x1f <= mw);
+  const bool by0 = (y0f >= 0.0f) && (y0f <= mh), by1 = (y1f >= 0.0f) && (y1f <= mh);
+  // out-of-bounds taps read 0 in the reference; w*0 keeps NaN/inf weights NaN (z == 0 planes -> NaN).
+  t.wt[0] = (bx0 && by0) ? wnw : __fmul_rn(wnw, 0.0f);
+  t.wt[1] = (bx1 && by0) ? wne : __fmul_rn(wne, 0.0f);
+  t.wt[2] = (bx0 && by1) ? wsw : __fmul_rn(wsw, 0.0f);
+  t.wt[3] = (bx1 && by1) ? wse : __fmul_rn(wse, 0.0f);
+  const int xi = (int)fminf(fmaxf(x0f, -2.0f), (float)g.w);  // NaN -> -2
+  const int yi = (int)fminf(fmaxf(y0f, -2.0f), (float)g.h);
+  const int xa = min(max(xi, 0), g.w - 1), xb = min(max(xi + 1, 0), g.w - 1);
+  const int ya = min(max(yi, 0), g.h - 1), yb = min(max(yi + 1, 0), g.h - 1);
+  t.off[0] = (ya * g.w + xa) * C;
+  t.off[1] = (ya * g.w + xb) * C;
+  t.off[2] = (yb * g.w + xa) * C;
+  t.off[3] = (yb * g.w + xb) * C;
+}
+
+enum Mode { kWarp = 0, kVec = 1, kVar = 2 };
+
+struct Params {
+  const float* ref;                      // [B,h,w,C] (unused for kWarp)
+  const float* src[MDF_MAX_SRC_VIEWS];   // each [B,h,w,C]
+  const float* proj;                     // [n_src,B,12]
+  const float* hypos;                    // [B,D] or [B,D,h,w]
+  const float* wpar;                     // [G+4] (kVec)
+  float* out;
+  Geom g;
+  int B, D, n_src, hypos_per_pixel, out_ndhwc, dchunk, nblk_x;
+};
+
+template <int LPP>
+__device__ __forceinline__ float pixel_sum(float v) {
+#pragma unroll
+  for (int s = 1; s < LPP; s <<= 1) v += __shfl_xor(v, s, 64);
+  return v;
+}
+template <int LPP>
+__device__ __forceinline__ float pixel_max(float v) {
+#pragma unroll
+  for (int s = 1; s < LPP; s <<= 1) v = fmaxf(v, __shfl_xor(v, s, 64));
+  return v;
+}
+
+// softmax over a pair (C/G = 2), as ATen: subtract max, exp, normalise.  Returns p0 (p1 = 1 - ... is
+// NOT used: both probabilities are formed from the same exponentials).
+__device__ __forceinline__ void softmax2(float a, float b, float& p0, float& p1) {
+  const float t = expf(-fabsf(a - b));
+  const float inv = __builtin_amdgcn_rcpf(1.0f + t);
+  const float hi = inv, lo = t * inv;
+  const bool a_big = a >= b;
+  p0 = a_big ? hi : lo;
+  p1 = a_big ? lo : hi;
+  if (a != a || b != b) p0 = p1 = a + b;  // NaN propagates as in softmax
+}
+
+template <int C, int MODE>
+__global__ __launch_bounds__(kThreads) void warp_kernel(const Params p) {
+  constexpr int LPP = C / 4;           // lanes per pixel
+  constexpr int PPB = kThreads / LPP;  // pixels per block
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  TapEntry* tab = reinterpret_cast<TapEntry*>(smem);
+
+  const int hw = p.g.h * p.g.w;
+  const int b = blockIdx.y;
+  const int tile = (int)mdf::xcd_remap(blockIdx.x, p.nblk_x);
+  const int pix0 = tile * PPB;
+  const int tid = threadIdx.x;
+  const int pl = tid / LPP;   // pixel inside the block tile
+  const int sub = tid % LPP;  // which 4-channel slice of the pixel
+  const int pix = min(pix0 + pl, hw - 1);
+  const bool live = (pix0 + pl) < hw;
+  const int G = C / 2;
+
+  // per-lane constants
+  float r[4] = {0.f, 0.f, 0.f, 0.f};   // kVec: ref group softmax (p0,p1 | p0,p1); kVar: raw ref
+  float cw0 = 0.f, cw1 = 0.f, alpha = 0.f, beta = 0.f, w2 = 0.f, b2 = 0.f;
+  if (MODE != kWarp) {
+    const float4 rv = *reinterpret_cast<const float4*>(p.ref + ((size_t)b * hw + pix) * C + 4 * sub);
+    if (MODE == kVec) {
+      softmax2(rv.x, rv.y, r[0], r[1]);
+      softmax2(rv.z, rv.w, r[2], r[3]);
+      cw0 = p.wpar[2 * sub];
+      cw1 = p.wpar[2 * sub + 1];
+      alpha = p.wpar[G];
+      beta = p.wpar[G + 1];
+      w2 = p.wpar[G + 2];
+      b2 = p.wpar[G + 3];
+    } else {
+      r[0] = rv.x; r[1] = rv.y; r[2] = rv.z; r[3] = rv.w;
+    }
+  }
+  const size_t map_stride = (size_t)hw * C;
+
+  for (int d0 = 0; d0 < p.D; d0 += p.dchunk) {
+    const int nd = min(p.dchunk, p.D - d0);
+    // ---------------- phase A: one thread per (plane, view, pixel) sample
+    const int nent = nd * p.n_src * PPB;
+    for (int e = tid; e < nent; e += kThreads) {
+      const int epl = e % PPB;
+      const int ev = (e / PPB) % p.n_src;
+      const int ed = e / (PPB * p.n_src);
+      const int epix = min(pix0 + epl, hw - 1);
+      const int yy = epix / p.g.w, xx = epix - yy * p.g.w;
+      const float* m = p.proj + ((size_t)ev * p.B + b) * 12;
+      const int d = d0 + ed;
+      const float dep = p.hypos_per_pixel ? p.hypos[((size_t)b * p.D + d) * hw + epix] : p.hypos[(size_t)b * p.D + d];
+      float ix, iy;
+      warp_position(m, (float)xx, (float)yy, dep, p.g, ix, iy);
+      TapEntry t;
+      make_taps(ix, iy, p.g, C, t);
+      tab[e] = t;
+    }
+    __syncthreads();
+    // ---------------- phase B
+    for (int dd = 0; dd < nd; ++dd) {
+      const int d = d0 + dd;
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      float acc2[4] = {0.f, 0.f, 0.f, 0.f};
+      float wsum = 0.f;
+      if (MODE == kVar) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { acc[k] = r[k]; acc2[k] = r[k] * r[k]; }
+      }
+      for (int v = 0; v < p.n_src; ++v) {
+        const TapEntry t = tab[(dd * p.n_src + v) * PPB + pl];
+        const float* sp = p.src[v] + (size_t)b * map_stride + 4 * sub;
+        const float4 nw = *reinterpret_cast<const float4*>(sp + t.off[0]);
+        const float4 ne = *reinterpret_cast<const float4*>(sp + t.off[1]);
+        const float4 sw = *reinterpret_cast<const float4*>(sp + t.off[2]);
+        const float4 se = *reinterpret_cast<const float4*>(sp + t.off[3]);
+        float val[4];
+        // ATen tap order: nw*w + ne*w + sw*w + se*w, each step one fma
+        val[0] = __fmaf_rn(se.x, t.wt[3], __fmaf_rn(sw.x, t.wt[2], __fmaf_rn(ne.x, t.wt[1], __fmul_rn(nw.x, t.wt[0]))));
+        val[1] = __fmaf_rn(se.y, t.wt[3], __fmaf_rn(sw.y, t.wt[2], __fmaf_rn(ne.y, t.wt[1], __fmul_rn(nw.y, t.wt[0]))));
+        val[2] = __fmaf_rn(se.z, t.wt[3], __fmaf_rn(sw.z, t.wt[2], __fmaf_rn(ne.z, t.wt[1], __fmul_rn(nw.z, t.wt[0]))));
+        val[3] = __fmaf_rn(se.w, t.wt[3], __fmaf_rn(sw.w, t.wt[2], __fmaf_rn(ne.w, t.wt[1], __fmul_rn(nw.w, t.wt[0]))));
+        if (MODE == kWarp) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[k] = val[k];
+        } else if (MODE == kVec) {
+          float s0, s1, q0, q1;
+          softmax2(val[0], val[1], s0, s1);
+          softmax2(val[2], val[3], q0, q1);
+          const float sim0 = s0 * r[0] + s1 * r[1];   // homoaggregate.py:39
+          const float sim1 = q0 * r[2] + q1 * r[3];
+          const float z = pixel_sum<LPP>(cw0 * sim0 + cw1 * sim1);     // Conv3d(G->1, 1x1x1)
+          const float u = fmaxf(z * alpha + beta, 0.0f) * w2 + b2;     // BN(eval) -> ReLU -> Conv3d(1->1)
+          const float wv = 1.0f / (1.0f + expf(-u));                   // Sigmoid
+          wsum += wv;
+          acc[0] += wv * sim0;
+          acc[1] += wv * sim1;
+        } else {  // kVar: softmax over all C channels of this pixel (homoaggregate.py:60)
+          const float mx = pixel_max<LPP>(fmaxf(fmaxf(val[0], val[1]), fmaxf(val[2], val[3])));
+          float e[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) e[k] = expf(val[k] - mx);
+          const float den = pixel_sum<LPP>((e[0] + e[1]) + (e[2] + e[3]));
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float pr = e[k] / den;
+            acc[k] += pr;
+            acc2[k] += pr * pr;
+          }
+        }
+      }
+      if (!live) continue;
+      const size_t vox = ((size_t)b * p.D + d) * hw + pix;
+      if (MODE == kVec) {
+        const float o0 = acc[0] / wsum, o1 = acc[1] / wsum;  // homoaggregate.py:46
+        if (p.out_ndhwc) {
+          *reinterpret_cast<float2*>(p.out + vox * G + 2 * sub) = make_float2(o0, o1);
+        } else {
+          const size_t cs = (size_t)p.D * hw;
+          float* o = p.out + ((size_t)b * G * p.D + d) * hw + pix;
+          o[(size_t)(2 * sub) * cs] = o0;
+          o[(size_t)(2 * sub + 1) * cs] = o1;
+        }
+      } else {
+        float o[4];
+        if (MODE == kVar) {
+          const float n = (float)(p.n_src + 1);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float mean = acc[k] / n;
+            o[k] = acc2[k] / n - mean * mean;  // homoaggregate.py:66
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = acc[k];
+        }
+        if (p.out_ndhwc) {
+          *reinterpret_cast<float4*>(p.out + vox * C + 4 * sub) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+          const size_t cs = (size_t)p.D * hw;
+          float* op = p.out + ((size_t)b * C * p.D + d) * hw + pix;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) op[(size_t)(4 * sub + k) * cs] = o[k];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void corner_index_kernel(const float* __restrict__ proj, const float* __restrict__ hypos, int per_pixel,
+                                    int32_t* __restrict__ out, Geom g, int B, int D) {
+  const int hw = g.h * g.w;
+  const size_t n = (size_t)B * D * hw;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int pix = (int)(i % hw);
+    const int d = (int)((i / hw) % D);
+    const int b = (int)(i / ((size_t)hw * D));
+    const int yy = pix / g.w, xx = pix - yy * g.w;
+    const float dep = per_pixel ? hypos[i] : hypos[(size_t)b * D + d];
+    float ix, iy;
+    warp_position(proj + (size_t)b * 12, (float)xx, (float)yy, dep, g, ix, iy);
+    const float lim = 1073741824.0f;
+    const bool fin = (fabsf(ix) <= 3.0e38f) && (fabsf(iy) <= 3.0e38f);  // false for NaN/inf
+    int32_t x0 = INT32_MIN, y0 = INT32_MIN;
+    if (fin) {
+      x0 = (int32_t)fminf(fmaxf(floorf(ix), -lim), lim);
+      y0 = (int32_t)fminf(fmaxf(floorf(iy), -lim), lim);
+    }
+    out[2 * i] = x0;
+    out[2 * i + 1] = y0;
+  }
+}
+
+Geom make_geom(int h, int w) {
+  Geom g;
+  g.w = w;
+  g.h = h;
+  g.half_w = (float)((double)(w - 1) / 2.0);
+  g.half_h = (float)((double)(h - 1) / 2.0);
+  g.sw = (float)((double)w / 2.0);
+  g.sh = (float)((double)h / 2.0);
+  return g;
+}
+
+template <int MODE>
+int launch(Params& p, int C, hipStream_t st) {
+  const int lpp = C / 4, ppb = kThreads / lpp;
+  const int hw = p.g.h * p.g.w;
+  p.nblk_x = (hw + ppb - 1) / ppb;
+  int dch = 512 / (p.n_src * ppb);  // ~16 KiB of tap table per block
+  if (dch < 1) dch = 1;
+  if (dch > p.D) dch = p.D;
+  p.dchunk = dch;
+  const size_t lds = (size_t)dch * p.n_src * ppb * sizeof(TapEntry);
+  dim3 grid(p.nblk_x, p.B), block(kThreads);
+  switch (C) {
+    case 64: hipLaunchKernelGGL((warp_kernel<64, MODE>), grid, block, lds, st, p); break;
+    case 32: hipLaunchKernelGGL((warp_kernel<32, MODE>), grid, block, lds, st, p); break;
+    case 16: hipLaunchKernelGGL((warp_kernel<16, MODE>), grid, block, lds, st, p); break;
+    default: return mdf::fail(MDF_EUNSUPPORTED, "warp kernels are built for C in {16,32,64}, got %d", C);
+  }
+  return mdf::check_launch("warp_kernel");
+}
+
+int check_common(const void* a, const void* b, const void* c, const void* d, int fea_layout, int B, int C, int D, int h,
+                 int w) {
+  MDF_REQUIRE(a && b && c && d, "null pointer argument");
+  MDF_REQUIRE(B > 0 && D > 0 && h > 1 && w > 1, "bad shape B=%d D=%d h=%d w=%d", B, D, h, w);
+  MDF_REQUIRE((long long)h * w * C < (1ll << 31), "feature map too large for 32-bit tap offsets");
+  if (fea_layout != MDF_FEA_NHWC)
+    return mdf::fail(MDF_EUNSUPPORTED, "feature layout %d not supported (kernels gather NHWC taps)", fea_layout);
+  if (C != 16 && C != 32 && C != 64)
+    return mdf::fail(MDF_EUNSUPPORTED, "C=%d not supported (built for 16, 32, 64)", C);
+  return MDF_OK;
+}
+
+}  // namespace
+
+extern "C" int mdf_homo_warp_fwd(const float* src_fea, int fea_layout, const float* proj, const float* hypos,
+                                 int hypos_per_pixel, float* out, int out_layout, int B, int C, int D, int h, int w,
+                                 void* stream) {
+  if (int rc = check_common(src_fea, proj, hypos, out, fea_layout, B, C, D, h, w)) return rc;
+  Params p{};
+  p.src[0] = src_fea;
+  p.proj = proj;
+  p.hypos = hypos;
+  p.out = out;
+  p.g = make_geom(h, w);
+  p.B = B; p.D = D; p.n_src = 1; p.hypos_per_pixel = hypos_per_pixel; p.out_ndhwc = (out_layout == MDF_VOL_NDHWC);
+  return launch<kWarp>(p, C, (hipStream_t)stream);
+}
+
+extern "C" int mdf_warp_corner_indices(const float* proj, const float* hypos, int hypos_per_pixel, int32_t* x0y0,
+                                       int B, int D, int h, int w, void* stream) {
+  MDF_REQUIRE(proj && hypos && x0y0, "null pointer argument");
+  MDF_REQUIRE(B > 0 && D > 0 && h > 1 && w > 1, "bad shape");
+  const size_t n = (size_t)B * D * h * w;
+  const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(corner_index_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, proj, hypos, hypos_per_pixel,
+                     x0y0, make_geom(h, w), B, D);
+  return mdf::check_launch("corner_index_kernel");
+}
+
+extern "C" int mdf_warp_aggregate_vec_fwd(const float* ref_fea, const float* const* src_feas, int fea_layout,
+                                          const float* proj, const float* hypos, int hypos_per_pixel,
+                                          const float* w_params, float* cost, int cost_layout, int B, int C, int G,
+                                          int D, int h, int w, int n_src, void* stream) {
+  if (int rc = check_common(ref_fea, proj, hypos, cost, fea_layout, B, C, D, h, w)) return rc;
+  MDF_REQUIRE(src_feas && w_params, "null pointer argument");
+  MDF_REQUIRE(n_src >= 1 && n_src <= MDF_MAX_SRC_VIEWS, "n_src=%d out of range [1,%d]", n_src, MDF_MAX_SRC_VIEWS);
+  if (G * 2 != C) return mdf::fail(MDF_EUNSUPPORTED, "only C/G == 2 is built (C=%d, G=%d)", C, G);
+  Params p{};
+  p.ref = ref_fea;
+  for (int v = 0; v < n_src; ++v) {
+    MDF_REQUIRE(src_feas[v], "src_feas[%d] is null", v);
+    p.src[v] = src_feas[v];
+  }
+  p.proj = proj; p.hypos = hypos; p.wpar = w_params; p.out = cost;
+  p.g = make_geom(h, w);
+  p.B = B; p.D = D; p.n_src = n_src; p.hypos_per_pixel = hypos_per_pixel; p.out_ndhwc = (cost_layout == MDF_VOL_NDHWC);
+  return launch<kVec>(p, C, (hipStream_t)stream);
+}
+
+extern "C" int mdf_warp_aggregate_var_fwd(const float* ref_fea, const float* const* src_feas, int fea_layout,
+                                          const float* proj, const float* hypos, int hypos_per_pixel, float* cost,
+                                          int cost_layout, int B, int C, int D, int h, int w, int n_src, void* stream) {
+  if (int rc = check_common(ref_fea, proj, hypos, cost, fea_layout, B, C, D, h, w)) return rc;
+  MDF_REQUIRE(src_feas, "null pointer argument");
+  MDF_REQUIRE(n_src >= 1 && n_src <= MDF_MAX_SRC_VIEWS, "n_src=%d out of range [1,%d]", n_src, MDF_MAX_SRC_VIEWS);
+  Params p{};
+  p.ref = ref_fea;
+  for (int v = 0; v < n_src; ++v) {
+    MDF_REQUIRE(src_feas[v], "src_feas[%d] is null", v);
+    p.src[v] = src_feas[v];
+  }
+  p.proj = proj; p.hypos = hypos; p.out = cost;
+  p.g = make_geom(h, w);
+  p.B = B; p.D = D; p.n_src = n_src; p.hypos_per_pixel = hypos_per_pixel; p.out_ndhwc = (cost_layout == MDF_VOL_NDHWC);
+  return launch<kVar>(p, C, (hipStream_t)stream);
+}

@@ -1,0 +1,70 @@
+"""ctypes binding of libmdfnet_hip.so (C ABI: include/mdfnet_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails, an exception is
+raised.  Build it with `python -m mdfnet_hip.build` (or __graft_entry__.build()).
+"""
+import ctypes
+import os
+import threading
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libmdfnet_hip.so")
+ABI_VERSION = 1
+
+_lib = None
+_lock = threading.Lock()
+
+c_fp = ctypes.c_void_p  # device pointers are passed as integers (tensor.data_ptr())
+c_int = ctypes.c_int
+c_i64 = ctypes.c_int64
+
+# name -> (restype, argtypes); mirrors include/mdfnet_hip.h one to one
+SIGNATURES = {
+    "mdf_abi_version": (c_int, []),
+    "mdf_last_error": (ctypes.c_char_p, []),
+    "mdf_homo_warp_fwd": (c_int, [c_fp, c_int, c_fp, c_fp, c_int, c_fp, c_int] + [c_int] * 5 + [c_fp]),
+    "mdf_warp_corner_indices": (c_int, [c_fp, c_fp, c_int, c_fp] + [c_int] * 4 + [c_fp]),
+    "mdf_warp_aggregate_vec_fwd": (c_int, [c_fp, ctypes.POINTER(c_fp), c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_int]
+                                   + [c_int] * 7 + [c_fp]),
+    "mdf_warp_aggregate_var_fwd": (c_int, [c_fp, ctypes.POINTER(c_fp), c_int, c_fp, c_fp, c_int, c_fp, c_int]
+                                   + [c_int] * 6 + [c_fp]),
+    "mdf_conv3d_fwd": (c_int, [c_fp] * 6 + [c_int] * 9 + [c_fp]),
+    "mdf_conv3d_packed_size": (c_i64, [c_int, c_int]),
+    "mdf_conv3d_pack_weights": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp]),
+    "mdf_prob_softmax_regress_fwd": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp, c_fp] + [c_int] * 5 + [c_fp]),
+    "mdf_depth_regress_fwd": (c_int, [c_fp, c_fp, c_int, c_fp] + [c_int] * 4 + [c_fp]),
+    "mdf_confidence_fwd": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 4 + [c_fp]),
+    "mdf_hypos_fit_fwd": (c_int, [c_int, c_fp, c_fp, c_fp, c_int, c_fp, c_fp] + [c_int] * 4 + [c_fp]),
+    "mdf_hypos_from_fit_fwd": (c_int, [c_int, c_fp, c_fp, c_fp, ctypes.c_float, c_fp] + [c_int] * 5 + [c_fp]),
+}
+
+
+class MdfHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP extension is not built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise MdfHipError(
+                        f"{LIB_PATH} not found: the HIP extension is not built and there is no fallback path. "
+                        "Run `python -m mdfnet_hip.build` (needs hipcc, --offload-arch=gfx950).")
+                h = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(h, name)  # AttributeError if the .so is stale
+                    fn.restype = res
+                    fn.argtypes = args
+                if h.mdf_abi_version() != ABI_VERSION:
+                    raise MdfHipError(f"ABI version mismatch: library {h.mdf_abi_version()}, binding {ABI_VERSION}")
+                _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().mdf_last_error().decode("utf-8", "replace")
+        raise MdfHipError(f"{what} failed with code {rc}: {msg}")

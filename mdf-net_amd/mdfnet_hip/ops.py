@@ -1,0 +1,194 @@
+"""Torch-facing wrappers over the C ABI (include/mdfnet_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every operator below is one
+(or a few) hand-written HIP kernels.  No fallback: tensors must live on a HIP device.
+"""
+import ctypes
+
+import torch
+
+from . import check, lib
+
+FEA_NHWC = 1
+VOL_NCDHW, VOL_NDHWC = 0, 1
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("mdfnet_hip ops run on an MI355X only (got a CPU tensor); there is no CPU fallback")
+
+
+def _f32c(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+def nhwc(t):
+    """[B,C,h,w] -> same logical tensor whose memory is [B,h,w,C] (no copy when already so)."""
+    return t.float().contiguous(memory_format=torch.channels_last)
+
+
+def relative_projections(ref_proj, src_projs):
+    """HOST side of homo_warping (base.py:98): (src_proj @ inverse(ref_proj))[:3,:4] for every source
+    view, computed on the CPU with the reference's own torch calls so the kernel consumes the same
+    12 floats as the oracle (GPU and CPU `torch.inverse` use different solvers).  -> [n_src,B,12] CPU."""
+    ref = ref_proj.detach().to("cpu", torch.float32)
+    inv = torch.inverse(ref)
+    rows = [torch.matmul(sp.detach().to("cpu", torch.float32), inv)[:, :3, :4].reshape(-1, 12) for sp in src_projs]
+    return torch.stack(rows, 0).contiguous()
+
+
+def _hypos_arg(hypos, h, w):
+    per_pixel = int(hypos.shape[-1] != 1 or hypos.shape[-2] != 1)
+    if per_pixel and (hypos.shape[-2] != h or hypos.shape[-1] != w):
+        raise ValueError(f"depth_hypos {tuple(hypos.shape)} does not match feature size {(h, w)}")
+    return _f32c(hypos), per_pixel
+
+
+def homo_warp(src_fea, proj12, depth_hypos):
+    """net/unit/base.py:85-126 with proj12 = relative_projections(...)[v] on device -> [B,C,D,h,w]."""
+    _need_gpu(src_fea, proj12, depth_hypos)
+    b, c, h, w = src_fea.shape
+    d = depth_hypos.shape[1]
+    fea = nhwc(src_fea)
+    hyp, pp = _hypos_arg(depth_hypos, h, w)
+    out = torch.empty((b, c, d, h, w), device=src_fea.device, dtype=torch.float32)
+    check(lib().mdf_homo_warp_fwd(fea.data_ptr(), FEA_NHWC, _f32c(proj12).data_ptr(), hyp.data_ptr(), pp,
+                                  out.data_ptr(), VOL_NCDHW, b, c, d, h, w, _stream(out)), "mdf_homo_warp_fwd")
+    return out
+
+
+def warp_corner_indices(proj12, depth_hypos, h, w):
+    """int32 [B,D,h,w,2] = (floor(ix), floor(iy)) of every sample (indexing-parity test hook)."""
+    _need_gpu(proj12, depth_hypos)
+    b, d = depth_hypos.shape[:2]
+    hyp, pp = _hypos_arg(depth_hypos, h, w)
+    out = torch.empty((b, d, h, w, 2), device=proj12.device, dtype=torch.int32)
+    check(lib().mdf_warp_corner_indices(_f32c(proj12).data_ptr(), hyp.data_ptr(), pp, out.data_ptr(), b, d, h, w,
+                                        _stream(out)), "mdf_warp_corner_indices")
+    return out
+
+
+def _src_array(srcs):
+    arr = (ctypes.c_void_p * len(srcs))(*[s.data_ptr() for s in srcs])
+    return arr
+
+
+def warp_aggregate_vec(features, proj, depth_hypos, w_params, ngroups, channels_last=True):
+    """Fused VectorAggregate.forward (eval).  features: list of V [B,C,h,w]; proj [n_src,B,12] device;
+    w_params [G+4] device.  Returns cost with logical shape [B,G,D,h,w]; memory is NDHWC when
+    channels_last (what the 3-D conv kernels consume) else NCDHW."""
+    _need_gpu(*features, proj, depth_hypos, w_params)
+    feas = [nhwc(f) for f in features]
+    b, c, h, w = feas[0].shape
+    d = depth_hypos.shape[1]
+    hyp, pp = _hypos_arg(depth_hypos, h, w)
+    g = ngroups
+    dev = feas[0].device
+    if channels_last:
+        mem = torch.empty((b, d, h, w, g), device=dev, dtype=torch.float32)
+        cost = mem.permute(0, 4, 1, 2, 3)
+    else:
+        mem = cost = torch.empty((b, g, d, h, w), device=dev, dtype=torch.float32)
+    srcs = feas[1:]
+    check(lib().mdf_warp_aggregate_vec_fwd(feas[0].data_ptr(), _src_array(srcs), FEA_NHWC, _f32c(proj).data_ptr(),
+                                           hyp.data_ptr(), pp, _f32c(w_params).data_ptr(), mem.data_ptr(),
+                                           VOL_NDHWC if channels_last else VOL_NCDHW, b, c, g, d, h, w, len(srcs),
+                                           _stream(mem)), "mdf_warp_aggregate_vec_fwd")
+    return cost
+
+
+def warp_aggregate_var(features, proj, depth_hypos, channels_last=False):
+    """Fused homo_aggregate_by_variance (homoaggregate.py:49-69) -> [B,C,D,h,w]."""
+    _need_gpu(*features, proj, depth_hypos)
+    feas = [nhwc(f) for f in features]
+    b, c, h, w = feas[0].shape
+    d = depth_hypos.shape[1]
+    hyp, pp = _hypos_arg(depth_hypos, h, w)
+    dev = feas[0].device
+    if channels_last:
+        mem = torch.empty((b, d, h, w, c), device=dev, dtype=torch.float32)
+        cost = mem.permute(0, 4, 1, 2, 3)
+    else:
+        mem = cost = torch.empty((b, c, d, h, w), device=dev, dtype=torch.float32)
+    srcs = feas[1:]
+    check(lib().mdf_warp_aggregate_var_fwd(feas[0].data_ptr(), _src_array(srcs), FEA_NHWC, _f32c(proj).data_ptr(),
+                                           hyp.data_ptr(), pp, mem.data_ptr(),
+                                           VOL_NDHWC if channels_last else VOL_NCDHW, b, c, d, h, w, len(srcs),
+                                           _stream(mem)), "mdf_warp_aggregate_var_fwd")
+    return cost
+
+
+def fold_view_weight(p, ngroups, prefix="depth_weight."):
+    """depth_weight head parameters -> device tensor [G+4] = (conv weight[G], alpha, beta, w2, b2) with
+    BatchNorm3d(1) folded as ATen does in eval (alpha = gamma/sqrt(var+eps), beta = bias - mean*alpha)."""
+    cw = p[prefix + "0.conv.weight"].reshape(ngroups).float()
+    invstd = 1.0 / torch.sqrt(p[prefix + "0.bn.running_var"].float() + 1e-5)
+    alpha = p[prefix + "0.bn.weight"].float() * invstd
+    beta = p[prefix + "0.bn.bias"].float() - p[prefix + "0.bn.running_mean"].float() * alpha
+    return torch.cat([cw, alpha.reshape(1), beta.reshape(1), p[prefix + "1.weight"].reshape(1).float(),
+                      p[prefix + "1.bias"].reshape(1).float()]).contiguous()
+
+
+# --------------------------------------------------------------------------- regression heads
+def depth_regress(prob, depth_hypos):
+    """net/unit/regress.py:5-7."""
+    _need_gpu(prob, depth_hypos)
+    b, d, h, w = prob.shape
+    hyp, pp = _hypos_arg(depth_hypos, h, w)
+    prob = _f32c(prob)
+    out = torch.empty((b, h, w), device=prob.device, dtype=torch.float32)
+    check(lib().mdf_depth_regress_fwd(prob.data_ptr(), hyp.data_ptr(), pp, out.data_ptr(), b, d, h, w, _stream(out)),
+          "mdf_depth_regress_fwd")
+    return out
+
+
+def confidence(prob, return_index=False):
+    """net/unit/regress.py:9-25 (n=4, pad=(1,2))."""
+    _need_gpu(prob)
+    b, d, h, w = prob.shape
+    prob = _f32c(prob)
+    out = torch.empty((b, h, w), device=prob.device, dtype=torch.float32)
+    idx = torch.empty((b, h, w), device=prob.device, dtype=torch.int64) if return_index else None
+    check(lib().mdf_confidence_fwd(prob.data_ptr(), out.data_ptr(), idx.data_ptr() if return_index else None,
+                                   b, d, h, w, _stream(out)), "mdf_confidence_fwd")
+    return (out, idx) if return_index else out
+
+
+def gauss1_fit_row(depth_hypos):
+    """HOST: row 0 of (X^T X)^-1 X^T for hypotheses [B,D,1,1] shared by every pixel, with the same
+    torch CPU calls as depthhypos.py:199-208 (cond(X^T X) ~ 1e14 in fp32: the bits of this inverse ARE the
+    reference's behaviour).  -> [B,D] CPU float32."""
+    hyp = depth_hypos.detach().to("cpu", torch.float32).reshape(depth_hypos.shape[0], -1)
+    x = torch.stack([hyp ** 2, hyp, torch.ones_like(hyp)], dim=-1)
+    xt = x.transpose(-1, -2)
+    return torch.matmul(torch.inverse(torch.matmul(xt, x)), xt)[:, 0, :].contiguous()
+
+
+def hypos_fit(mode, prob, depth, depth_hypos, fit_row=None):
+    """Step 1 of HyposByFit: per-pixel curve parameter s [B,h,w].  mode 1 gauss1, 2 laplace."""
+    _need_gpu(prob)
+    b, d, h, w = prob.shape
+    prob = _f32c(prob)
+    hyp, pp = _hypos_arg(depth_hypos, h, w)
+    out = torch.empty((b, h, w), device=prob.device, dtype=torch.float32)
+    check(lib().mdf_hypos_fit_fwd(mode, prob.data_ptr(), None if depth is None else _f32c(depth).data_ptr(),
+                                  hyp.data_ptr(), pp, None if fit_row is None else _f32c(fit_row).data_ptr(),
+                                  out.data_ptr(), b, d, h, w, _stream(out)), "mdf_hypos_fit_fwd")
+    return out
+
+
+def hypos_from_fit(mode, s, depth, depth_range_f32, log_thresh, ndepths, upsample=True):
+    """Step 2 of HyposByFit (depthhypos.py:49-76) -> [B,D,2h,2w] (or [B,D,h,w])."""
+    _need_gpu(s, depth, depth_range_f32)
+    b, h, w = s.shape
+    ho, wo = (2 * h, 2 * w) if upsample else (h, w)
+    out = torch.empty((b, ndepths, ho, wo), device=s.device, dtype=torch.float32)
+    check(lib().mdf_hypos_from_fit_fwd(mode, _f32c(s).data_ptr(), _f32c(depth).data_ptr(),
+                                       _f32c(depth_range_f32).data_ptr(), ctypes.c_float(log_thresh), out.data_ptr(),
+                                       b, ndepths, h, w, int(upsample), _stream(out)), "mdf_hypos_from_fit_fwd")
+    return out
