@@ -1,14 +1,276 @@
-// placeholder: implemented next
+// 3-D convolution layers of the cost regularisers (net/unit/regular.py:9-133, base.py:50-68) as an
+// implicit GEMM on the fp32 matrix cores of gfx950 (v_mfma_f32_16x16x4_f32: exact f32 fma chain, so
+// results differ from the reference only by summation order).
+//
+// Data layout: activations NDHWC (the aggregation kernel writes the cost volume in this layout), so the
+// Cin values of one voxel are contiguous and one MFMA B-fragment (16 voxels x 16 cin) is a single
+// coalesced 1-KiB wavefront load.  GEMM orientation is  D[cout][voxel] = W[cout][k] * X[k][voxel]:
+//   A operand (weights)     lane l holds W[cout = l&15][k = l>>4]
+//   B operand (activations) lane l holds X[k = l>>4][voxel = l&15]
+//   C/D                     lane l holds couts 4*(l>>4)..+3 of voxel l&15  -> one 16-B store per lane,
+//                           the 4 lanes of a voxel write 64 contiguous bytes (NDHWC output).
+// K is walked tap by tap; inside a tap the k order is permuted so that lane group q = l>>4 owns cin
+// {KPL*q .. KPL*q+KPL-1} of a chunk: a lane fetches its KPL consecutive cin with ONE 8/16-byte load and
+// feeds them to KPL successive MFMAs.  Weights are pre-packed on the device into exactly that fragment
+// order (mdf_conv3d_pack_weights), so an A fragment is also one coalesced load.
+//
+// Epilogue (fused): y = [res +] [relu]( acc * alpha + beta )   (BatchNorm3d folded as ATen does in eval).
+//
+// Modes: stride 1, stride 2, and ConvTranspose3d(k3,s2,p1,op1).  The transposed conv is computed per
+// output parity class (blockIdx.y = 0..7): inside a class every output voxel uses the same 1/2/4/8 taps,
+// so no MFMA is spent on structurally-zero taps.
 #include "common.h"
-extern "C" int mdf_conv3d_fwd(const float*, const float*, const float*, const float*, const float*, float*, int, int, int,
-                              int, int, int, int, int, int, void*) {
-  return mdf::fail(MDF_EUNSUPPORTED, "mdf_conv3d_fwd not built yet");
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum ConvMode { kS1 = 0, kS2 = 1, kTr = 2 };
+
+struct ConvParams {
+  const float* x;
+  const float* wpack;
+  const float* alpha;
+  const float* beta;
+  const float* res;
+  float* y;
+  int B, Di, Hi, Wi, Do, Ho, Wo;
+  int relu;
+  long long m_total;  // voxels in the M index space (per parity class for kTr)
+  unsigned nblk;
+};
+
+template <int KPL>
+struct Frag;
+template <>
+struct Frag<4> {
+  float v[4];
+  __device__ __forceinline__ void load(const float* p) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  __device__ __forceinline__ void zero() { v[0] = v[1] = v[2] = v[3] = 0.f; }
+};
+template <>
+struct Frag<2> {
+  float v[2];
+  __device__ __forceinline__ void load(const float* p) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    v[0] = t.x; v[1] = t.y;
+  }
+  __device__ __forceinline__ void zero() { v[0] = v[1] = 0.f; }
+};
+
+template <int CIN, int COUT, int MODE, int MT>
+__global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
+  constexpr int KPL = (CIN >= 16) ? 4 : 2;   // k values per lane per chunk
+  constexpr int CK = 4 * KPL;                // cin per chunk
+  constexpr int NCH = CIN / CK;
+  constexpr int NT = (COUT + 15) / 16;
+  static_assert(CIN % CK == 0, "CIN must be a multiple of the chunk");
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int q = lane >> 4;    // k sub-slot / cout quad
+  const int n16 = lane & 15;  // voxel inside the m-tile (B operand, C/D column)
+  const unsigned tile_blk = mdf::xcd_remap(blockIdx.x, p.nblk);
+  const long long m0 = ((long long)tile_blk * 4 + wave) * (MT * 16);
+
+  // transposed: parity class of this block
+  const int pc = (MODE == kTr) ? blockIdx.y : 0;
+  const int pd = (pc >> 2) & 1, ph = (pc >> 1) & 1, pw = pc & 1;
+
+  // per-lane voxel bookkeeping for each m-tile
+  int in_off[MT];       // float offset of the base input voxel (channel 0)
+  long long out_vox[MT];
+  unsigned vmask[MT];   // bits 0-2: kd valid, 3-5: kh valid, 6-8: kw valid
+  bool live[MT];
+  // index space dims (output dims for S1/S2, input dims for Tr)
+  const int Md = (MODE == kTr) ? p.Di : p.Do, Mh = (MODE == kTr) ? p.Hi : p.Ho, Mw = (MODE == kTr) ? p.Wi : p.Wo;
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    long long m = m0 + t * 16 + n16;
+    live[t] = m < p.m_total;
+    if (!live[t]) m = p.m_total - 1;
+    const int mw = (int)(m % Mw);
+    long long r = m / Mw;
+    const int mh = (int)(r % Mh);
+    r /= Mh;
+    const int md = (int)(r % Md);
+    const int b = (int)(r / Md);
+    int bd, bh, bw;  // base input coordinate
+    unsigned vm = 0;
+    if (MODE == kS1) { bd = md; bh = mh; bw = mw; }
+    else if (MODE == kS2) { bd = 2 * md; bh = 2 * mh; bw = 2 * mw; }
+    else { bd = md; bh = mh; bw = mw; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      int od, oh, ow;
+      if (MODE == kTr) { od = oh = ow = (k == 0) ? 1 : 0; }
+      else { od = oh = ow = k - 1; }
+      if (bd + od >= 0 && bd + od < p.Di) vm |= 1u << k;
+      if (bh + oh >= 0 && bh + oh < p.Hi) vm |= 8u << k;
+      if (bw + ow >= 0 && bw + ow < p.Wi) vm |= 64u << k;
+    }
+    vmask[t] = live[t] ? vm : 0u;
+    in_off[t] = (int)((((long long)b * p.Di + bd) * p.Hi + bh) * p.Wi + bw) * CIN;
+    if (MODE == kTr)
+      out_vox[t] = (((long long)b * p.Do + (2 * md + pd)) * p.Ho + (2 * mh + ph)) * p.Wo + (2 * mw + pw);
+    else
+      out_vox[t] = m;
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const float* xq = p.x + KPL * q;                       // this lane's cin slot inside a chunk
+  const float* wl = p.wpack + (size_t)lane * KPL;        // this lane's slot inside a packed 64-lane fragment
+
+  for (int tap = 0; tap < 27; ++tap) {
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    int od, oh, ow;
+    if (MODE == kTr) {
+      // output parity p uses kernel taps with (k + p) odd: p=0 -> k=1 ; p=1 -> k=0 (input i'+1), k=2 (input i')
+      if ((((kd + pd) & 1) == 0) || (((kh + ph) & 1) == 0) || (((kw + pw) & 1) == 0)) continue;
+      od = (kd == 0); oh = (kh == 0); ow = (kw == 0);
+    } else {
+      od = kd - 1; oh = kh - 1; ow = kw - 1;
+    }
+    const int tapoff = ((od * p.Hi + oh) * p.Wi + ow) * CIN;
+    const unsigned need = (1u << kd) | (8u << kh) | (64u << kw);
+    const float* wt = wl + (size_t)tap * (NCH * NT * 64 * KPL);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      Frag<KPL> bf[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        if ((vmask[t] & need) == need) bf[t].load(xq + in_off[t] + tapoff + ch * CK);
+        else bf[t].zero();
+      }
+      Frag<KPL> af[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) af[nt].load(wt + (size_t)(ch * NT + nt) * (64 * KPL));
+#pragma unroll
+      for (int s = 0; s < KPL; ++s)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[nt].v[s], bf[t].v[s], acc[t][nt], 0, 0, 0);
+    }
+  }
+
+  // epilogue: lane owns couts nt*16 + 4q .. +3 of voxel out_vox[t]
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int c0 = nt * 16 + 4 * q;
+    if (c0 >= COUT) continue;
+    float4 al = make_float4(1.f, 1.f, 1.f, 1.f), be = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.alpha) {
+      al = *reinterpret_cast<const float4*>(p.alpha + c0);
+      be = *reinterpret_cast<const float4*>(p.beta + c0);
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      if (!live[t]) continue;
+      float4 o;
+      o.x = acc[t][nt][0] * al.x + be.x;
+      o.y = acc[t][nt][1] * al.y + be.y;
+      o.z = acc[t][nt][2] * al.z + be.z;
+      o.w = acc[t][nt][3] * al.w + be.w;
+      if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      const size_t oi = (size_t)out_vox[t] * COUT + c0;
+      if (p.res) {
+        const float4 rr = *reinterpret_cast<const float4*>(p.res + oi);
+        o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+      }
+      *reinterpret_cast<float4*>(p.y + oi) = o;
+    }
+  }
 }
-extern "C" int64_t mdf_conv3d_packed_size(int, int) { return 0; }
-extern "C" int mdf_conv3d_pack_weights(const float*, float*, int, int, int, void*) {
-  return mdf::fail(MDF_EUNSUPPORTED, "mdf_conv3d_pack_weights not built yet");
+
+// torch weights -> fragment order  wpack[tap][chunk][nt][q][n][s] = W(cout = nt*16+n, cin = chunk*CK + KPL*q + s, tap)
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int transposed) {
+  const int KPL = (Cin >= 16) ? 4 : 2, CK = 4 * KPL, NCH = Cin / CK, NT = (Cout + 15) / 16;
+  const int total = 27 * NCH * NT * 64 * KPL;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int r = i;
+    const int s = r % KPL; r /= KPL;
+    const int n = r % 16; r /= 16;
+    const int qq = r % 4; r /= 4;
+    const int nt = r % NT; r /= NT;
+    const int ch = r % NCH; r /= NCH;
+    const int tap = r;
+    const int cout = nt * 16 + n, cin = ch * CK + KPL * qq + s;
+    float v = 0.f;
+    if (cout < Cout) v = transposed ? w[((size_t)cin * Cout + cout) * 27 + tap] : w[((size_t)cout * Cin + cin) * 27 + tap];
+    wp[i] = v;
+  }
 }
-extern "C" int mdf_prob_softmax_regress_fwd(const float*, const float*, const float*, int, float*, float*, int, int, int, int,
-                                            int, void*) {
-  return mdf::fail(MDF_EUNSUPPORTED, "mdf_prob_softmax_regress_fwd not built yet");
+
+template <int CIN, int COUT, int MODE, int MT>
+int launch_conv(ConvParams& p, hipStream_t st) {
+  const long long per_blk = 4LL * MT * 16;
+  p.nblk = (unsigned)((p.m_total + per_blk - 1) / per_blk);
+  dim3 grid(p.nblk, MODE == kTr ? 8 : 1), block(256);
+  hipLaunchKernelGGL((conv3d_kernel<CIN, COUT, MODE, MT>), grid, block, 0, st, p);
+  return mdf::check_launch("conv3d_kernel");
+}
+
+template <int CIN, int COUT, int MODE>
+int launch_conv_mt(ConvParams& p, hipStream_t st) {
+  constexpr int MTMAX = (COUT > 32) ? 2 : 4;
+  // small volumes: shrink the wave tile so the grid still covers the 256 CUs a few times over
+  const long long tiles_big = p.m_total / (64LL * MTMAX) * (MODE == kTr ? 8 : 1);
+  if (tiles_big >= 1024) return launch_conv<CIN, COUT, MODE, MTMAX>(p, st);
+  return launch_conv<CIN, COUT, MODE, 1>(p, st);
+}
+
+}  // namespace
+
+extern "C" int64_t mdf_conv3d_packed_size(int Cin, int Cout) {
+  if (Cin < 8 || Cout < 1) return 0;
+  return (int64_t)27 * Cin * (((Cout + 15) / 16) * 16);
+}
+
+extern "C" int mdf_conv3d_pack_weights(const float* w, float* wpack, int Cin, int Cout, int transposed, void* stream) {
+  MDF_REQUIRE(w && wpack, "null pointer argument");
+  MDF_REQUIRE(Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64, "Cin=%d not in {8,16,32,64}", Cin);
+  MDF_REQUIRE(Cout >= 1 && Cout <= 64, "Cout=%d out of range", Cout);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, wpack, Cin, Cout, transposed);
+  return mdf::check_launch("pack_weights_kernel");
+}
+
+#define MDF_CONV_CASE(ci, co, mode)                          \
+  if (Cin == ci && Cout == co && m == mode) return launch_conv_mt<ci, co, mode>(p, (hipStream_t)stream);
+
+extern "C" int mdf_conv3d_fwd(const float* x, const float* wpack, const float* alpha, const float* beta,
+                              const float* res, float* y, int B, int Di, int Hi, int Wi, int Cin, int Cout, int stride,
+                              int transposed, int relu, void* stream) {
+  MDF_REQUIRE(x && wpack && y, "null pointer argument");
+  MDF_REQUIRE((alpha == nullptr) == (beta == nullptr), "alpha and beta must both be given or both be NULL");
+  MDF_REQUIRE(B > 0 && Di > 0 && Hi > 0 && Wi > 0, "bad shape");
+  MDF_REQUIRE(stride == 1 || stride == 2, "stride must be 1 or 2");
+  MDF_REQUIRE(!transposed || stride == 2, "transposed conv is built for stride 2 only");
+  MDF_REQUIRE((long long)B * Di * Hi * Wi * Cin < (1ll << 31), "input volume too large for 32-bit offsets");
+  ConvParams p{};
+  p.x = x; p.wpack = wpack; p.alpha = alpha; p.beta = beta; p.res = res; p.y = y;
+  p.B = B; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.relu = relu;
+  const int m = transposed ? kTr : (stride == 2 ? kS2 : kS1);
+  if (m == kS1) { p.Do = Di; p.Ho = Hi; p.Wo = Wi; }
+  else if (m == kS2) { p.Do = (Di - 1) / 2 + 1; p.Ho = (Hi - 1) / 2 + 1; p.Wo = (Wi - 1) / 2 + 1; }
+  else { p.Do = 2 * Di; p.Ho = 2 * Hi; p.Wo = 2 * Wi; }
+  p.m_total = (m == kTr) ? (long long)B * Di * Hi * Wi : (long long)B * p.Do * p.Ho * p.Wo;
+  // stride 1 (every Cin x Cout the nets use)
+  MDF_CONV_CASE(32, 16, kS1) MDF_CONV_CASE(16, 16, kS1) MDF_CONV_CASE(32, 32, kS1) MDF_CONV_CASE(64, 64, kS1)
+  MDF_CONV_CASE(16, 8, kS1) MDF_CONV_CASE(8, 8, kS1) MDF_CONV_CASE(8, 16, kS1) MDF_CONV_CASE(16, 32, kS1)
+  // stride 2
+  MDF_CONV_CASE(16, 32, kS2) MDF_CONV_CASE(32, 64, kS2) MDF_CONV_CASE(8, 16, kS2)
+  // transposed
+  MDF_CONV_CASE(64, 32, kTr) MDF_CONV_CASE(32, 16, kTr) MDF_CONV_CASE(16, 8, kTr)
+  return mdf::fail(MDF_EUNSUPPORTED, "conv3d Cin=%d Cout=%d stride=%d transposed=%d is not built", Cin, Cout, stride,
+                   transposed);
 }

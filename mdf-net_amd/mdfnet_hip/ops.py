@@ -192,3 +192,71 @@ def hypos_from_fit(mode, s, depth, depth_range_f32, log_thresh, ndepths, upsampl
                                        _f32c(depth_range_f32).data_ptr(), ctypes.c_float(log_thresh), out.data_ptr(),
                                        b, ndepths, h, w, int(upsample), _stream(out)), "mdf_hypos_from_fit_fwd")
     return out
+
+
+# --------------------------------------------------------------------------- 3-D conv layers (NDHWC)
+def to_ndhwc(t):
+    """logical [B,C,D,H,W] -> contiguous [B,D,H,W,C] tensor (no copy when the memory already is)."""
+    cl = t.permute(0, 2, 3, 4, 1)
+    return cl if (cl.is_contiguous() and cl.dtype == torch.float32) else cl.float().contiguous()
+
+
+def from_ndhwc(cl):
+    """[B,D,H,W,C] memory -> logical [B,C,D,H,W] view."""
+    return cl.permute(0, 4, 1, 2, 3)
+
+
+def pack_conv3d_weight(w, transposed=False):
+    """torch Conv3d [Cout,Cin,3,3,3] / ConvTranspose3d [Cin,Cout,3,3,3] weight -> MFMA fragment order."""
+    _need_gpu(w)
+    cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+    n = lib().mdf_conv3d_packed_size(cin, cout)
+    out = torch.empty((n,), device=w.device, dtype=torch.float32)
+    check(lib().mdf_conv3d_pack_weights(_f32c(w.detach()).data_ptr(), out.data_ptr(), cin, cout, int(transposed),
+                                        _stream(out)), "mdf_conv3d_pack_weights")
+    return out
+
+
+def conv3d_ndhwc(x, wpack, cin, cout, stride=1, transposed=False, alpha=None, beta=None, relu=False, res=None):
+    """y = [res +] [relu](conv(x)*alpha + beta).  x [B,D,H,W,Cin] contiguous -> y [B,Do,Ho,Wo,Cout]."""
+    _need_gpu(x, wpack)
+    b, d, h, w, c = x.shape
+    assert c == cin and x.is_contiguous()
+    if transposed:
+        do, ho, wo = 2 * d, 2 * h, 2 * w
+    elif stride == 2:
+        do, ho, wo = (d - 1) // 2 + 1, (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    else:
+        do, ho, wo = d, h, w
+    y = torch.empty((b, do, ho, wo, cout), device=x.device, dtype=torch.float32)
+    if res is not None:
+        assert res.shape == y.shape and res.is_contiguous()
+    check(lib().mdf_conv3d_fwd(x.data_ptr(), wpack.data_ptr(), None if alpha is None else alpha.data_ptr(),
+                               None if beta is None else beta.data_ptr(), None if res is None else res.data_ptr(),
+                               y.data_ptr(), b, d, h, w, cin, cout, stride, int(transposed), int(relu), _stream(y)),
+          "mdf_conv3d_fwd")
+    return y
+
+
+def prob_head(x, weight, depth_hypos=None):
+    """Conv3d(Cin->1,k3,p1) + softmax over D [+ soft-argmin].  x [B,D,h,w,Cin] -> prob [B,D,h,w] (, depth)."""
+    _need_gpu(x, weight)
+    b, d, h, w, c = x.shape
+    prob = torch.empty((b, d, h, w), device=x.device, dtype=torch.float32)
+    depth, hyp, pp = None, None, 0
+    if depth_hypos is not None:
+        hyp, pp = _hypos_arg(depth_hypos, h, w)
+        depth = torch.empty((b, h, w), device=x.device, dtype=torch.float32)
+    check(lib().mdf_prob_softmax_regress_fwd(x.data_ptr(), _f32c(weight.detach()).data_ptr(),
+                                             None if hyp is None else hyp.data_ptr(), pp, prob.data_ptr(),
+                                             None if depth is None else depth.data_ptr(), b, d, h, w, c, _stream(prob)),
+          "mdf_prob_softmax_regress_fwd")
+    return prob if depth is None else (prob, depth)
+
+
+def fold_bn(bn_weight, bn_bias, running_mean, running_var, eps=1e-5):
+    """Eval BatchNorm as ATen folds it: alpha = gamma/sqrt(var+eps), beta = bias - mean*alpha."""
+    invstd = 1.0 / torch.sqrt(running_var.float() + eps)
+    alpha = (bn_weight.float() * invstd).contiguous()
+    beta = (bn_bias.float() - running_mean.float() * alpha).contiguous()
+    return alpha, beta

@@ -1,0 +1,44 @@
+"""Stage orchestrator (reference: net/core.py:4-78): same constructor slots, forward signature, output
+dicts and state_dict keys; the stage loop runs on one HIP stream with the hot operators as fused kernels."""
+import torch
+
+from mdfnet_hip import hostmirror
+
+
+class CoreNet(torch.nn.Module):
+    def __init__(self, Backbone, Depth_hypos, scale, Homoaggre, Regular, Regress, Refine):
+        """Backbone: img -> 3 feature maps; Depth_hypos/Homoaggre/Regular: ModuleLists (one per stage);
+        scale: callable(K, E, stage); Regress: [depth_regression, confidence_regress]; Refine: module."""
+        super().__init__()
+        self.Backbone, self.Depth_hypos, self.scale = Backbone, Depth_hypos, scale
+        self.Homoaggre, self.Regular, self.Refine = Homoaggre, Regular, Refine
+        self.Depth_regress, self.Confidence_regress = Regress
+        print("{} parameters: {}".format(self._get_name(), sum(p.data.nelement() for p in self.parameters())))
+
+    def forward(self, origin_imgs, extrinsics, intrinsics, depth_range):
+        """imgs [B,V,3,H,W] (view 0 = reference), E [B,V,4,4], K [B,V,3,3], range [B,2]
+        -> train: {"depth": [1/8, 1/4, 1/2, 1/1]};  eval: {"depth": [B,H,W], "confidence": [B,H,W]}."""
+        if origin_imgs.is_cuda:
+            # one device->host hop for the control-plane tensors (cameras, range); the slots then find host
+            # mirrors and never synchronise again
+            for t in (extrinsics, intrinsics, depth_range):
+                hostmirror.put(t, t.detach().cpu())
+        views = torch.unbind(origin_imgs.float(), 1)
+        pyramids = [self.Backbone(v) for v in views]
+        depth = hypos = prob = None
+        depths = []
+        for stage, (make_hypos, aggregate, regular) in enumerate(zip(self.Depth_hypos, self.Homoaggre, self.Regular)):
+            feats = [p[stage] for p in pyramids]
+            ref_proj, src_projs = self.scale(intrinsics, extrinsics, stage)
+            hypos = make_hypos(depth, depth_range, prob, hypos, upsample=True)
+            cost = aggregate(feats, ref_proj, src_projs, hypos)
+            prob = regular(cost)
+            depth = self.Depth_regress(prob, hypos)
+            depths.append(depth)
+        depth = self.Refine(depth, depth_range)
+        depths.append(depth)
+        if self.training:
+            return {"depth": depths}
+        conf = self.Confidence_regress(prob)
+        conf = torch.nn.functional.interpolate(conf.unsqueeze(1), scale_factor=2, mode="nearest").squeeze(1)
+        return {"depth": depth, "confidence": conf}

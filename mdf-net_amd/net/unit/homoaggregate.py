@@ -1,0 +1,47 @@
+"""Cost-volume aggregation slot (reference: net/unit/homoaggregate.py)."""
+import torch
+import torch.nn as nn
+
+from mdfnet_hip import hostmirror, ops
+from .base import ConvBNReLU3D
+
+
+def _projections(ref_proj, src_projs, device):
+    host = ops.relative_projections(hostmirror.get(ref_proj), [hostmirror.get(s) for s in src_projs])
+    return host.to(device, non_blocking=True)
+
+
+class VectorAggregate(nn.Module):
+    """Group-wise softmax similarity with a learned per-voxel view weight (homoaggregate.py:8-46),
+    fused with the plane-sweep warp into one kernel.  state_dict keys: depth_weight.0.{conv,bn}.*,
+    depth_weight.1.{weight,bias}.  Returns cost [B,G,D,h,w] whose memory is NDHWC (what the
+    regulariser's conv kernels read)."""
+
+    def __init__(self, ngroups: int = 8):
+        super().__init__()
+        self.ngroups = ngroups
+        self.depth_weight = nn.Sequential(ConvBNReLU3D(ngroups, 1, 1, 1, 0), nn.Conv3d(1, 1, 1, 1, 0), nn.Sigmoid())
+        self._folded = None
+
+    def _params(self):
+        sd = {k: v for k, v in self.depth_weight.state_dict(keep_vars=True).items()}
+        key = tuple((v.data_ptr(), v._version) for v in sd.values())
+        if self._folded is None or self._folded[0] != key:
+            with torch.no_grad():
+                self._folded = (key, ops.fold_view_weight(sd, self.ngroups, prefix=""))
+        return self._folded[1]
+
+    def forward(self, features, ref_proj, src_projs, depth_hypos):
+        if self.training:
+            raise NotImplementedError("VectorAggregate: the HIP path is eval/forward-only (training needs the "
+                                      "batch-stat BN two-pass kernels and backward; not built)")
+        with torch.no_grad():
+            proj = _projections(ref_proj, src_projs, features[0].device)
+            return ops.warp_aggregate_vec(list(features), proj, depth_hypos, self._params(), self.ngroups)
+
+
+def homo_aggregate_by_variance(features, ref_proj, src_projs, depth_hypos):
+    """homoaggregate.py:49-69: variance over {ref, softmax_C(warped src)} -> [B,C,D,h,w]."""
+    with torch.no_grad():
+        proj = _projections(ref_proj, src_projs, features[0].device)
+        return ops.warp_aggregate_var(list(features), proj, depth_hypos)

@@ -1,0 +1,15 @@
+"""Regress slot: soft-argmin depth and photometric confidence (reference: net/unit/regress.py)."""
+from mdfnet_hip import ops
+
+
+def depth_regression(prob_volume, depth_hypos):
+    """regress.py:5-7: sum_d prob * hypos.  prob [B,D,h,w]; hypos [B,D,1,1] | [B,D,h,w] -> [B,h,w]."""
+    return ops.depth_regress(prob_volume, depth_hypos)
+
+
+def confidence_regress(prob_volume, last_confidence=None, n=4, pad=(0, 0, 0, 0, 1, 2)):
+    """regress.py:9-25: sum of the 4 probabilities around trunc(E[d]).  Only the configuration the model
+    uses (n=4, pad=(1,2) on D, no last_confidence) is built."""
+    if last_confidence is not None or n != 4 or tuple(pad) != (0, 0, 0, 0, 1, 2):
+        raise NotImplementedError("confidence_regress: only n=4, pad=(0,0,0,0,1,2), last_confidence=None is built")
+    return ops.confidence(prob_volume.detach())

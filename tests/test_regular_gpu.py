@@ -1,0 +1,70 @@
+"""GPU parity: MFMA 3-D conv layers and the full regularisers vs torch-CPU / reference goldens."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from mdfnet_hip import ops, synth
+from oracle import mvs_oracle as O
+from modelutil import build_model
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+DEV = "cuda:0"
+
+COMBOS = [(32, 16, "s1"), (16, 16, "s1"), (32, 32, "s1"), (64, 64, "s1"), (16, 8, "s1"), (8, 8, "s1"),
+          (16, 32, "s2"), (32, 64, "s2"), (8, 16, "s2"), (64, 32, "tr"), (32, 16, "tr"), (16, 8, "tr")]
+
+
+@pytest.mark.parametrize("cin,cout,mode", COMBOS)
+@pytest.mark.parametrize("shape", [(1, 4, 6, 8), (2, 5, 7, 9), (1, 8, 20, 36)])
+def test_conv3d_layer(cin, cout, mode, shape):
+    b, d, h, w = shape
+    rng = np.random.RandomState(cin * 131 + cout + d)
+    x = T(rng.randn(b, cin, d, h, w).astype(np.float32))
+    tr = mode == "tr"
+    wt = T((rng.randn(*((cin, cout) if tr else (cout, cin)), 3, 3, 3) / np.sqrt(27 * cin)).astype(np.float32))
+    alpha = T(rng.uniform(0.5, 1.5, cout).astype(np.float32))
+    beta = T(rng.uniform(-0.2, 0.2, cout).astype(np.float32))
+    if tr:
+        ref = F.conv_transpose3d(x, wt, None, 2, 1, 1)
+    else:
+        ref = F.conv3d(x, wt, None, 2 if mode == "s2" else 1, 1)
+    res = T(rng.randn(*ref.shape).astype(np.float32))
+    exp = F.relu(ref * alpha.view(1, -1, 1, 1, 1) + beta.view(1, -1, 1, 1, 1)) + res
+    wp = ops.pack_conv3d_weight(wt.to(DEV), tr)
+    y = ops.conv3d_ndhwc(ops.to_ndhwc(x.to(DEV)), wp, cin, cout, 2 if mode != "s1" else 1, tr, alpha.to(DEV), beta.to(DEV),
+                         True, ops.to_ndhwc(res.to(DEV)))
+    got = ops.from_ndhwc(y).cpu()
+    assert got.shape == exp.shape
+    # fp32 fma chain over K = 27*cin terms, different summation order than oneDNN
+    np.testing.assert_allclose(got.numpy(), exp.numpy(), rtol=1e-4, atol=2e-5)
+    # no BN / relu / residual variant (raw conv)
+    y2 = ops.conv3d_ndhwc(ops.to_ndhwc(x.to(DEV)), wp, cin, cout, 2 if mode != "s1" else 1, tr)
+    np.testing.assert_allclose(ops.from_ndhwc(y2).cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("stage", [0, 1, 2])
+def test_regulariser_vs_reference_golden(golden, seeded_sd, stage):
+    g = golden("ops.npz")
+    model = build_model()
+    model.load_state_dict(seeded_sd)
+    model.eval().to(DEV)
+    cost = T(g[f"agg{stage}_cost"]).to(DEV)
+    hyp = T(g[f"agg{stage}_hyp"]).to(DEV)
+    prob, depth = model.Regular[stage](cost, hyp)
+    np.testing.assert_allclose(prob.cpu().numpy(), g[f"reg{stage}_prob"], rtol=2e-3, atol=2e-6)
+    np.testing.assert_allclose(depth.cpu().numpy(), g[f"reg{stage}_depth"], rtol=0, atol=5e-3)
+    prob2 = model.Regular[stage](cost)
+    assert torch.equal(prob2, prob)
+    # standalone regress slot on the golden prob
+    d2 = model.Depth_regress(T(g[f"reg{stage}_prob"]).to(DEV), hyp)
+    np.testing.assert_allclose(d2.cpu().numpy(), g[f"reg{stage}_depth"], rtol=0, atol=3e-4)
+
+
+def test_train_mode_fails_loudly(seeded_sd):
+    model = build_model()
+    model.load_state_dict(seeded_sd)
+    model.train().to(DEV)
+    with pytest.raises(NotImplementedError):
+        model.Regular[1](torch.zeros(1, 16, 8, 8, 8, device=DEV))
