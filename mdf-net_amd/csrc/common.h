@@ -34,6 +34,27 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
   return base + (bid >> 3);
 }
 
+// ATen's CPU float sum (SumKernel.cpp multi_row_sum / cascade_sum): elements are added sequentially into
+// level 0; after every 16 elements level 0 is folded into level 1 (after every 256 into level 2, ...); the
+// result is ((l0 + l1) + l2) + l3.  Mirroring it makes `torch.sum(a*b, dim)`-style reductions bit-identical
+// to the reference's CPU result for the same inputs (verified against the goldens for D = 8, 24, 48).
+struct CascadeSum {
+  float l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
+  unsigned n = 0;
+  __device__ __forceinline__ void add(float v) {
+    l0 += v;
+    ++n;
+    if ((n & 15u) == 0) {
+      l1 += l0; l0 = 0.f;
+      if ((n & 255u) == 0) {
+        l2 += l1; l1 = 0.f;
+        if ((n & 4095u) == 0) { l3 += l2; l2 = 0.f; }
+      }
+    }
+  }
+  __device__ __forceinline__ float result() const { return ((l0 + l1) + l2) + l3; }
+};
+
 }  // namespace mdf
 
 #define MDF_REQUIRE(cond, ...) \

@@ -58,13 +58,13 @@ __global__ __launch_bounds__(256) void prob_head_kernel(const float* __restrict_
     pr[(size_t)d * hw] = e;
     sum += e;
   }
-  float dep = 0.f;
+  mdf::CascadeSum dep;  // regress.py:5-7 with ATen's summation order
   for (int d = 0; d < D; ++d) {
     const float pv = pr[(size_t)d * hw] / sum;
     pr[(size_t)d * hw] = pv;
-    if (depth) dep += pv * (per_pixel ? hypos[((size_t)b * D + d) * hw + pix] : hypos[(size_t)b * D + d]);
+    if (depth) dep.add(pv * (per_pixel ? hypos[((size_t)b * D + d) * hw + pix] : hypos[(size_t)b * D + d]));
   }
-  if (depth) depth[i] = dep;
+  if (depth) depth[i] = dep.result();
 }
 
 }  // namespace

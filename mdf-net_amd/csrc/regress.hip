@@ -20,9 +20,9 @@ __global__ void depth_regress_kernel(const float* __restrict__ prob, const float
   const size_t n = (size_t)B * hw;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const size_t b = i / hw, pix = i % hw;
-    float acc = 0.0f;
-    for (int d = 0; d < D; ++d) acc += prob[(b * D + d) * hw + pix] * hyp_at(hypos, per_pixel, b, D, d, hw, pix);
-    depth[i] = acc;
+    mdf::CascadeSum acc;  // torch.sum(prob * hypos, 1): product tensor, then ATen's cascade sum
+    for (int d = 0; d < D; ++d) acc.add(prob[(b * D + d) * hw + pix] * hyp_at(hypos, per_pixel, b, D, d, hw, pix));
+    depth[i] = acc.result();
   }
 }
 
@@ -33,9 +33,9 @@ __global__ void confidence_kernel(const float* __restrict__ prob, float* __restr
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const size_t b = i / hw, pix = i % hw;
     const float* p = prob + b * D * hw + pix;
-    float e = 0.0f;
-    for (int d = 0; d < D; ++d) e += p[(size_t)d * hw] * (float)d;
-    long long idx = (long long)e;  // .long() truncates toward zero
+    mdf::CascadeSum ex;
+    for (int d = 0; d < D; ++d) ex.add(p[(size_t)d * hw] * (float)d);
+    long long idx = (long long)ex.result();  // .long() truncates toward zero
     if (idx_out) idx_out[i] = idx;
     idx = idx < 0 ? 0 : (idx > D - 1 ? D - 1 : idx);  // torch.gather would raise outside [0,D-1]; prob sums to 1 so never hit
     float s = 0.0f;
@@ -54,19 +54,22 @@ __global__ void hypos_fit_kernel(int mode, const float* __restrict__ prob, const
     const size_t b = i / hw, pix = i % hw;
     const float* p = prob + b * D * hw + pix;
     if (mode == 1) {
+      // b0 = row . ln(p): torch.matmul([.,3,D] @ [.,D,1]) runs ATen's naive bmm kernel (contraction*rows*cols
+      // < 400): sequential k loop, separate multiply and add in fp32.  The sum cancels heavily, so mirroring
+      // the order (verified bit-exact on the goldens given torch's log) matters more than accuracy here.
       float acc = 0.0f;
-      for (int d = 0; d < D; ++d) acc += row[b * D + d] * logf(fmaxf(p[(size_t)d * hw], 1e-40f));
+      for (int d = 0; d < D; ++d) acc = acc + row[b * D + d] * logf(fmaxf(p[(size_t)d * hw], 1e-40f));
       s_out[i] = fabsf(-1.0f / acc);
     } else {
       const float dep = depth[i];
-      float sxy = 0.0f, sxx = 0.0f;
+      mdf::CascadeSum sxy, sxx;  // torch.sum(x*y, -1), torch.sum(x*x, -1)
       for (int d = 0; d < D; ++d) {
         const float x = fabsf(hyp_at(hypos, per_pixel, b, D, d, hw, pix) - dep);
         const float y = logf(fmaxf(p[(size_t)d * hw], 1e-40f));
-        sxy += x * y;
-        sxx += x * x;
+        sxy.add(x * y);
+        sxx.add(x * x);
       }
-      s_out[i] = 1.0f / fabsf(sxy / sxx);
+      s_out[i] = 1.0f / fabsf(sxy.result() / sxx.result());
     }
   }
 }
@@ -83,9 +86,12 @@ __device__ __forceinline__ void up2_coord(int o, int n_in, int& i0, int& i1, flo
 
 __device__ __forceinline__ float up2_sample(const float* __restrict__ m, int w, int y0, int y1, int x0, int x1, float ly0,
                                             float ly1, float lx0, float lx1) {
-  const float top = lx0 * m[(size_t)y0 * w + x0] + lx1 * m[(size_t)y0 * w + x1];
-  const float bot = lx0 * m[(size_t)y1 * w + x0] + lx1 * m[(size_t)y1 * w + x1];
-  return ly0 * top + ly1 * bot;
+  // rounding order of ATen's CPU upsample_bilinear2d (found by exhaustive search, bit-exact on the goldens):
+  //   w_ij = ly_i*lx_j ;  out = fma(w11,v11, fma(w10,v10, fma(w00,v00, w01*v01)))
+  const float v00 = m[(size_t)y0 * w + x0], v01 = m[(size_t)y0 * w + x1];
+  const float v10 = m[(size_t)y1 * w + x0], v11 = m[(size_t)y1 * w + x1];
+  const float w00 = ly0 * lx0, w01 = ly0 * lx1, w10 = ly1 * lx0, w11 = ly1 * lx1;
+  return __fmaf_rn(w11, v11, __fmaf_rn(w10, v10, __fmaf_rn(w00, v00, w01 * v01)));
 }
 
 // depthhypos.py:49-76.  One thread per OUTPUT pixel; writes D_out hypotheses (stride Ho*Wo -> coalesced).

@@ -160,13 +160,20 @@ def confidence(prob, return_index=False):
 
 
 def gauss1_fit_row(depth_hypos):
-    """HOST: row 0 of (X^T X)^-1 X^T for hypotheses [B,D,1,1] shared by every pixel, with the same
-    torch CPU calls as depthhypos.py:199-208 (cond(X^T X) ~ 1e14 in fp32: the bits of this inverse ARE the
-    reference's behaviour).  -> [B,D] CPU float32."""
-    hyp = depth_hypos.detach().to("cpu", torch.float32).reshape(depth_hypos.shape[0], -1)
-    x = torch.stack([hyp ** 2, hyp, torch.ones_like(hyp)], dim=-1)
+    """HOST: row 0 of (X^T X)^-1 X^T for hypotheses [B,D,1,1] shared by every pixel.
+
+    cond(X^T X) ~ 1e14 in fp32, so the *bits* of this row are the reference's behaviour and they
+    depend on which BLAS path torch takes, i.e. on the operand shapes/strides.  The row is therefore produced by
+    replaying depthhypos.py:191-208 verbatim (repeat -> stack -> permute -> matmul -> inverse -> matmul) on a
+    2x2-pixel replica: verified bit-identical to the per-pixel matrices of any larger image, for any batch size
+    (a 1x1 replica is NOT: degenerate strides take another path).  -> [B,D] CPU float32."""
+    hyp = depth_hypos.detach().to("cpu", torch.float32)
+    b, d = hyp.shape[:2]
+    hyp = hyp.reshape(b, d, 1, 1).repeat(1, 1, 2, 2)
+    x = torch.stack([hyp ** 2, hyp, torch.ones_like(hyp)], dim=-1).permute(0, 2, 3, 1, 4)
     xt = x.transpose(-1, -2)
-    return torch.matmul(torch.inverse(torch.matmul(xt, x)), xt)[:, 0, :].contiguous()
+    m = torch.matmul(torch.inverse(torch.matmul(xt, x)), xt)  # [B,2,2,3,D]
+    return m[:, 0, 0, 0, :].contiguous()
 
 
 def hypos_fit(mode, prob, depth, depth_hypos, fit_row=None):

@@ -309,13 +309,25 @@ def gauss1_fit(prob, depth_hypos):
 
 
 def gauss1_row0(depth_hypos_b_d):
-    """Row 0 of (X^T X)^-1 X^T for hypotheses shared by every pixel ([B,D]); same ATen calls as
-    gauss1_fit so the 3x3 inverse is bit-identical.  Used by the product's host side as well
-    (re-implemented there, not imported)."""
-    hyp = depth_hypos_b_d
-    x = torch.stack([hyp ** 2, hyp, torch.ones_like(hyp)], dim=-1)  # [B,D,3]
+    """Row 0 of (X^T X)^-1 X^T for hypotheses shared by every pixel ([B,D]), bit-identical to the per-pixel
+    matrices inside gauss1_fit: same op sequence on a 2x2-pixel replica (operand strides select the BLAS path,
+    and with cond ~1e14 the path decides the bits)."""
+    b, d = depth_hypos_b_d.shape
+    hyp = depth_hypos_b_d.reshape(b, d, 1, 1).repeat(1, 1, 2, 2)
+    x = torch.stack([hyp ** 2, hyp, torch.ones_like(hyp)], dim=-1).permute(0, 2, 3, 1, 4)
     xt = x.transpose(-1, -2)
-    return torch.matmul(torch.inverse(torch.matmul(xt, x)), xt)[:, 0, :]
+    return torch.matmul(torch.inverse(torch.matmul(xt, x)), xt)[:, 0, 0, 0, :]
+
+
+def gauss1_fit_explicit(prob, depth_hypos_b_d):
+    """gauss1_fit with the per-pixel matmul written out: b0 = sequential fp32 sum_k row[k]*ln p[k] (ATen's naive
+    bmm order).  Bit-identical to gauss1_fit (test_oracle_golden.py); this is the form the HIP kernel mirrors."""
+    row = gauss1_row0(depth_hypos_b_d)
+    z = torch.log(prob.clamp(min=1e-40))
+    acc = torch.zeros_like(z[:, 0])
+    for k in range(z.shape[1]):
+        acc = acc + row[:, k].reshape(-1, 1, 1) * z[:, k]
+    return torch.abs(-1 / acc)
 
 
 def laplace_fit(depth, prob, depth_hypos):

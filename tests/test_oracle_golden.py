@@ -113,6 +113,7 @@ def test_hypos_by_fit(golden):
     assert np.array_equal(hyp0[:, ::4].numpy(), g["warp0_hyp"])
     p0, d0 = T(g["reg0_prob"]), T(g["reg0_depth"])
     assert np.array_equal(O.gauss1_fit(p0, hyp0).numpy(), g["hyp1_s"])
+    assert np.array_equal(O.gauss1_fit_explicit(p0, hyp0.reshape(2, 48)).numpy(), g["hyp1_s"])  # explicit order
     h1 = O.hypos_by_fit(d0, dr, p0, hyp0, 24, "gauss1", 0.95)
     assert np.array_equal(h1.numpy(), g["hyp1_out"])
     p1, d1 = T(g["reg1_prob"]), T(g["reg1_depth"])
