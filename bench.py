@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: views/sec of the 4-scale MVS eval forward at DTU 1600x1184 (cropped 1600x1200), 5 views,
+hypotheses (48,24,8), batch 1 per rank (BASELINE.json configs[1]); synthetic DTU-shaped tensors, seeded weights.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one reference-view inference (one CoreNet.forward, B=1) with the inputs already resident in HBM.
+Views shard across ranks with no data-path collective (eval items are independent): weak scaling.
+Rank 0 prints ONE JSON line; it also carries
+  roofline      the dominant hand-written kernel family (by time), measured live with HIP events on the launch
+                stream in a separate profile pass: algorithmic flops (or bytes) / summed launch time vs CDNA4 peak
+  kernels       the same for every hand-written kernel family + the stock (MIOpen) remainder
+  cpu_baseline  the oracle (CPU restatement of the reference, kind "port") timed on this box's host cores on a
+                bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(ROOT, "mdf-net_amd")]
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+WIDTH, HEIGHT, VIEWS = 1600, 1184, 5
+
+
+def build(device):
+    import contextlib
+    import io
+    from mdfnet_hip import synth
+    with contextlib.redirect_stdout(io.StringIO()):
+        import config
+        model = config.build_model()
+    model.load_state_dict(synth.seeded_state_dict(model.state_dict(), seed=1))
+    return model.eval().to(device)
+
+
+def family(name, tag):
+    if name == "mdf_conv3d_fwd":
+        return "conv3d_kernel (fp32 MFMA implicit GEMM)"
+    if name == "mdf_warp_aggregate_vec_fwd":
+        return "warp_kernel<kVec> (fused warp+aggregate)"
+    if name == "mdf_prob_softmax_regress_fwd":
+        return "prob_head_kernel"
+    return name.replace("mdf_", "").replace("_fwd", "") + "_kernel"
+
+
+def profile_pass(model, inputs, steps=3):
+    """Per-launch HIP-event timing of every hand-written kernel (events recorded on the launch stream)."""
+    from mdfnet_hip import ops
+    agg = {}
+    with torch.no_grad():
+        for _ in range(steps):
+            ops.profile_begin()
+            model(*inputs)
+            for name, tag, ms, work in ops.profile_end():
+                if name == "mdf_conv3d_pack_weights":
+                    continue
+                f = agg.setdefault(family(name, tag), {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0,
+                                                       "bound": work.get("bound", "hbm"), "top": {}})
+                f["ms"] += ms
+                f["flops"] += work.get("flops", 0.0)
+                f["bytes"] += work.get("bytes", 0.0)
+                f["launches"] += 1
+                t = f["top"].setdefault(tag, [0.0, 0.0, 0.0, 0])
+                t[0] += ms; t[1] += work.get("flops", 0.0); t[2] += work.get("bytes", 0.0); t[3] += 1
+    out = []
+    for fam, f in agg.items():
+        ms = f["ms"] / steps
+        rec = {"kernel": fam, "launches_per_step": f["launches"] // steps, "ms_per_step": round(ms, 4), "bound": f["bound"]}
+        if f["bound"] == "mfma" and f["flops"]:
+            ach = f["flops"] / steps / (ms * 1e-3) / 1e12
+            rec.update(achieved=round(ach, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                       algorithmic_gflop_per_step=round(f["flops"] / steps / 1e9, 2))
+        elif f["bytes"]:
+            ach = f["bytes"] / steps / (ms * 1e-3) / 1e9
+            rec.update(achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4),
+                       algorithmic_mb_per_step=round(f["bytes"] / steps / 1e6, 1))
+        heavy = max(f["top"].items(), key=lambda kv: kv[1][0])
+        rec["heaviest_launch"] = {"shape": heavy[0], "ms": round(heavy[1][0] / heavy[1][3], 4)}
+        if f["bound"] == "mfma" and heavy[1][1]:
+            rec["heaviest_launch"]["tflops"] = round(heavy[1][1] / heavy[1][3] / (heavy[1][0] / heavy[1][3] * 1e-3) / 1e12, 2)
+        elif heavy[1][2]:
+            rec["heaviest_launch"]["gbs"] = round(heavy[1][2] / heavy[1][3] / (heavy[1][0] / heavy[1][3] * 1e-3) / 1e9, 1)
+        out.append(rec)
+    out.sort(key=lambda r: -r["ms_per_step"])
+    return out
+
+
+def cpu_baseline(sample_views=1):
+    """Oracle (CPU port of the reference algorithm) on the host cores; bounded sample of the same workload."""
+    from mdfnet_hip import synth
+    from oracle import mvs_oracle as O
+    model_sd = synth.seeded_state_dict(build("cpu").state_dict(), seed=1)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        tiny = synth.make_scene(160, 128, 3, seed=0)
+        O.core_forward(model_sd, *tiny)  # warm oneDNN / thread pool
+        scene = synth.make_scene(WIDTH, HEIGHT, VIEWS, seed=0)
+        t0 = time.time()
+        for _ in range(sample_views):
+            O.core_forward(model_sd, *scene)
+        dt = time.time() - t0
+    return {"value": round(sample_views / dt, 4), "unit": "views/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{sample_views} full-size view(s) ({WIDTH}x{HEIGHT}x{VIEWS}, hypotheses 48/24/8) through oracle.core_forward "
+                      f"(torch {torch.__version__} CPU, {cores} logical cores), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no GPU visible); the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    from mdfnet_hip import synth
+
+    model = build(dev)
+    inputs = tuple(t.to(dev) for t in synth.make_scene(WIDTH, HEIGHT, VIEWS, batch=1, rot_deg=3.0, seed=100 + rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            model(*inputs)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = model(*inputs)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    assert torch.isfinite(out["depth"]).all()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    kernels, cpu = None, None
+    if rank == 0 and not args.no_profile:
+        kernels = profile_pass(model, inputs)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+    if rank == 0:
+        views_per_s = world * args.steps / dt
+        rec = {"metric": "views/sec at DTU 1600x1200x5-view x4-scale", "value": round(views_per_s, 3), "unit": "views/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"DTU eval {WIDTH}x{HEIGHT} (1600x1200 cropped as load/dtueval.py:34), {VIEWS} views, "
+                                      "3 cost-volume stages + x2 refine = 4 output scales, hypotheses (48,24,8), batch 1 per rank, "
+                                      "seeded random weights (pth/dtu_29.pth is not available offline)",
+                          "views_per_rank_per_step": 1, "parallelism": f"views sharded over {world} rank(s), no collective"}}
+        if kernels:
+            hip = [k for k in kernels if "achieved" in k]
+            dom = max(hip, key=lambda k: k["ms_per_step"]) if hip else None
+            if dom:
+                rec["roofline"] = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"],
+                                   "unit": dom["unit"], "frac": dom["frac"], "traffic": None,
+                                   "ms_per_step": dom["ms_per_step"], "launches_per_step": dom["launches_per_step"]}
+            rec["kernels"] = kernels
+            rec["hip_kernels_ms_per_step"] = round(sum(k["ms_per_step"] for k in kernels), 3)
+        if cpu:
+            rec["cpu_baseline"] = cpu
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,6 +12,35 @@ from . import check, lib
 FEA_NHWC = 1
 VOL_NCDHW, VOL_NDHWC = 0, 1
 
+# Optional per-launch timing (bench.py's roofline pass): when `_prof` is a list, every C-ABI call is bracketed by
+# HIP events recorded on the stream the kernel is launched on, with its algorithmic work attached.
+_prof = None
+
+
+def profile_begin():
+    global _prof
+    _prof = []
+
+
+def profile_end():
+    """-> list of (abi_name, tag, ms, work-dict) for every launch since profile_begin()."""
+    global _prof
+    recs, _prof = _prof, None
+    torch.cuda.synchronize()
+    return [(n, tag, e0.elapsed_time(e1), work) for n, tag, e0, e1, work in recs]
+
+
+def _abi(name, args, tag="", work=None):
+    fn = getattr(lib(), name)
+    if _prof is None:
+        check(fn(*args), name)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(fn(*args), name)
+    e1.record()
+    _prof.append((name, tag, e0, e1, work or {}))
+
 
 def _stream(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
@@ -57,8 +86,8 @@ def homo_warp(src_fea, proj12, depth_hypos):
     fea = nhwc(src_fea)
     hyp, pp = _hypos_arg(depth_hypos, h, w)
     out = torch.empty((b, c, d, h, w), device=src_fea.device, dtype=torch.float32)
-    check(lib().mdf_homo_warp_fwd(fea.data_ptr(), FEA_NHWC, _f32c(proj12).data_ptr(), hyp.data_ptr(), pp,
-                                  out.data_ptr(), VOL_NCDHW, b, c, d, h, w, _stream(out)), "mdf_homo_warp_fwd")
+    _abi("mdf_homo_warp_fwd", (fea.data_ptr(), FEA_NHWC, _f32c(proj12).data_ptr(), hyp.data_ptr(), pp,
+                                  out.data_ptr(), VOL_NCDHW, b, c, d, h, w, _stream(out),))
     return out
 
 
@@ -68,8 +97,8 @@ def warp_corner_indices(proj12, depth_hypos, h, w):
     b, d = depth_hypos.shape[:2]
     hyp, pp = _hypos_arg(depth_hypos, h, w)
     out = torch.empty((b, d, h, w, 2), device=proj12.device, dtype=torch.int32)
-    check(lib().mdf_warp_corner_indices(_f32c(proj12).data_ptr(), hyp.data_ptr(), pp, out.data_ptr(), b, d, h, w,
-                                        _stream(out)), "mdf_warp_corner_indices")
+    _abi("mdf_warp_corner_indices", (_f32c(proj12).data_ptr(), hyp.data_ptr(), pp, out.data_ptr(), b, d, h, w,
+                                        _stream(out),))
     return out
 
 
@@ -95,10 +124,12 @@ def warp_aggregate_vec(features, proj, depth_hypos, w_params, ngroups, channels_
     else:
         mem = cost = torch.empty((b, g, d, h, w), device=dev, dtype=torch.float32)
     srcs = feas[1:]
-    check(lib().mdf_warp_aggregate_vec_fwd(feas[0].data_ptr(), _src_array(srcs), FEA_NHWC, _f32c(proj).data_ptr(),
+    _abi("mdf_warp_aggregate_vec_fwd", (feas[0].data_ptr(), _src_array(srcs), FEA_NHWC, _f32c(proj).data_ptr(),
                                            hyp.data_ptr(), pp, _f32c(w_params).data_ptr(), mem.data_ptr(),
                                            VOL_NDHWC if channels_last else VOL_NCDHW, b, c, g, d, h, w, len(srcs),
-                                           _stream(mem)), "mdf_warp_aggregate_vec_fwd")
+                                           _stream(mem),), tag=f"C{c}G{g}D{d} {w}x{h} V{len(feas)}",
+         work={"bytes": 4.0 * b * (len(feas) * c * h * w + hyp.numel() / b + g * d * h * w),  # feats once +
+               "bound": "hbm"})                                                            # hypos once + cost once
     return cost
 
 
@@ -116,10 +147,10 @@ def warp_aggregate_var(features, proj, depth_hypos, channels_last=False):
     else:
         mem = cost = torch.empty((b, c, d, h, w), device=dev, dtype=torch.float32)
     srcs = feas[1:]
-    check(lib().mdf_warp_aggregate_var_fwd(feas[0].data_ptr(), _src_array(srcs), FEA_NHWC, _f32c(proj).data_ptr(),
+    _abi("mdf_warp_aggregate_var_fwd", (feas[0].data_ptr(), _src_array(srcs), FEA_NHWC, _f32c(proj).data_ptr(),
                                            hyp.data_ptr(), pp, mem.data_ptr(),
                                            VOL_NDHWC if channels_last else VOL_NCDHW, b, c, d, h, w, len(srcs),
-                                           _stream(mem)), "mdf_warp_aggregate_var_fwd")
+                                           _stream(mem),))
     return cost
 
 
@@ -142,8 +173,7 @@ def depth_regress(prob, depth_hypos):
     hyp, pp = _hypos_arg(depth_hypos, h, w)
     prob = _f32c(prob)
     out = torch.empty((b, h, w), device=prob.device, dtype=torch.float32)
-    check(lib().mdf_depth_regress_fwd(prob.data_ptr(), hyp.data_ptr(), pp, out.data_ptr(), b, d, h, w, _stream(out)),
-          "mdf_depth_regress_fwd")
+    _abi("mdf_depth_regress_fwd", (prob.data_ptr(), hyp.data_ptr(), pp, out.data_ptr(), b, d, h, w, _stream(out),))
     return out
 
 
@@ -154,8 +184,8 @@ def confidence(prob, return_index=False):
     prob = _f32c(prob)
     out = torch.empty((b, h, w), device=prob.device, dtype=torch.float32)
     idx = torch.empty((b, h, w), device=prob.device, dtype=torch.int64) if return_index else None
-    check(lib().mdf_confidence_fwd(prob.data_ptr(), out.data_ptr(), idx.data_ptr() if return_index else None,
-                                   b, d, h, w, _stream(out)), "mdf_confidence_fwd")
+    _abi("mdf_confidence_fwd", (prob.data_ptr(), out.data_ptr(), idx.data_ptr() if return_index else None,
+                                   b, d, h, w, _stream(out),))
     return (out, idx) if return_index else out
 
 
@@ -183,9 +213,9 @@ def hypos_fit(mode, prob, depth, depth_hypos, fit_row=None):
     prob = _f32c(prob)
     hyp, pp = _hypos_arg(depth_hypos, h, w)
     out = torch.empty((b, h, w), device=prob.device, dtype=torch.float32)
-    check(lib().mdf_hypos_fit_fwd(mode, prob.data_ptr(), None if depth is None else _f32c(depth).data_ptr(),
+    _abi("mdf_hypos_fit_fwd", (mode, prob.data_ptr(), None if depth is None else _f32c(depth).data_ptr(),
                                   hyp.data_ptr(), pp, None if fit_row is None else _f32c(fit_row).data_ptr(),
-                                  out.data_ptr(), b, d, h, w, _stream(out)), "mdf_hypos_fit_fwd")
+                                  out.data_ptr(), b, d, h, w, _stream(out),))
     return out
 
 
@@ -195,9 +225,9 @@ def hypos_from_fit(mode, s, depth, depth_range_f32, log_thresh, ndepths, upsampl
     b, h, w = s.shape
     ho, wo = (2 * h, 2 * w) if upsample else (h, w)
     out = torch.empty((b, ndepths, ho, wo), device=s.device, dtype=torch.float32)
-    check(lib().mdf_hypos_from_fit_fwd(mode, _f32c(s).data_ptr(), _f32c(depth).data_ptr(),
+    _abi("mdf_hypos_from_fit_fwd", (mode, _f32c(s).data_ptr(), _f32c(depth).data_ptr(),
                                        _f32c(depth_range_f32).data_ptr(), ctypes.c_float(log_thresh), out.data_ptr(),
-                                       b, ndepths, h, w, int(upsample), _stream(out)), "mdf_hypos_from_fit_fwd")
+                                       b, ndepths, h, w, int(upsample), _stream(out),))
     return out
 
 
@@ -219,8 +249,8 @@ def pack_conv3d_weight(w, transposed=False):
     cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
     n = lib().mdf_conv3d_packed_size(cin, cout)
     out = torch.empty((n,), device=w.device, dtype=torch.float32)
-    check(lib().mdf_conv3d_pack_weights(_f32c(w.detach()).data_ptr(), out.data_ptr(), cin, cout, int(transposed),
-                                        _stream(out)), "mdf_conv3d_pack_weights")
+    _abi("mdf_conv3d_pack_weights", (_f32c(w.detach()).data_ptr(), out.data_ptr(), cin, cout, int(transposed),
+                                        _stream(out),))
     return out
 
 
@@ -238,10 +268,12 @@ def conv3d_ndhwc(x, wpack, cin, cout, stride=1, transposed=False, alpha=None, be
     y = torch.empty((b, do, ho, wo, cout), device=x.device, dtype=torch.float32)
     if res is not None:
         assert res.shape == y.shape and res.is_contiguous()
-    check(lib().mdf_conv3d_fwd(x.data_ptr(), wpack.data_ptr(), None if alpha is None else alpha.data_ptr(),
+    _abi("mdf_conv3d_fwd", (x.data_ptr(), wpack.data_ptr(), None if alpha is None else alpha.data_ptr(),
                                None if beta is None else beta.data_ptr(), None if res is None else res.data_ptr(),
-                               y.data_ptr(), b, d, h, w, cin, cout, stride, int(transposed), int(relu), _stream(y)),
-          "mdf_conv3d_fwd")
+                               y.data_ptr(), b, d, h, w, cin, cout, stride, int(transposed), int(relu), _stream(y),),
+         tag=f"{cin}->{cout} {'T' if transposed else 's%d' % stride} {d}x{h}x{w}",
+         work={"flops": 2.0 * 27 * cin * cout * b * (d * h * w if transposed else do * ho * wo),
+               "bytes": 4.0 * (x.numel() + y.numel() * (2 if res is not None else 1)), "bound": "mfma"})
     return y
 
 
@@ -254,10 +286,11 @@ def prob_head(x, weight, depth_hypos=None):
     if depth_hypos is not None:
         hyp, pp = _hypos_arg(depth_hypos, h, w)
         depth = torch.empty((b, h, w), device=x.device, dtype=torch.float32)
-    check(lib().mdf_prob_softmax_regress_fwd(x.data_ptr(), _f32c(weight.detach()).data_ptr(),
+    _abi("mdf_prob_softmax_regress_fwd", (x.data_ptr(), _f32c(weight.detach()).data_ptr(),
                                              None if hyp is None else hyp.data_ptr(), pp, prob.data_ptr(),
-                                             None if depth is None else depth.data_ptr(), b, d, h, w, c, _stream(prob)),
-          "mdf_prob_softmax_regress_fwd")
+                                             None if depth is None else depth.data_ptr(), b, d, h, w, c, _stream(prob),),
+         tag=f"{c}->1 {d}x{h}x{w}", work={"flops": 2.0 * 27 * c * b * d * h * w,
+                                          "bytes": 4.0 * (x.numel() + prob.numel()), "bound": "hbm"})
     return prob if depth is None else (prob, depth)
 
 

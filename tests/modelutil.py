@@ -1,20 +1,9 @@
-"""Build the product model (mdf-net_amd/net) the way the reference's config.py:186-218 composes it."""
+"""Build the product model (mdf-net_amd/net) through the product's own config counterpart."""
 import contextlib
 import io
 
-import torch.nn as nn
-
 
 def build_model():
-    from net import core
-    from net.unit import scale, backbone, regress, refine
-    from net.unit.depthhypos import HyposByFit
-    from net.unit.homoaggregate import VectorAggregate
-    from net.unit.regular import RegularNet_4Scales, RegularNet_3Scales
-    nd, curves, thr, ng = (48, 24, 8), (None, "gauss1", "laplace"), (0.0, 0.95, 1e-5), (32, 16, 8)
     with contextlib.redirect_stdout(io.StringIO()):
-        return core.CoreNet(backbone.FPN_4Scales((8, 16, 32, 64)),
-                            nn.ModuleList([HyposByFit(nd[i], curves[i], thr[i]) for i in range(3)]),
-                            scale.scale_cam, nn.ModuleList([VectorAggregate(g) for g in ng]),
-                            nn.ModuleList([RegularNet_3Scales(32), RegularNet_4Scales(16), RegularNet_4Scales(8)]),
-                            [regress.depth_regression, regress.confidence_regress], refine.RefineNet2())
+        import config
+        return config.build_model()
