@@ -7,6 +7,11 @@ import ctypes
 import os
 import threading
 
+# torch bundles its own libamdhip64; it must be loaded BEFORE libmdfnet_hip.so so that the library's
+# libamdhip64.so.7 dependency resolves to the SAME runtime instance (two HIP runtimes in one process do not
+# share devices/streams: "no ROCm-capable device is detected" on the first launch).
+import torch  # noqa: F401
+
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmdfnet_hip.so")
 ABI_VERSION = 1

@@ -1,0 +1,26 @@
+"""Condense a rocprofv3 --kernel-trace --stats run into profiles/<name>.md (+ the raw kernel_stats.csv).
+usage: python scripts/summarize_rocprof.py gpurun_out/prof_r1 profiles/r01_bench_cfg2 <steps_incl_warmup> ["cmd"]"""
+import csv, glob, os, shutil, sys
+
+src, dst, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+cmd = sys.argv[4] if len(sys.argv) > 4 else ""
+stats = glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True)[0]
+rows = list(csv.DictReader(open(stats)))
+os.makedirs(os.path.dirname(dst), exist_ok=True)
+shutil.copy(stats, dst + "_kernel_stats.csv")
+ours = ("conv3d_kernel", "warp_kernel", "prob_head_kernel", "regress_kernel", "confidence_kernel", "hypos_", "pack_weights",
+        "corner_index", "conv2d_kernel", "refine_")
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+tune = sum(float(r["TotalDurationNs"]) for r in rows if r["Name"].startswith("naive_conv"))
+mine = sum(float(r["TotalDurationNs"]) for r in rows if any(k in r["Name"] for k in ours))
+with open(dst + ".md", "w") as f:
+    f.write(f"# rocprofv3 --kernel-trace --stats summary\n\ncommand: `{cmd}`\n\n")
+    f.write(f"forward passes in the run (warm-up + timed): {steps}\n\n")
+    f.write(f"* all kernels: {tot/1e6:.2f} ms; MIOpen find-mode `naive_conv*` (first call only): {tune/1e6:.2f} ms\n")
+    f.write(f"* steady state per forward: {(tot-tune)/steps/1e6:.3f} ms GPU-busy, of which hand-written HIP kernels "
+            f"{mine/steps/1e6:.3f} ms\n\n| kernel | calls | calls/fwd | total ms | avg us | min us | max us |\n|---|---|---|---|---|---|---|\n")
+    for r in rows[:45]:
+        name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:110]
+        f.write(f"| `{name}` | {r['Calls']} | {int(r['Calls'])/steps:.1f} | {float(r['TotalDurationNs'])/1e6:.3f} | "
+                f"{float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} |\n")
+print(open(dst + ".md").read()[:1500])
