@@ -1,0 +1,65 @@
+"""CPU: the product's `net` package is a drop-in for the reference's (same state_dict contract), and — when the
+reference tree is present (build container only) — the reference's own config.py composes its model out of OUR slots."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("MDF_REFERENCE", "/root/reference")
+
+
+def test_state_dict_matches_reference_contract(golden, seeded_sd):
+    from modelutil import build_model
+    meta = golden("state_dict_meta.npz")
+    m = build_model()
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(k) for k in meta["keys"]]            # same keys, same order
+    assert [str(list(v.shape)) for v in sd.values()] == [str(s) for s in meta["shapes"]]
+    assert sum(p.numel() for p in m.parameters()) == int(meta["nparams"]) == 1206380
+    m.load_state_dict(seeded_sd)                                         # strict, as eval.py:17 / train.py:21
+    assert not any(k.startswith("Depth_hypos") for k in sd)              # H8: prob_thresh is not a buffer
+    assert sd["Backbone.conv01.0.bn.num_batches_tracked"].dtype == torch.int64
+
+
+def test_slot_signatures_and_train_mode_guard():
+    from modelutil import build_model
+    from net.unit import regress, scale
+    m = build_model()
+    assert callable(m.scale) and m.scale is scale.scale_cam
+    assert m.Depth_regress is regress.depth_regression and m.Confidence_regress is regress.confidence_regress
+    k = torch.eye(3).reshape(1, 1, 3, 3).repeat(1, 3, 1, 1) * 100
+    e = torch.eye(4).reshape(1, 1, 4, 4).repeat(1, 3, 1, 1)
+    k0 = k.clone()
+    rp, sps = m.scale(k, e, 0)
+    assert rp.shape == (1, 4, 4) and len(sps) == 2 and torch.equal(k, k0)   # inputs untouched (scale.py:14)
+    hyp = m.Depth_hypos[0](None, torch.tensor([[425.0, 935.0]], dtype=torch.float64), None, None, upsample=True)
+    assert hyp.shape == (1, 48, 1, 1) and float(hyp[0, 0]) == 425.0 and float(hyp[0, -1]) == 935.0
+    m.train()
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        m.Homoaggre[0]([torch.zeros(1, 64, 4, 4)] * 2, rp, sps[:1], hyp)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "config.py")), reason="reference tree not present (GPU box)")
+def test_reference_config_builds_on_our_slots():
+    code = (
+        "import sys, io, contextlib; sys.path.insert(0, %r)\n"
+        "from mdfnet_hip import dropin; dropin.install(%r)\n"
+        "import os; os.chdir('/tmp')\n"
+        "with contextlib.redirect_stdout(io.StringIO()):\n"
+        "    import config\n"
+        "import net.core, net.unit.regular\n"
+        "assert config.__file__.startswith(%r), config.__file__\n"
+        "assert net.core.__file__.startswith(%r), net.core.__file__\n"
+        "m = config.model\n"
+        "assert type(m).__module__ == 'net.core' and type(m.Regular[0]).__module__ == 'net.unit.regular'\n"
+        "from mdfnet_hip import ops  # our slots are HIP-backed\n"
+        "print(len(m.state_dict()), sum(p.numel() for p in m.parameters()))\n"
+    ) % (os.path.join(ROOT, "mdf-net_amd"), REF, REF, os.path.join(ROOT, "mdf-net_amd"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                       env={**os.environ, "PYTHONDONTWRITEBYTECODE": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip().splitlines()[-1] == "290 1206380"
