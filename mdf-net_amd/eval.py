@@ -1,0 +1,80 @@
+"""Evaluation driver (counterpart of the reference's eval.py:10-89): same CLI (-p/-d/-s), same outputs
+(<out>/<scan>/depth_est/%08d.pfm|.png, <out>/<scan>/confidence/%08d.pfm), same per-item print line — plus:
+one process per GPU with the item list sharded over ranks (`torchrun --nproc-per-node N eval.py ...`), a device
+synchronise before reading the clock (the reference's timing has none), and no collective on the data path."""
+import argparse
+import logging
+import os
+import time
+
+import torch
+from torch.utils.data import DataLoader, Subset
+
+from mdfnet_hip import shard
+from tools.data_io import save_pfm, write_depth_img
+
+
+def run_eval(model, dataset, device, output_path, rank=0, world=1, nworks=1, log=print):
+    """Shard `dataset` over ranks, run `model` item by item, write PFM/PNG.  Returns (n_items_this_rank, seconds)."""
+    idx = shard.shard_items(len(dataset), rank, world)
+    loader = DataLoader(Subset(dataset, idx), batch_size=1, num_workers=nworks, shuffle=False,
+                        pin_memory=(device.type == "cuda"), drop_last=False)
+    model.eval()
+    busy = 0.0
+    with torch.no_grad():
+        for it, data in enumerate(loader):
+            batch = {k: v.to(device, non_blocking=True) for k, v in data.items() if isinstance(v, torch.Tensor)}
+            if device.type == "cuda":
+                torch.cuda.synchronize(device)
+            t0 = time.time()
+            out = model(batch["imgs"], batch["extrinsics"], batch["intrinsics"], batch["depth_range"])
+            if device.type == "cuda":
+                torch.cuda.synchronize(device)
+            dt = time.time() - t0
+            busy += dt
+            mem = torch.cuda.max_memory_allocated(device) / (1024 ** 2) if device.type == "cuda" else 0.0
+            log("batch: " + str(it + 1) + "/" + str(len(loader)) + " time: {:.3f}".format(dt) + " memory: " + str(mem) + "MB")
+            for name, depth, conf in zip(data["filename"], out["depth"], out["confidence"]):
+                dfile = os.path.join(output_path, name.format("depth_est", ".pfm"))
+                cfile = os.path.join(output_path, name.format("confidence", ".pfm"))
+                os.makedirs(os.path.dirname(dfile), exist_ok=True)
+                os.makedirs(os.path.dirname(cfile), exist_ok=True)
+                save_pfm(dfile, depth.cpu().numpy())
+                write_depth_img(os.path.join(output_path, name.format("depth_est", ".png")), depth.cpu().numpy())
+                save_pfm(cfile, conf.cpu().numpy())
+                logging.info("save depth file in: " + dfile)
+    return len(idx), busy
+
+
+def main():
+    import config
+    parser = argparse.ArgumentParser(description="eval parameter setting")
+    parser.add_argument("-p", "--pre_model", default=None, type=str, help="Pre training model")
+    parser.add_argument("-d", "--dataset", default="dtu", type=str, choices=["dtu", "tanks"], help="Set dataset")
+    parser.add_argument("-s", "--set", default="intermediate", type=str, choices=["intermediate", "advanced"])
+    args = parser.parse_args()
+    logging.info(args)
+    rank, world, local = shard.init()
+    if args.dataset == "dtu":
+        load_args, eval_args = config.LoadDTU(), config.EvalDTU()
+        from load.dtueval import LoadDataset
+        dataset = LoadDataset(datasetpath=load_args.eval_root, pairpath=load_args.eval_pair,
+                              scencelist=load_args.eval_label, nviews=eval_args.nviews)
+    else:
+        load_args, eval_args = config.LoadTanks(tanks_set=args.set), config.EvalTanks()
+        from load.tankseval import LoadDataset
+        dataset = LoadDataset(datasetpath=load_args.eval_root, scenelist=load_args.scenelist, nviews=eval_args.nviews)
+    model = config.model
+    if args.pre_model is not None:
+        model.load_state_dict(torch.load(args.pre_model, map_location="cpu")["model"])
+    model.to(eval_args.DEVICE)
+    n, busy = run_eval(model, dataset, eval_args.DEVICE, eval_args.output_path, rank, world, eval_args.nworks)
+    dev = eval_args.DEVICE if eval_args.DEVICE.type == "cuda" else "cpu"
+    total, slowest = shard.sum_over_ranks(n, dev), shard.max_over_ranks(busy, dev)
+    if rank == 0:
+        logging.info("items: %d on %d rank(s); model time of the slowest rank %.3f s -> %.2f views/s",
+                     int(total), world, slowest, total / max(slowest, 1e-9))
+
+
+if __name__ == "__main__":
+    main()

@@ -41,9 +41,32 @@ def npy(t):
     return t.detach().cpu().numpy()
 
 
+def gen_io():
+    """PFM bytes written by the reference's tools/data_io.py:44-71 for a known array, and its parse of a pair file."""
+    import tempfile
+    sys.path.insert(0, REF)
+    from tools import data_io as ref_io
+    sys.path.remove(REF)
+    rng = np.random.RandomState(3)
+    img = (425 + 510 * rng.rand(5, 7)).astype(np.float32)
+    with tempfile.TemporaryDirectory() as d:
+        f = os.path.join(d, "a.pfm")
+        ref_io.save_pfm(f, img)
+        raw = np.frombuffer(open(f, "rb").read(), dtype=np.uint8)
+        back, scale = ref_io.read_pfm(f)
+        pair = os.path.join(d, "pair.txt")
+        open(pair, "w").write("2\n0\n3 1 9.5 2 8.0 3 7.5\n1\n2 0 9.5 2 6.0\n")
+        n, pairs = ref_io.read_pairfile(pair)
+    np.savez(os.path.join(OUT, "io.npz"), img=img, pfm_bytes=raw, pfm_back=np.ascontiguousarray(back), pfm_scale=scale,
+             pair_n=n, pair_ref=np.array([p[0] for p in pairs]), pair_src0=np.array(pairs[0][1]), pair_src1=np.array(pairs[1][1]))
+    print("io.npz written", raw.size, "bytes of PFM")
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
+    if "--only-io" in sys.argv:
+        return gen_io()
     cfg, base, agg, regress, dh, scale, ref_loss = load_reference()
     model = cfg.model
     sd = synth.seeded_state_dict(model.state_dict(), seed=1)
@@ -176,6 +199,7 @@ def main():
         tg["gt" + k] = npy(gt[k])
     np.savez_compressed(os.path.join(OUT, "train_tiny.npz"), **tg)
     print("train loss", float(loss))
+    gen_io()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 
