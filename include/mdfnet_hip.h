@@ -101,6 +101,19 @@ int64_t mdf_conv3d_packed_size(int Cin, int Cout);
  *   w: Conv3d [Cout,Cin,3,3,3] (transposed=0) or ConvTranspose3d [Cin,Cout,3,3,3] (transposed=1). */
 int mdf_conv3d_pack_weights(const float* w, float* wpack, int Cin, int Cout, int transposed, void* stream);
 
+/* ---- a11/a12  2-D convolution layers of the feature pyramid and refinement net (net/unit/backbone.py:17-45,
+ *      net/unit/refine.py:13-21, net/unit/base.py:7-25,71-82): Conv2d k in {1,3,5}, pad (k-1)/2, stride {1,2},
+ *      y = [res + res_scale *] ( [up2(res_up) +] [relu]( conv(x) * alpha + beta ) )
+ *      (alpha NULL: beta is the conv bias or NULL; res_up [B,Ho/2,Wo/2,Cout]: its bilinear x2 upsample,
+ *      align_corners=False, is added -- the FPN top-down step backbone.py:60,62 fused into the lateral conv).
+ *   x [B,H,W,Cin] NHWC; y [B,Ho,Wo,Cout] NHWC; wpack from mdf_conv_pack_weights (Cin 3 or 1 is zero-padded to 4).   */
+int mdf_conv2d_fwd(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
+                   float res_scale, const float* res_up, float* y, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int relu,
+                   void* stream);
+int64_t mdf_conv_packed_size(int Cin, int Cout, int ntaps);
+/* w: [Cout,Cin,k,k] (ntaps = k*k) or [Cout,Cin,3,3,3] (ntaps = 27), device -> device. */
+int mdf_conv_pack_weights(const float* w, float* wpack, int Cin, int Cout, int ntaps, void* stream);
+
 /* `prob` head: Conv3d(Cin->1,k3,p1,no bias) + softmax over D [+ soft-argmin]  (regular.py:43,69 /
  * :110,133 and net/unit/regress.py:5-7).  x NDHWC [B,D,h,w,Cin]; w [Cin*27] torch order [1,Cin,3,3,3];
  *   prob [B,D,h,w]; depth [B,h,w] or NULL; hypos as above (may be NULL when depth is NULL).       */

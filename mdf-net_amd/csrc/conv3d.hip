@@ -19,6 +19,7 @@
 // Modes: stride 1, stride 2, and ConvTranspose3d(k3,s2,p1,op1).  The transposed conv is computed per
 // output parity class (blockIdx.y = 0..7): inside a class every output voxel uses the same 1/2/4/8 taps,
 // so no MFMA is spent on structurally-zero taps.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -193,9 +194,10 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
 }
 
 // torch weights -> fragment order  wpack[tap][chunk][nt][q][n][s] = W(cout = nt*16+n, cin = chunk*CK + KPL*q + s, tap)
-__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int transposed) {
-  const int KPL = (Cin >= 16) ? 4 : 2, CK = 4 * KPL, NCH = Cin / CK, NT = (Cout + 15) / 16;
-  const int total = 27 * NCH * NT * 64 * KPL;
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cin_mem, int Cout,
+                                    int ntaps, int transposed) {
+  const int KPL = (Cin >= 16) ? 4 : (Cin == 8 ? 2 : 1), CK = 4 * KPL, NCH = Cin / CK, NT = (Cout + 15) / 16;
+  const int total = ntaps * NCH * NT * 64 * KPL;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     int r = i;
     const int s = r % KPL; r /= KPL;
@@ -206,7 +208,8 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     const int tap = r;
     const int cout = nt * 16 + n, cin = ch * CK + KPL * qq + s;
     float v = 0.f;
-    if (cout < Cout) v = transposed ? w[((size_t)cin * Cout + cout) * 27 + tap] : w[((size_t)cout * Cin + cin) * 27 + tap];
+    if (cout < Cout && cin < Cin_mem)
+      v = transposed ? w[((size_t)cin * Cout + cout) * ntaps + tap] : w[((size_t)cout * Cin_mem + cin) * ntaps + tap];
     wp[i] = v;
   }
 }
@@ -240,8 +243,43 @@ extern "C" int mdf_conv3d_pack_weights(const float* w, float* wpack, int Cin, in
   MDF_REQUIRE(w && wpack, "null pointer argument");
   MDF_REQUIRE(Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64, "Cin=%d not in {8,16,32,64}", Cin);
   MDF_REQUIRE(Cout >= 1 && Cout <= 64, "Cout=%d out of range", Cout);
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, wpack, Cin, Cout, transposed);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, wpack, Cin, Cin, Cout, 27, transposed);
   return mdf::check_launch("pack_weights_kernel");
+}
+
+static int padded_cin(int c) { return c <= 4 ? 4 : c; }
+
+extern "C" int64_t mdf_conv_packed_size(int Cin_mem, int Cout, int ntaps) {
+  if (Cin_mem < 1 || Cout < 1 || ntaps < 1) return 0;
+  return (int64_t)ntaps * padded_cin(Cin_mem) * (((Cout + 15) / 16) * 16);
+}
+
+extern "C" int mdf_conv_pack_weights(const float* w, float* wpack, int Cin_mem, int Cout, int ntaps, void* stream) {
+  MDF_REQUIRE(w && wpack, "null pointer argument");
+  const int Cin = padded_cin(Cin_mem);
+  MDF_REQUIRE(Cin == 4 || Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64, "Cin=%d not supported", Cin_mem);
+  MDF_REQUIRE(Cout >= 1 && Cout <= 64 && ntaps >= 1 && ntaps <= 27, "Cout=%d ntaps=%d out of range", Cout, ntaps);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, wpack, Cin, Cin_mem, Cout, ntaps, 0);
+  return mdf::check_launch("pack_weights_kernel");
+}
+
+int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
+                          float res_scale, const float* res_up, float* y, int B, int D, int H, int W, int Cin, int Cin_mem, int Cout, int KD,
+                          int KHW, int stride, int relu, void* stream);
+
+extern "C" int mdf_conv2d_fwd(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
+                              float res_scale, const float* res_up, float* y, int B, int H, int W, int Cin_mem, int Cout, int ksize, int stride,
+                              int relu, void* stream) {
+  MDF_REQUIRE(x && wpack && y, "null pointer argument");
+  MDF_REQUIRE(B > 0 && H > 0 && W > 0, "bad shape");
+  MDF_REQUIRE((long long)B * H * W * Cin_mem < (1ll << 31), "input too large for 32-bit offsets");
+  MDF_REQUIRE(res_up == nullptr || (stride == 1 && H % 2 == 0 && W % 2 == 0 && Cout % 4 == 0),
+              "res_up needs stride 1, even H and W, Cout %% 4 == 0");
+  const int rc = mdf_conv_lds_dispatch(x, wpack, alpha, beta, res, res_scale, res_up, y, B, 1, H, W, padded_cin(Cin_mem), Cin_mem, Cout, 1,
+                                       ksize, stride, relu, stream);
+  if (rc == MDF_EUNSUPPORTED)
+    return mdf::fail(MDF_EUNSUPPORTED, "conv2d Cin=%d Cout=%d k=%d stride=%d is not built", Cin_mem, Cout, ksize, stride);
+  return rc;
 }
 
 #define MDF_CONV_CASE(ci, co, mode)                          \
@@ -264,6 +302,14 @@ extern "C" int mdf_conv3d_fwd(const float* x, const float* wpack, const float* a
   else if (m == kS2) { p.Do = (Di - 1) / 2 + 1; p.Ho = (Hi - 1) / 2 + 1; p.Wo = (Wi - 1) / 2 + 1; }
   else { p.Do = 2 * Di; p.Ho = 2 * Hi; p.Wo = 2 * Wi; }
   p.m_total = (m == kTr) ? (long long)B * Di * Hi * Wi : (long long)B * p.Do * p.Ho * p.Wo;
+  static const long long lds_min = [] {  // test hook: MDF_CONV_LDS_MIN_VOXELS=0 forces the LDS kernel at any size
+    const char* e = getenv("MDF_CONV_LDS_MIN_VOXELS");
+    return e ? atoll(e) : 150000LL;
+  }();
+  if (m == kS1 && p.m_total >= lds_min) {  // large stride-1 layers: LDS-staged planes (conv_lds.hip)
+    const int rc = mdf_conv_lds_dispatch(x, wpack, alpha, beta, res, 1.0f, nullptr, y, B, Di, Hi, Wi, Cin, Cin, Cout, 3, 3, 1, relu, stream);
+    if (rc != MDF_EUNSUPPORTED) return rc;
+  }
   // stride 1 (every Cin x Cout the nets use)
   MDF_CONV_CASE(32, 16, kS1) MDF_CONV_CASE(16, 16, kS1) MDF_CONV_CASE(32, 32, kS1) MDF_CONV_CASE(64, 64, kS1)
   MDF_CONV_CASE(16, 8, kS1) MDF_CONV_CASE(8, 8, kS1) MDF_CONV_CASE(8, 16, kS1) MDF_CONV_CASE(16, 32, kS1)

@@ -1,0 +1,429 @@
+// conv v2: implicit-GEMM convolution with LDS-staged activation planes (fp32 MFMA 16x16x4), for the layers
+// that carry most of the work: stride-1 3x3x3 layers of the regularisers on large volumes, and (KD = 1) the
+// 2-D 3x3 / 5x5(stride 2) / 1x1 layers of the feature pyramid and refinement net.
+//
+// Why: conv v1 (conv3d.hip) fetches every B fragment (16 voxels x 16 cin) from L1/L2 once per tap, i.e. each
+// input voxel 27 times per output tile.  Here a block owns a TH x TW output tile and walks the depth axis with a
+// rolling window of KD input planes in LDS (halo included, zero-filled outside the volume, so the MFMA loop has
+// no bounds masks): every input voxel is fetched from global memory once per tile, B fragments come from LDS by
+// conflict-free ds_read_b128/b64 with immediate offsets (all taps unrolled), the next plane is prefetched into
+// registers while the current one is multiplied, and only the small packed-weight fragments stream through L1.
+//
+// LDS image of one plane:  [cin / KPL][S] vectors of KPL floats, S = plane-tile voxels rounded to 16 (mod 32), so
+// the lane groups of ds_read_b128 (and the two halves of ds_read_b64) fall on disjoint banks for every tap shift.
+// GEMM orientation and weight packing are those of conv3d.hip:  D[cout][voxel] = W[cout][k] * X[k][voxel].
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct LdsConvParams {
+  const float* x;      // [B,D,H,W,CIN_MEM]
+  const float* wpack;  // conv3d.hip packing (taps = KD*KHW*KHW)
+  const float* alpha;  // [COUT] or null
+  const float* beta;   // [COUT] or null (bias when alpha is null)
+  const float* res;    // [B,D,Ho,Wo,COUT] or null
+  const float* res_up; // [B,D,Ho/2,Wo/2,COUT] or null: bilinear x2 (align_corners=False) of it is added (FPN top-down)
+  float* y;            // [B,D,Ho,Wo,COUT]
+  float res_scale;     // y = res + res_scale * act(...)  (Res block: x + 0.1*conv)
+  int B, D, H, W, Ho, Wo;
+  int relu;
+  int tiles_h, tiles_w, dchunks, dch;  // item space (3-D: tile x depth chunk)
+  int n_items;
+  int n_tiles, tiles_per_item;         // 2-D: an item is a run of consecutive tiles
+};
+
+template <int N> struct VecT;
+template <> struct VecT<4> { typedef float4 type; };
+template <> struct VecT<2> { typedef float2 type; };
+template <> struct VecT<1> { typedef float type; };
+
+template <int KPL> __device__ __forceinline__ void vec_to(const typename VecT<KPL>::type& v, float* o);
+template <> __device__ __forceinline__ void vec_to<4>(const float4& v, float* o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+template <> __device__ __forceinline__ void vec_to<2>(const float2& v, float* o) { o[0] = v.x; o[1] = v.y; }
+template <> __device__ __forceinline__ void vec_to<1>(const float& v, float* o) { o[0] = v; }
+
+template <int KPL> __device__ __forceinline__ typename VecT<KPL>::type vec_zero();
+template <> __device__ __forceinline__ float4 vec_zero<4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+template <> __device__ __forceinline__ float2 vec_zero<2>() { return make_float2(0.f, 0.f); }
+template <> __device__ __forceinline__ float vec_zero<1>() { return 0.f; }
+
+// Dynamic work distribution: [0] next item, [1] finished blocks.  Module-level device words (nothing is allocated);
+// the last block of a launch resets both, so every launch starts from zero.  Launches of conv_lds_kernel must not
+// overlap on different streams of one device (the product issues everything on one stream).
+__device__ unsigned g_sched[2];
+
+constexpr int round_s(int n) {  // smallest s >= n with s % 32 == 16
+  int s = (n + 15) / 16 * 16;
+  return (s % 32 == 16) ? s : s + 16;
+}
+
+template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT>
+struct Cfg {
+  static constexpr int KPL = (CIN >= 16) ? 4 : (CIN == 8 ? 2 : 1);
+  static constexpr int CK = 4 * KPL;
+  static constexpr int NCH = CIN / CK;
+  static constexpr int NG = CIN / KPL;  // k-groups per voxel
+  static constexpr int NT = (COUT + 15) / 16;
+  static constexpr int TH = 4, TW = 16 * MT;
+  static constexpr int PAD = (KHW - 1) / 2, PD = (KD - 1) / 2;
+  static constexpr int PH = (TH - 1) * SHW + KHW, PW = (TW - 1) * SHW + KHW;
+  static constexpr int S = round_s(PH * PW);
+  static constexpr int PLANE = CIN * S;  // floats
+  static constexpr int NFILL = (NG * PH * PW + 255) / 256;
+  static constexpr int RING = (KD > 1) ? KD : 2;  // 3-D: rolling window of KD planes; 2-D: double-buffered tiles
+  static constexpr size_t LDS_BYTES = (size_t)RING * PLANE * sizeof(float) + 16;  // + the broadcast slot of the item id
+};
+
+// One output row-tile of one depth plane: MTL live m-tiles (16 voxels each) x all couts.  Fully unrolled over the
+// taps: LDS offsets are immediates, no bounds logic (halos are zero-filled in LDS).
+template <typename C, int KD, int KHW, int SHW, int COUT, int MTL>
+__device__ __forceinline__ void step(const float* const (&planes)[KD], const float* __restrict__ wl, const LdsConvParams& p,
+                                     size_t row_vox, int w0, int q, int n16) {
+  constexpr int KPL = C::KPL, NCH = C::NCH, NT = C::NT, S = C::S, PW = C::PW;
+  typedef typename VecT<KPL>::type vec_t;
+  f32x4 acc[MTL][NT];
+#pragma unroll
+  for (int t = 0; t < MTL; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // Software pipeline over the flattened (kd,kh,kw,chunk) steps.  hipcc otherwise places every operand load right
+  // before its MFMAs (prefetch distance <= 1), leaving the matrix pipe idle for an L1/L2 round trip per step.
+  // Weight fragments (global, L1-resident) run AHEAD_A steps ahead, LDS activation fragments one step ahead; the
+  // order is pinned with sched_barrier, the counted s_waitcnt is left to the compiler.
+  constexpr int NSTEP = KD * KHW * KHW * NCH;
+  constexpr int AHEAD_A = (NSTEP >= 3) ? 2 : (NSTEP - 1 > 0 ? NSTEP - 1 : 0);
+  constexpr int NA = AHEAD_A + 1;
+  float af[NA][NT][KPL], bf[2][MTL][KPL];
+  auto load_a = [&](int i, int buf) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      vec_to<KPL>(*reinterpret_cast<const vec_t*>(wl + (size_t)(i * NT + nt) * (64 * KPL)), af[buf][nt]);
+  };
+  auto load_b = [&](int i, int buf) {
+    const int ch = i % NCH, tap = i / NCH;
+    const int kw = tap % KHW, kh = (tap / KHW) % KHW, kd = tap / (KHW * KHW);
+#pragma unroll
+    for (int t = 0; t < MTL; ++t)
+      vec_to<KPL>(*reinterpret_cast<const vec_t*>(planes[kd] + ((ch * 4) * S + kh * PW + kw + t * 16 * SHW) * KPL), bf[buf][t]);
+  };
+#pragma unroll
+  for (int i = 0; i < AHEAD_A; ++i) load_a(i, i % NA);
+  load_b(0, 0);
+#pragma unroll
+  for (int i = 0; i < NSTEP; ++i) {
+    if (i + AHEAD_A < NSTEP) load_a(i + AHEAD_A, (i + AHEAD_A) % NA);
+    if (i + 1 < NSTEP) load_b(i + 1, (i + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < KPL; ++s)
+#pragma unroll
+      for (int t = 0; t < MTL; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i % NA][nt][s], bf[i & 1][t][s], acc[t][nt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // epilogue: lane owns couts nt*16 + 4q .. +3 of voxel (row, w0 + t*16 + n16)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int c0 = nt * 16 + 4 * q;
+    if (c0 >= COUT) continue;
+    float al[4] = {1.f, 1.f, 1.f, 1.f}, be[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (c0 + k < COUT) {
+        if (p.alpha) al[k] = p.alpha[c0 + k];
+        if (p.beta) be[k] = p.beta[c0 + k];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < MTL; ++t) {
+      const int ow = w0 + t * 16 + n16;
+      if (ow >= p.Wo) continue;
+      float o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        o[k] = acc[t][nt][k] * al[k] + be[k];
+        if (p.relu) o[k] = fmaxf(o[k], 0.f);
+      }
+      const size_t oi = (row_vox + ow) * COUT + c0;
+      if (COUT % 4 == 0) {
+        if (p.res_up) {  // + F.interpolate(top, scale_factor=2, bilinear, align_corners=False)[row, ow]   (backbone.py:60,62)
+          const int Hh = p.Ho >> 1, Wh = p.Wo >> 1;
+          const size_t rr = row_vox / p.Wo;             // (b*D + d)*Ho + oh
+          const int oh = (int)(rr % p.Ho);
+          const size_t img = rr / p.Ho;
+          float sy = ((float)oh + 0.5f) * 0.5f - 0.5f; sy = sy < 0.f ? 0.f : sy;
+          float sx = ((float)ow + 0.5f) * 0.5f - 0.5f; sx = sx < 0.f ? 0.f : sx;
+          const int y0 = (int)sy, x0 = (int)sx;
+          const int y1 = y0 + (y0 < Hh - 1), x1 = x0 + (x0 < Wh - 1);
+          const float ly1 = sy - (float)y0, ly0 = 1.f - ly1, lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+          const float* base = p.res_up + img * Hh * Wh * COUT + c0;
+          const float4 v00 = *reinterpret_cast<const float4*>(base + ((size_t)y0 * Wh + x0) * COUT);
+          const float4 v01 = *reinterpret_cast<const float4*>(base + ((size_t)y0 * Wh + x1) * COUT);
+          const float4 v10 = *reinterpret_cast<const float4*>(base + ((size_t)y1 * Wh + x0) * COUT);
+          const float4 v11 = *reinterpret_cast<const float4*>(base + ((size_t)y1 * Wh + x1) * COUT);
+          const float w00 = ly0 * lx0, w01 = ly0 * lx1, w10 = ly1 * lx0, w11 = ly1 * lx1;
+          // torch order: interpolate(...) + lat(x)  ->  up + o
+          o[0] = __fmaf_rn(w11, v11.x, __fmaf_rn(w10, v10.x, __fmaf_rn(w00, v00.x, w01 * v01.x))) + o[0];
+          o[1] = __fmaf_rn(w11, v11.y, __fmaf_rn(w10, v10.y, __fmaf_rn(w00, v00.y, w01 * v01.y))) + o[1];
+          o[2] = __fmaf_rn(w11, v11.z, __fmaf_rn(w10, v10.z, __fmaf_rn(w00, v00.z, w01 * v01.z))) + o[2];
+          o[3] = __fmaf_rn(w11, v11.w, __fmaf_rn(w10, v10.w, __fmaf_rn(w00, v00.w, w01 * v01.w))) + o[3];
+        }
+        if (p.res) {
+          const float4 rr = *reinterpret_cast<const float4*>(p.res + oi);
+          o[0] = rr.x + o[0] * p.res_scale; o[1] = rr.y + o[1] * p.res_scale;
+          o[2] = rr.z + o[2] * p.res_scale; o[3] = rr.w + o[3] * p.res_scale;
+        }
+        *reinterpret_cast<float4*>(p.y + oi) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (c0 + k < COUT) p.y[oi + k] = p.res ? p.res[oi + k] + o[k] * p.res_scale : o[k];
+        }
+      }
+    }
+  }
+}
+
+template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT>
+__global__ __launch_bounds__(256) void conv_lds_kernel(const LdsConvParams p) {
+  typedef Cfg<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT> C;
+  constexpr int KPL = C::KPL, NG = C::NG, S = C::S, PW = C::PW, PH = C::PH;
+  typedef typename VecT<KPL>::type vec_t;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, n16 = lane & 15;
+  const float* wl = p.wpack + (size_t)lane * KPL;
+  // lane-constant part of the B-fragment LDS address (floats)
+  const int lane_lds = (q * S + wave * SHW * PW + n16 * SHW) * KPL;
+
+  int* item_slot = reinterpret_cast<int*>(lds + C::RING * C::PLANE);
+  for (;;) {
+    __syncthreads();  // previous item's readers are done with the ring (and with item_slot)
+    if (tid == 0) *item_slot = (int)atomicAdd(&g_sched[0], 1u);
+    __syncthreads();
+    const int item = *item_slot;
+    if (item >= p.n_items) break;
+    if constexpr (KD == 1) {
+      // ------------------------------------------------------------------ 2-D: run of tiles, double-buffered
+      const int t_begin = item * p.tiles_per_item, t_end = min(t_begin + p.tiles_per_item, p.n_tiles);
+      auto tile_origin = [&](int tl, int& tb, int& th0, int& tw0) {
+        const int twi = tl % p.tiles_w;
+        const int rest = tl / p.tiles_w;
+        tb = rest / p.tiles_h;
+        th0 = (rest % p.tiles_h) * C::TH;
+        tw0 = twi * C::TW;
+      };
+      auto load2 = [&](int idx, int tb, int th0, int tw0) -> vec_t {
+        const int g = idx / (PH * PW), v = idx - g * (PH * PW);
+        const int row = v / PW, col = v - row * PW;
+        const int ih = th0 * SHW - C::PAD + row, iw = tw0 * SHW - C::PAD + col;
+        if (idx >= NG * PH * PW || ih < 0 || ih >= p.H || iw < 0 || iw >= p.W) return vec_zero<KPL>();
+        const float* src = p.x + (((size_t)tb * p.H + ih) * p.W + iw) * CIN_MEM + g * KPL;
+        if (CIN_MEM == CIN) return *reinterpret_cast<const vec_t*>(src);
+        float o[KPL];
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) o[k] = (g * KPL + k < CIN_MEM) ? src[k] : 0.f;
+        return *reinterpret_cast<vec_t*>(o);
+      };
+      auto store2 = [&](int idx, int slot, const vec_t& val) {
+        if (idx < NG * PH * PW) {
+          const int g = idx / (PH * PW), v = idx - g * (PH * PW);
+          *reinterpret_cast<vec_t*>(lds + slot * C::PLANE + (g * S + v) * KPL) = val;
+        }
+      };
+      int tb, th0, tw0;
+      tile_origin(t_begin, tb, th0, tw0);
+#pragma unroll
+      for (int k = 0; k < C::NFILL; ++k) store2(tid + k * 256, 0, load2(tid + k * 256, tb, th0, tw0));
+      __syncthreads();
+      for (int tl = t_begin; tl < t_end; ++tl) {
+        const int slot = (tl - t_begin) & 1;
+        const bool row_live2 = (th0 + wave) < p.Ho;
+        const int cols2 = min(p.Wo - tw0, C::TW);
+        const int mt_live2 = row_live2 ? (cols2 + 15) / 16 : 0;
+        if (mt_live2 > 0) {
+          const float* planes[1] = {lds + slot * C::PLANE + lane_lds};
+          const size_t row_vox = ((size_t)tb * p.Ho + (th0 + wave)) * p.Wo;
+          switch (mt_live2) {
+            case 1: step<C, KD, KHW, SHW, COUT, 1>(planes, wl, p, row_vox, tw0, q, n16); break;
+            case 2: if (MT >= 2) step<C, KD, KHW, SHW, COUT, (MT >= 2 ? 2 : 1)>(planes, wl, p, row_vox, tw0, q, n16); break;
+            case 3: if (MT >= 3) step<C, KD, KHW, SHW, COUT, (MT >= 3 ? 3 : 1)>(planes, wl, p, row_vox, tw0, q, n16); break;
+            default: step<C, KD, KHW, SHW, COUT, MT>(planes, wl, p, row_vox, tw0, q, n16); break;
+          }
+        }
+        if (tl + 1 < t_end) {
+          // next tile -> the other slot.  Every wave passed the barrier before this tile's compute, so nobody still
+          // reads that slot; one barrier (after the writes) per tile.
+          tile_origin(tl + 1, tb, th0, tw0);
+          vec_t pf[C::NFILL];
+#pragma unroll
+          for (int k = 0; k < C::NFILL; ++k) pf[k] = load2(tid + k * 256, tb, th0, tw0);
+#pragma unroll
+          for (int k = 0; k < C::NFILL; ++k) store2(tid + k * 256, slot ^ 1, pf[k]);
+          __syncthreads();
+        }
+      }
+      continue;
+    } else {
+    int r = item;
+    const int dc = r % p.dchunks; r /= p.dchunks;
+    const int tw = r % p.tiles_w; r /= p.tiles_w;
+    const int th = r % p.tiles_h;
+    const int b = r / p.tiles_h;
+    const int h0 = th * C::TH, w0 = tw * C::TW;           // output tile origin
+    const int ih0 = h0 * SHW - C::PAD, iw0 = w0 * SHW - C::PAD;  // input tile origin
+    const int d0 = dc * p.dch, d1 = min(d0 + p.dch, p.D);
+    const bool row_live = (h0 + wave) < p.Ho;
+    const int cols = min(p.Wo - w0, C::TW);
+    const int mt_live = row_live ? (cols + 15) / 16 : 0;  // wave-uniform
+
+    // ---- plane fill helpers -------------------------------------------------------------------------
+    auto load_elem = [&](int idx, int dz) -> vec_t {
+      const int g = idx / (PH * PW), v = idx - g * (PH * PW);
+      const int row = v / PW, col = v - row * PW;
+      const int ih = ih0 + row, iw = iw0 + col;
+      if (idx >= NG * PH * PW || dz < 0 || dz >= p.D || ih < 0 || ih >= p.H || iw < 0 || iw >= p.W) return vec_zero<KPL>();
+      const float* src = p.x + ((((size_t)b * p.D + dz) * p.H + ih) * p.W + iw) * CIN_MEM + g * KPL;
+      if (CIN_MEM == CIN) return *reinterpret_cast<const vec_t*>(src);
+      // channel-padded input (e.g. RGB -> 4): KPL == 1
+      float o[KPL];
+#pragma unroll
+      for (int k = 0; k < KPL; ++k) o[k] = (g * KPL + k < CIN_MEM) ? src[k] : 0.f;
+      return *reinterpret_cast<vec_t*>(o);
+    };
+    auto store_elem = [&](int idx, int slot, const vec_t& val) {
+      if (idx < NG * PH * PW) {
+        const int g = idx / (PH * PW), v = idx - g * (PH * PW);
+        *reinterpret_cast<vec_t*>(lds + slot * C::PLANE + (g * S + v) * KPL) = val;
+      }
+    };
+    auto slot_of = [](int dz) { return (KD == 1) ? 0 : ((dz % KD) + KD) % KD; };
+
+    // prologue: planes d0-PD .. d0+PD
+#pragma unroll 1
+    for (int dz = d0 - C::PD; dz <= d0 + C::PD; ++dz) {
+#pragma unroll
+      for (int k = 0; k < C::NFILL; ++k) store_elem(tid + k * 256, slot_of(dz), load_elem(tid + k * 256, dz));
+    }
+    __syncthreads();
+
+    for (int d = d0; d < d1; ++d) {
+      const bool more = (KD > 1) && (d + 1 < d1);
+      if (mt_live > 0) {
+        const float* planes[KD];
+#pragma unroll
+        for (int kd = 0; kd < KD; ++kd) planes[kd] = lds + slot_of(d + kd - C::PD) * C::PLANE + lane_lds;
+        const size_t row_vox = (((size_t)b * p.D + d) * p.Ho + (h0 + wave)) * p.Wo;
+        switch (mt_live) {
+          case 1: step<C, KD, KHW, SHW, COUT, 1>(planes, wl, p, row_vox, w0, q, n16); break;
+          case 2: if (MT >= 2) step<C, KD, KHW, SHW, COUT, (MT >= 2 ? 2 : 1)>(planes, wl, p, row_vox, w0, q, n16); break;
+          case 3: if (MT >= 3) step<C, KD, KHW, SHW, COUT, (MT >= 3 ? 3 : 1)>(planes, wl, p, row_vox, w0, q, n16); break;
+          default: step<C, KD, KHW, SHW, COUT, MT>(planes, wl, p, row_vox, w0, q, n16); break;
+        }
+      }
+      if (more) {
+        // fetch the plane the next step needs (d+1+PD).  Issued AFTER the MFMA block: vmcnt retires in order, so
+        // plane loads queued ahead of the weight-fragment loads would stall the first MFMA of the step; the other
+        // resident block of the CU computes while this one refills.
+        vec_t pf[C::NFILL];
+#pragma unroll
+        for (int k = 0; k < C::NFILL; ++k) pf[k] = load_elem(tid + k * 256, d + 1 + C::PD);
+        __syncthreads();  // all waves finished reading plane d-PD: its slot is free
+#pragma unroll
+        for (int k = 0; k < C::NFILL; ++k) store_elem(tid + k * 256, slot_of(d + 1 + C::PD), pf[k]);
+        __syncthreads();
+      }
+    }
+    }  // 3-D path
+  }
+  if (tid == 0) {
+    const unsigned done = atomicAdd(&g_sched[1], 1u);
+    if (done == gridDim.x - 1) {  // last block out: re-arm the counters for the next launch
+      g_sched[0] = 0u;
+      g_sched[1] = 0u;
+      __threadfence();
+    }
+  }
+}
+
+template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT>
+int launch_lds(LdsConvParams& p, hipStream_t st) {
+  typedef Cfg<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT> C;
+  p.tiles_h = (p.Ho + C::TH - 1) / C::TH;
+  p.tiles_w = (p.Wo + C::TW - 1) / C::TW;
+  const long long tiles = (long long)p.B * p.tiles_h * p.tiles_w;
+  const int blocks_per_cu = (int)(160 * 1024 / C::LDS_BYTES) < 1 ? 1 : (int)(160 * 1024 / C::LDS_BYTES);
+  const int max_grid = 256 * (blocks_per_cu > 4 ? 4 : blocks_per_cu);
+  // 3-D: items = tile x depth chunk, handed out dynamically; aim for >= ~6 items per resident block (smooths the cheaper
+  // partially-filled tile columns) while keeping >= 3 planes per chunk (prologue = KD-1 extra planes).
+  // 2-D: items = runs of consecutive tiles (double-buffered inside the run), ~8 runs per resident block.
+  if (KD > 1) {
+    long long want = (6LL * max_grid + tiles - 1) / tiles;
+    if (want < 1) want = 1;
+    int dch = (int)(p.D / want);
+    if (dch < 3) dch = 3;
+    if (dch > p.D) dch = p.D;
+    p.dch = dch;
+    p.dchunks = (p.D + dch - 1) / dch;
+    const long long items = tiles * p.dchunks;
+    if (items > 0x7fffffff) return mdf::fail(MDF_EARG, "conv_lds: too many work items");
+    p.n_items = (int)items;
+  } else {
+    if (p.D != 1) return mdf::fail(MDF_EARG, "2-D conv path needs D == 1");
+    if (tiles > 0x7fffffff) return mdf::fail(MDF_EARG, "conv_lds: too many tiles");
+    p.n_tiles = (int)tiles;
+    long long tpi = tiles / (8LL * max_grid);
+    if (tpi < 1) tpi = 1;
+    if (tpi > 64) tpi = 64;
+    p.tiles_per_item = (int)tpi;
+    p.n_items = (int)((tiles + tpi - 1) / tpi);
+    p.dch = 1; p.dchunks = 1;
+  }
+  static bool attr_done = false;  // benign race: the call is idempotent
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    if (e != hipSuccess) return mdf::fail(MDF_EHIP, "hipFuncSetAttribute(dynamic LDS %zu): %s", C::LDS_BYTES, hipGetErrorString(e));
+    attr_done = true;
+  }
+  int grid = max_grid;
+  if (grid > p.n_items) grid = p.n_items;
+  hipLaunchKernelGGL((conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT>), dim3(grid), dim3(256), C::LDS_BYTES, st, p);
+  return mdf::check_launch("conv_lds_kernel");
+}
+
+}  // namespace
+
+// Internal entry used by mdf_conv3d_fwd (stride-1 3x3x3) and mdf_conv2d_fwd.  Returns MDF_EUNSUPPORTED when the
+// configuration has no LDS-kernel instantiation (caller falls back to conv v1 / reports the error).
+#define LDS_CASE(ci, cim, co, kd, k, s, mt)                                                      \
+  if (Cin == ci && Cin_mem == cim && Cout == co && KD == kd && KHW == k && stride == s)          \
+    return launch_lds<ci, cim, co, kd, k, s, mt>(p, (hipStream_t)stream);
+
+int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
+                          float res_scale, const float* res_up, float* y, int B, int D, int H, int W, int Cin, int Cin_mem, int Cout, int KD,
+                          int KHW, int stride, int relu, void* stream) {
+  LdsConvParams p{};
+  p.x = x; p.wpack = wpack; p.alpha = alpha; p.beta = beta; p.res = res; p.res_scale = res_scale; p.res_up = res_up; p.y = y;
+  p.B = B; p.D = D; p.H = H; p.W = W; p.relu = relu;
+  const int pad = (KHW - 1) / 2;
+  p.Ho = (H + 2 * pad - KHW) / stride + 1;
+  p.Wo = (W + 2 * pad - KHW) / stride + 1;
+  // 3-D regulariser layers (stride 1)
+  LDS_CASE(32, 32, 16, 3, 3, 1, 2) LDS_CASE(16, 16, 16, 3, 3, 1, 4) LDS_CASE(16, 16, 8, 3, 3, 1, 4) LDS_CASE(8, 8, 8, 3, 3, 1, 4)
+  LDS_CASE(32, 32, 32, 3, 3, 1, 2)
+  // 2-D layers of the feature pyramid / refinement (KD = 1)
+  LDS_CASE(4, 3, 8, 1, 3, 1, 4) LDS_CASE(8, 8, 8, 1, 3, 1, 4) LDS_CASE(16, 16, 16, 1, 3, 1, 4) LDS_CASE(32, 32, 32, 1, 3, 1, 2)
+  LDS_CASE(64, 64, 64, 1, 3, 1, 1)
+  LDS_CASE(8, 8, 16, 1, 5, 2, 2) LDS_CASE(16, 16, 32, 1, 5, 2, 2) LDS_CASE(32, 32, 64, 1, 5, 2, 1)
+  LDS_CASE(16, 16, 64, 1, 1, 1, 4) LDS_CASE(32, 32, 64, 1, 1, 1, 2) LDS_CASE(64, 64, 16, 1, 1, 1, 1) LDS_CASE(64, 64, 32, 1, 1, 1, 1)
+  LDS_CASE(64, 64, 64, 1, 1, 1, 1)
+  LDS_CASE(4, 1, 8, 1, 3, 1, 4) LDS_CASE(8, 8, 32, 1, 3, 1, 4) LDS_CASE(8, 8, 1, 1, 3, 1, 4)
+  return MDF_EUNSUPPORTED;
+}

@@ -1,0 +1,48 @@
+"""Glue between torch parameter containers (the reference's module tree, kept for state_dict compatibility) and
+the fused conv kernels: per-layer cache of packed weights + folded BatchNorm, rebuilt when a tensor changes."""
+import torch
+
+from . import ops
+
+
+class _Folded:
+    def __init__(self):
+        self.key, self.val = None, None
+
+    def get(self, tensors, build):
+        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors if t is not None)
+        if key != self.key:
+            with torch.no_grad():
+                self.val = build()
+            self.key = key
+        return self.val
+
+
+def cache_of(mod):
+    c = mod.__dict__.get("_mdf_cache")
+    if c is None:
+        c = mod.__dict__["_mdf_cache"] = _Folded()
+    return c
+
+
+def hip_eval(mod, x):
+    """True when the fused HIP path applies: eval mode on a GPU tensor."""
+    return (not mod.training) and x.is_cuda
+
+
+def conv2d_layer(conv, bn, x, relu=False, res=None, res_scale=1.0, res_up=None):
+    """Conv2d [+ BatchNorm2d eval] [+ ReLU] [+ residual / upsample-add] as one kernel.  x, res: [B,H,W,C] NHWC."""
+    k = conv.kernel_size[0]
+    tensors = [conv.weight, conv.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
+
+    def build():
+        wp = ops.pack_conv2d_weight(conv.weight)
+        if bn is not None:
+            alpha, beta = ops.fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+            if conv.bias is not None:
+                beta = (beta + conv.bias.float() * alpha).contiguous()
+            return wp, alpha, beta
+        return wp, None, (None if conv.bias is None else conv.bias.detach().float().contiguous())
+
+    wp, alpha, beta = cache_of(conv).get(tensors, build)
+    return ops.conv2d_nhwc(x, wp, conv.in_channels, conv.out_channels, k, conv.stride[0], alpha, beta, relu, res, res_scale, res_up)

@@ -300,3 +300,43 @@ def fold_bn(bn_weight, bn_bias, running_mean, running_var, eps=1e-5):
     alpha = (bn_weight.float() * invstd).contiguous()
     beta = (bn_bias.float() - running_mean.float() * alpha).contiguous()
     return alpha, beta
+
+
+# --------------------------------------------------------------------------- 2-D conv layers (NHWC)
+def pack_conv2d_weight(w):
+    """torch Conv2d weight [Cout,Cin,k,k] -> MFMA fragment order (Cin 1 or 3 is zero-padded to 4)."""
+    _need_gpu(w)
+    cout, cin, k, _ = w.shape
+    n = lib().mdf_conv_packed_size(cin, cout, k * k)
+    out = torch.empty((n,), device=w.device, dtype=torch.float32)
+    _abi("mdf_conv_pack_weights", (_f32c(w.detach()).data_ptr(), out.data_ptr(), cin, cout, k * k, _stream(out),))
+    return out
+
+
+def conv2d_nhwc(x, wpack, cin, cout, ksize, stride=1, alpha=None, beta=None, relu=False, res=None, res_scale=1.0,
+                res_up=None):
+    """y = [res + res_scale *] ([up2(res_up) +] [relu](conv(x)*alpha + beta)).  x [B,H,W,Cin] contiguous."""
+    _need_gpu(x, wpack)
+    b, h, w, c = x.shape
+    assert c == cin and x.is_contiguous()
+    pad = (ksize - 1) // 2
+    ho, wo = (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
+    y = torch.empty((b, ho, wo, cout), device=x.device, dtype=torch.float32)
+    _abi("mdf_conv2d_fwd", (x.data_ptr(), wpack.data_ptr(), None if alpha is None else alpha.data_ptr(),
+                            None if beta is None else beta.data_ptr(), None if res is None else res.data_ptr(),
+                            ctypes.c_float(res_scale), None if res_up is None else res_up.data_ptr(), y.data_ptr(),
+                            b, h, w, cin, cout, ksize, stride, int(relu), _stream(y),),
+         tag=f"{cin}->{cout} k{ksize}s{stride} {h}x{w}x{b}",
+         work={"flops": 2.0 * ksize * ksize * cin * cout * b * ho * wo, "bytes": 4.0 * (x.numel() + y.numel()),
+               "bound": "mfma"})
+    return y
+
+
+def to_nhwc(t):
+    """logical [B,C,H,W] -> contiguous [B,H,W,C] (no copy when the memory is already channels_last)."""
+    cl = t.permute(0, 2, 3, 1)
+    return cl if (cl.is_contiguous() and cl.dtype == torch.float32) else cl.float().contiguous()
+
+
+def from_nhwc(cl):
+    return cl.permute(0, 3, 1, 2)

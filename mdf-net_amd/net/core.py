@@ -23,8 +23,14 @@ class CoreNet(torch.nn.Module):
             # mirrors and never synchronise again
             for t in (extrinsics, intrinsics, depth_range):
                 hostmirror.put(t, t.detach().cpu())
-        views = torch.unbind(origin_imgs.float(), 1)
-        pyramids = [self.Backbone(v) for v in views]
+        imgs = origin_imgs.float()
+        nb, nv = imgs.shape[:2]
+        if getattr(self.Backbone, "batch_views", False) and not self.training:
+            # eval BatchNorm is per-sample: one batched pass over the B*V images == V separate calls (core.py:42)
+            f = self.Backbone(imgs.reshape(nb * nv, *imgs.shape[2:]))
+            pyramids = [tuple(lv.reshape(nb, nv, *lv.shape[1:])[:, v] for lv in f) for v in range(nv)]
+        else:
+            pyramids = [self.Backbone(v) for v in torch.unbind(imgs, 1)]
         depth = hypos = prob = None
         depths = []
         for stage, (make_hypos, aggregate, regular) in enumerate(zip(self.Depth_hypos, self.Homoaggre, self.Regular)):

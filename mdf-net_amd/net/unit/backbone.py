@@ -1,11 +1,14 @@
-"""Feature pyramid (reference: net/unit/backbone.py:9-66).  Surface only: stock PyTorch-ROCm 2-D convs
-(MIOpen), run in channels_last so the three outputs are already NHWC for the aggregation kernel."""
+"""Feature pyramid (reference: net/unit/backbone.py:9-66).  Eval on a GPU: every Conv2d+BN+ReLU is one fused
+implicit-GEMM MFMA kernel (conv_lds.hip, NHWC), the FPN top-down step (bilinear x2 + lateral 1x1 conv + add) is fused
+into the lateral conv's epilogue, and the three outputs are NHWC in memory, ready for the aggregation kernel.
+Training / CPU: the stock PyTorch modules (same parameters)."""
 from typing import Tuple
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from mdfnet_hip import layers, ops
 from .base import ConvBNReLU
 
 
@@ -15,6 +18,8 @@ def _stage(cin, cout, first_k, first_s):
 
 
 class FPN_4Scales(nn.Module):
+    batch_views = True   # CoreNet may push all views through in one batched call (eval BN is per-sample)
+
     def __init__(self, out_chs: Tuple = (8, 16, 32, 64)) -> None:
         super().__init__()
         c0, c1, c2, c3 = out_chs
@@ -28,10 +33,26 @@ class FPN_4Scales(nn.Module):
         self.out3 = nn.Conv2d(c3, c2, 1, bias=False)
         self.out4 = nn.Conv2d(c3, c3, 1, bias=False)
 
+    def _hip_forward(self, x):
+        def seq(blocks, t):
+            for blk in blocks:
+                t = layers.conv2d_layer(blk.conv, blk.bn, t, relu=True)
+            return t
+        with torch.no_grad():
+            t2 = seq(self.conv12, seq(self.conv01, ops.to_nhwc(x)))
+            t3 = seq(self.conv23, t2)
+            t4 = seq(self.conv34, t3)
+            y4 = layers.conv2d_layer(self.out4, None, t4)
+            up3 = layers.conv2d_layer(self.lat3, None, t3, res_up=t4)    # interpolate(t4) + lat3(t3)
+            y3 = layers.conv2d_layer(self.out3, None, up3)
+            up2 = layers.conv2d_layer(self.lat2, None, t2, res_up=up3)   # interpolate(up3) + lat2(t2)
+            y2 = layers.conv2d_layer(self.out2, None, up2)
+        return ops.from_nhwc(y4), ops.from_nhwc(y3), ops.from_nhwc(y2)
+
     def forward(self, x: torch.Tensor):
         """[B,3,H,W] -> (1/8: 64ch, 1/4: 32ch, 1/2: 16ch)   (backbone.py:50-66)."""
-        if x.is_cuda:
-            x = x.contiguous(memory_format=torch.channels_last)
+        if layers.hip_eval(self, x):
+            return self._hip_forward(x)
         t2 = self.conv12(self.conv01(x))
         t3 = self.conv23(t2)
         t4 = self.conv34(t3)

@@ -1,6 +1,10 @@
-"""Depth refinement / x2 upsampling (reference: net/unit/refine.py:8-46).  Surface only: stock 2-D convs."""
+"""Depth refinement / x2 upsampling (reference: net/unit/refine.py:8-46).  Eval on a GPU: fused implicit-GEMM conv
+kernels (NHWC) with the Res-block update x + 0.1*conv(...) and the skip add in the conv epilogues; training / CPU: stock
+PyTorch modules."""
 import torch
 import torch.nn as nn
+
+from mdfnet_hip import layers, ops
 
 from .base import Res
 
@@ -19,6 +23,19 @@ class RefineNet2(nn.Module):
         b = depth.shape[0]
         lo = depth_range[:, 0].float().view(b, 1, 1, 1)
         span = depth_range[:, 1].float().view(b, 1, 1, 1) - lo
+        if layers.hip_eval(self, depth):
+            with torch.no_grad():
+                x = ((depth.detach().unsqueeze(1) - lo) / span).permute(0, 2, 3, 1).contiguous()   # [B,h,w,1]
+                x0 = layers.conv2d_layer(self.conv0, None, x)
+                y = x0
+                for blk in self.ress:                                                               # x + 0.1*conv(relu(conv(x)))
+                    t = layers.conv2d_layer(blk.conv[0], None, y, relu=True)
+                    y = layers.conv2d_layer(blk.conv[2], None, t, res=y, res_scale=0.1)
+                y = layers.conv2d_layer(self.conv1, None, y, res=x0)                               # x0 + conv1(y)
+                y = layers.conv2d_layer(self.conv2[0], None, y)                                    # [B,h,w,32]
+                y = torch.nn.functional.pixel_shuffle(y.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).contiguous()
+                y = layers.conv2d_layer(self.conv2[2], None, y)                                    # [B,2h,2w,1]
+                return (lo + y.permute(0, 3, 1, 2) * span).squeeze(1)
         x0 = self.conv0((depth.detach().unsqueeze(1) - lo) / span)
         y = x0
         for blk in self.ress:

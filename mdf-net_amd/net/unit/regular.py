@@ -8,29 +8,8 @@ import torch
 import torch.nn as nn
 
 from mdfnet_hip import ops
+from mdfnet_hip.layers import cache_of as _cache
 from .base import ConvBNReLU3D
-
-
-class _Folded:
-    """Per-layer cache of packed weights and folded BN, rebuilt when any tensor changes."""
-
-    def __init__(self):
-        self.key, self.val = None, None
-
-    def get(self, tensors, build):
-        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors)
-        if key != self.key:
-            with torch.no_grad():
-                self.val = build()
-            self.key = key
-        return self.val
-
-
-def _cache(mod):
-    c = mod.__dict__.get("_mdf_cache")
-    if c is None:
-        c = mod.__dict__["_mdf_cache"] = _Folded()
-    return c
 
 
 def run_layer(block, x, res=None):

@@ -1,0 +1,67 @@
+"""GPU parity: fused 2-D conv layers (feature pyramid / refinement) vs torch-CPU and the reference goldens."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from mdfnet_hip import ops, synth
+from modelutil import build_model
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+DEV = "cuda:0"
+
+# (cin, cout, k, stride) = every 2-D layer shape of FPN_4Scales and RefineNet2
+COMBOS = [(3, 8, 3, 1), (8, 8, 3, 1), (8, 16, 5, 2), (16, 16, 3, 1), (16, 32, 5, 2), (32, 32, 3, 1), (32, 64, 5, 2),
+          (64, 64, 3, 1), (64, 64, 1, 1), (32, 64, 1, 1), (64, 32, 1, 1), (16, 64, 1, 1), (64, 16, 1, 1),
+          (1, 8, 3, 1), (8, 32, 3, 1), (8, 1, 3, 1)]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride", COMBOS)
+@pytest.mark.parametrize("shape", [(1, 8, 16), (2, 13, 37), (1, 40, 136)])
+def test_conv2d_layer(cin, cout, k, stride, shape):
+    b, h, w = shape
+    rng = np.random.RandomState(cin * 7 + cout * 3 + k + h)
+    x = T(rng.randn(b, cin, h, w).astype(np.float32))
+    wt = T((rng.randn(cout, cin, k, k) / np.sqrt(k * k * cin)).astype(np.float32))
+    alpha = T(rng.uniform(0.5, 1.5, cout).astype(np.float32))
+    beta = T(rng.uniform(-0.2, 0.2, cout).astype(np.float32))
+    ref = F.conv2d(x, wt, None, stride, (k - 1) // 2)
+    res = T(rng.randn(*ref.shape).astype(np.float32))
+    exp = res + 0.1 * F.relu(ref * alpha.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1))
+    wp = ops.pack_conv2d_weight(wt.to(DEV))
+    y = ops.conv2d_nhwc(ops.to_nhwc(x.to(DEV)), wp, cin, cout, k, stride, alpha.to(DEV), beta.to(DEV), True,
+                        ops.to_nhwc(res.to(DEV)), 0.1)
+    got = ops.from_nhwc(y).cpu()
+    assert got.shape == exp.shape
+    np.testing.assert_allclose(got.numpy(), exp.numpy(), rtol=1e-4, atol=2e-5)
+    y2 = ops.conv2d_nhwc(ops.to_nhwc(x.to(DEV)), wp, cin, cout, k, stride)      # raw conv, no epilogue
+    np.testing.assert_allclose(ops.from_nhwc(y2).cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_lateral_conv_with_fused_upsample_add():
+    rng = np.random.RandomState(5)
+    x = T(rng.randn(2, 32, 12, 20).astype(np.float32))
+    top = T(rng.randn(2, 64, 6, 10).astype(np.float32))
+    wt = T((rng.randn(64, 32, 1, 1) / 6).astype(np.float32))
+    bias = T(rng.randn(64).astype(np.float32))
+    exp = F.interpolate(top, scale_factor=2.0, mode="bilinear", align_corners=False) + F.conv2d(x, wt, bias)
+    y = ops.conv2d_nhwc(ops.to_nhwc(x.to(DEV)), ops.pack_conv2d_weight(wt.to(DEV)), 32, 64, 1, 1, None, bias.to(DEV),
+                        res_up=ops.to_nhwc(top.to(DEV)))
+    np.testing.assert_allclose(ops.from_nhwc(y).cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_backbone_and_refine_vs_reference_golden(golden, seeded_sd):
+    g = golden("ops.npz")
+    m = build_model()
+    m.load_state_dict(seeded_sd)
+    m.eval().to(DEV)
+    imgs, _, _, dr = synth.make_scene(96, 64, 3, batch=2, rot_deg=4.0, seed=5)
+    with torch.no_grad():
+        f8, f4, f2 = m.Backbone(imgs[:, 0].to(DEV))
+        r = m.Refine(T(g["reg2_depth"]).to(DEV), dr.to(DEV))
+    for a, k in ((f8, "fpn_f8"), (f4, "fpn_f4"), (f2, "fpn_f2")):
+        assert a.shape == g[k].shape
+        np.testing.assert_allclose(a.cpu().numpy(), g[k], rtol=1e-4, atol=2e-5)
+        assert a.permute(0, 2, 3, 1).is_contiguous()        # NHWC memory for the aggregation kernel
+    np.testing.assert_allclose(r.cpu().numpy(), g["refine_out"], rtol=0, atol=2e-3)   # mm; fp32 ulp at 600 = 6e-5, gain ~4
