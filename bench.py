@@ -158,7 +158,9 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            out = model(*inputs)
+            # images stay resident; the (tiny) camera tensors are fresh objects every step, as in a real eval loop,
+            # so the control-plane device->host hop is part of every timed step
+            out = model(inputs[0], inputs[1].clone(), inputs[2].clone(), inputs[3].clone())
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()

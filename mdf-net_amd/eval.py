@@ -10,7 +10,7 @@ import time
 import torch
 from torch.utils.data import DataLoader, Subset
 
-from mdfnet_hip import shard
+from mdfnet_hip import hostmirror, shard
 from tools.data_io import save_pfm, write_depth_img
 
 
@@ -24,6 +24,9 @@ def run_eval(model, dataset, device, output_path, rank=0, world=1, nworks=1, log
     with torch.no_grad():
         for it, data in enumerate(loader):
             batch = {k: v.to(device, non_blocking=True) for k, v in data.items() if isinstance(v, torch.Tensor)}
+            if device.type == "cuda":   # the loader's CPU tensors ARE the host mirrors: no device->host hop later
+                for k in ("extrinsics", "intrinsics", "depth_range"):
+                    hostmirror.put(batch[k], data[k])
             if device.type == "cuda":
                 torch.cuda.synchronize(device)
             t0 = time.time()

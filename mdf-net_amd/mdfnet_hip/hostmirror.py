@@ -8,6 +8,8 @@ passes around.  A mirror is registered when the host value is known (no device->
 import threading
 import weakref
 
+import torch
+
 _tls = threading.local()
 
 
@@ -25,11 +27,42 @@ def put(dev_tensor, host_tensor):
     return dev_tensor
 
 
+def fetch(tensors):
+    """Device -> host for a few tiny tensors with ONE stream synchronise: pinned staging buffers + non-blocking
+    copies.  (A plain `.cpu()` queued behind pending kernels stalls ~10 ms on this ROCm stack, measured with
+    scripts/diag_copy_latency.py; a stream synchronise does not.)"""
+    outs, dev = [], None
+    for t in tensors:
+        if t.is_cuda:
+            buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            buf.copy_(t.detach(), non_blocking=True)
+            outs.append(buf)
+            dev = t.device
+        else:
+            outs.append(t.detach())
+    if dev is not None:
+        torch.cuda.current_stream(dev).synchronize()
+    return outs
+
+
+def _lookup(t):
+    ent = _table().get(id(t))
+    if ent is not None and ent[0]() is t and ent[2] == t._version:
+        return ent[1]
+    return None
+
+
+def ensure(tensors):
+    """Register host mirrors for device tensors that do not have a current one (one sync for all of them)."""
+    missing = [t for t in tensors if t.is_cuda and _lookup(t) is None]
+    if missing:
+        for t, h in zip(missing, fetch(missing)):
+            put(t, h)
+
+
 def get(t):
     """CPU copy of `t` (cached if registered and unmodified since)."""
     if not t.is_cuda:
         return t.detach()
-    ent = _table().get(id(t))
-    if ent is not None and ent[0]() is t and ent[2] == t._version:
-        return ent[1]
-    return t.detach().cpu()
+    h = _lookup(t)
+    return h if h is not None else fetch([t])[0]

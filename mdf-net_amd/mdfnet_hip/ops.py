@@ -42,6 +42,20 @@ def _abi(name, args, tag="", work=None):
     _prof.append((name, tag, e0, e1, work or {}))
 
 
+class _single_thread:
+    """Tiny host-side linear algebra (3x3 / 4x4) must not be fanned out over a 256-thread pool: on the GPU box the
+    fork/join alone cost 56 ms per call (scripts/profile_forward.py)."""
+
+    def __enter__(self):
+        self.n = torch.get_num_threads()
+        if self.n > 1:
+            torch.set_num_threads(1)
+
+    def __exit__(self, *a):
+        if self.n > 1:
+            torch.set_num_threads(self.n)
+
+
 def _stream(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
@@ -66,9 +80,10 @@ def relative_projections(ref_proj, src_projs):
     view, computed on the CPU with the reference's own torch calls so the kernel consumes the same
     12 floats as the oracle (GPU and CPU `torch.inverse` use different solvers).  -> [n_src,B,12] CPU."""
     ref = ref_proj.detach().to("cpu", torch.float32)
-    inv = torch.inverse(ref)
-    rows = [torch.matmul(sp.detach().to("cpu", torch.float32), inv)[:, :3, :4].reshape(-1, 12) for sp in src_projs]
-    return torch.stack(rows, 0).contiguous()
+    with _single_thread():
+        inv = torch.inverse(ref)
+        rows = [torch.matmul(sp.detach().to("cpu", torch.float32), inv)[:, :3, :4].reshape(-1, 12) for sp in src_projs]
+        return torch.stack(rows, 0).contiguous()
 
 
 def _hypos_arg(hypos, h, w):
@@ -189,6 +204,9 @@ def confidence(prob, return_index=False):
     return (out, idx) if return_index else out
 
 
+_fit_row_cache = {}
+
+
 def gauss1_fit_row(depth_hypos):
     """HOST: row 0 of (X^T X)^-1 X^T for hypotheses [B,D,1,1] shared by every pixel.
 
@@ -196,14 +214,22 @@ def gauss1_fit_row(depth_hypos):
     depend on which BLAS path torch takes, i.e. on the operand shapes/strides.  The row is therefore produced by
     replaying depthhypos.py:191-208 verbatim (repeat -> stack -> permute -> matmul -> inverse -> matmul) on a
     2x2-pixel replica: verified bit-identical to the per-pixel matrices of any larger image, for any batch size
-    (a 1x1 replica is NOT: degenerate strides take another path).  -> [B,D] CPU float32."""
+    (a 1x1 replica is NOT: degenerate strides take another path).  Cached by value: the row only depends on the
+    hypotheses, i.e. on (depth_min, depth_max, D), which is constant for a whole dataset.  -> [B,D] CPU float32."""
     hyp = depth_hypos.detach().to("cpu", torch.float32)
     b, d = hyp.shape[:2]
-    hyp = hyp.reshape(b, d, 1, 1).repeat(1, 1, 2, 2)
-    x = torch.stack([hyp ** 2, hyp, torch.ones_like(hyp)], dim=-1).permute(0, 2, 3, 1, 4)
-    xt = x.transpose(-1, -2)
-    m = torch.matmul(torch.inverse(torch.matmul(xt, x)), xt)  # [B,2,2,3,D]
-    return m[:, 0, 0, 0, :].contiguous()
+    key = (b, d, hyp.numpy().tobytes())
+    row = _fit_row_cache.get(key)
+    if row is None:
+        with _single_thread():
+            rep = hyp.reshape(b, d, 1, 1).repeat(1, 1, 2, 2)
+            x = torch.stack([rep ** 2, rep, torch.ones_like(rep)], dim=-1).permute(0, 2, 3, 1, 4)
+            xt = x.transpose(-1, -2)
+            row = torch.matmul(torch.inverse(torch.matmul(xt, x)), xt)[:, 0, 0, 0, :].contiguous()
+        if len(_fit_row_cache) > 256:
+            _fit_row_cache.clear()
+        _fit_row_cache[key] = row
+    return row
 
 
 def hypos_fit(mode, prob, depth, depth_hypos, fit_row=None):

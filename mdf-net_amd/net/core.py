@@ -21,8 +21,7 @@ class CoreNet(torch.nn.Module):
         if origin_imgs.is_cuda:
             # one device->host hop for the control-plane tensors (cameras, range); the slots then find host
             # mirrors and never synchronise again
-            for t in (extrinsics, intrinsics, depth_range):
-                hostmirror.put(t, t.detach().cpu())
+            hostmirror.ensure((extrinsics, intrinsics, depth_range))
         imgs = origin_imgs.float()
         nb, nv = imgs.shape[:2]
         if getattr(self.Backbone, "batch_views", False) and not self.training:
