@@ -96,29 +96,40 @@ struct Params {
   int B, D, n_src, hypos_per_pixel, out_ndhwc, dchunk, nblk_x;
 };
 
+// Reductions over the LPP (4/8/16) lanes of one pixel with DPP row operations (full-rate VALU, no LDS-pipe
+// permutes): xor-1 and xor-2 inside the quad, then row_half_mirror / row_mirror -- valid because after the quad steps
+// all 4 lanes of a quad already hold the same partial result.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 template <int LPP>
 __device__ __forceinline__ float pixel_sum(float v) {
-#pragma unroll
-  for (int s = 1; s < LPP; s <<= 1) v += __shfl_xor(v, s, 64);
+  v += dpp_mov<0xB1>(v);                  // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);                  // quad_perm [2,3,0,1]
+  if (LPP >= 8) v += dpp_mov<0x141>(v);   // row_half_mirror
+  if (LPP >= 16) v += dpp_mov<0x140>(v);  // row_mirror
   return v;
 }
 template <int LPP>
 __device__ __forceinline__ float pixel_max(float v) {
-#pragma unroll
-  for (int s = 1; s < LPP; s <<= 1) v = fmaxf(v, __shfl_xor(v, s, 64));
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  if (LPP >= 8) v = fmaxf(v, dpp_mov<0x141>(v));
+  if (LPP >= 16) v = fmaxf(v, dpp_mov<0x140>(v));
   return v;
 }
 
-// softmax over a pair (C/G = 2), as ATen: subtract max, exp, normalise.  Returns p0 (p1 = 1 - ... is
-// NOT used: both probabilities are formed from the same exponentials).
+constexpr float kLog2e = 1.4426950408889634f;
+
+// softmax over a pair (C/G = 2): p0 = e^a/(e^a+e^b) = 1/(1 + e^(b-a)), p1 = 1 - p0.  One v_exp + one v_rcp, no selects;
+// b-a -> +inf gives p0 = 0, NaN propagates.  (|error| ~1e-7 vs ATen's exp(x-max)/sum; tolerance of the cost is 2e-6.)
+__device__ __forceinline__ float softmax2_p0(float a, float b) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((b - a) * kLog2e));
+}
 __device__ __forceinline__ void softmax2(float a, float b, float& p0, float& p1) {
-  const float t = expf(-fabsf(a - b));
-  const float inv = __builtin_amdgcn_rcpf(1.0f + t);
-  const float hi = inv, lo = t * inv;
-  const bool a_big = a >= b;
-  p0 = a_big ? hi : lo;
-  p1 = a_big ? lo : hi;
-  if (a != a || b != b) p0 = p1 = a + b;  // NaN propagates as in softmax
+  p0 = softmax2_p0(a, b);
+  p1 = 1.0f - p0;
 }
 
 template <int C, int MODE>
@@ -147,6 +158,8 @@ __global__ __launch_bounds__(kThreads) void warp_kernel(const Params p) {
     if (MODE == kVec) {
       softmax2(rv.x, rv.y, r[0], r[1]);
       softmax2(rv.z, rv.w, r[2], r[3]);
+      r[0] -= r[1];  // sim = p0*r0 + (1-p0)*r1 = r1 + p0*(r0 - r1)
+      r[2] -= r[3];
       cw0 = p.wpar[2 * sub];
       cw1 = p.wpar[2 * sub + 1];
       alpha = p.wpar[G];
@@ -206,14 +219,11 @@ __global__ __launch_bounds__(kThreads) void warp_kernel(const Params p) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) acc[k] = val[k];
         } else if (MODE == kVec) {
-          float s0, s1, q0, q1;
-          softmax2(val[0], val[1], s0, s1);
-          softmax2(val[2], val[3], q0, q1);
-          const float sim0 = s0 * r[0] + s1 * r[1];   // homoaggregate.py:39
-          const float sim1 = q0 * r[2] + q1 * r[3];
-          const float z = pixel_sum<LPP>(cw0 * sim0 + cw1 * sim1);     // Conv3d(G->1, 1x1x1)
-          const float u = fmaxf(z * alpha + beta, 0.0f) * w2 + b2;     // BN(eval) -> ReLU -> Conv3d(1->1)
-          const float wv = 1.0f / (1.0f + expf(-u));                   // Sigmoid
+          const float sim0 = __fmaf_rn(softmax2_p0(val[0], val[1]), r[0], r[1]);   // homoaggregate.py:38-39
+          const float sim1 = __fmaf_rn(softmax2_p0(val[2], val[3]), r[2], r[3]);
+          const float z = pixel_sum<LPP>(__fmaf_rn(cw0, sim0, cw1 * sim1));        // Conv3d(G->1, 1x1x1)
+          const float u = __fmaf_rn(fmaxf(__fmaf_rn(z, alpha, beta), 0.0f), w2, b2);  // BN(eval) -> ReLU -> Conv3d(1->1)
+          const float wv = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-u * kLog2e));  // Sigmoid
           wsum += wv;
           acc[0] += wv * sim0;
           acc[1] += wv * sim1;

@@ -33,20 +33,44 @@ class FPN_4Scales(nn.Module):
         self.out3 = nn.Conv2d(c3, c2, 1, bias=False)
         self.out4 = nn.Conv2d(c3, c3, 1, bias=False)
 
+    def _composed_heads(self):
+        """The FPN head is linear: out(up(x) + lat(t) + b) = up(out(x)) + (out.lat)(t) + out.b  (1x1 convs commute with
+        bilinear upsampling).  Composing the 1x1 weights once (fp64, rounded to fp32) means the 64-channel 1/4- and
+        1/2-resolution tensors of backbone.py:60-63 (606 MB written and re-read per 5-view step) are never formed."""
+        mods = (self.out2, self.out3, self.out4, self.lat2, self.lat3)
+        tensors = [t for m in mods for t in (m.weight, m.bias) if t is not None]
+
+        def build():
+            def mat(m):
+                return m.weight.detach().double().reshape(m.out_channels, m.in_channels)
+            o2, o3, l2, l3 = mat(self.out2), mat(self.out3), mat(self.lat2), mat(self.lat3)
+            b2, b3 = self.lat2.bias.detach().double(), self.lat3.bias.detach().double()
+
+            def pack(w, bias=None):
+                w4 = w.float().reshape(w.shape[0], w.shape[1], 1, 1).contiguous()
+                return ops.pack_conv2d_weight(w4), (None if bias is None else bias.float().contiguous()), w.shape[1], w.shape[0]
+            return {"y4": pack(mat(self.out4)), "a4": pack(o3), "y3": pack(o3 @ l3, o3 @ b3),
+                    "c4": pack(o2), "c3": pack(o2 @ l3, o2 @ b3), "y2": pack(o2 @ l2, o2 @ b2)}
+        return layers.cache_of(self.out2).get(tensors, build)
+
     def _hip_forward(self, x):
         def seq(blocks, t):
             for blk in blocks:
                 t = layers.conv2d_layer(blk.conv, blk.bn, t, relu=True)
             return t
+
+        def head(h, t, res_up=None):
+            wp, bias, cin, cout = h
+            return ops.conv2d_nhwc(t, wp, cin, cout, 1, 1, None, bias, False, None, 1.0, res_up)
         with torch.no_grad():
             t2 = seq(self.conv12, seq(self.conv01, ops.to_nhwc(x)))
             t3 = seq(self.conv23, t2)
             t4 = seq(self.conv34, t3)
-            y4 = layers.conv2d_layer(self.out4, None, t4)
-            up3 = layers.conv2d_layer(self.lat3, None, t3, res_up=t4)    # interpolate(t4) + lat3(t3)
-            y3 = layers.conv2d_layer(self.out3, None, up3)
-            up2 = layers.conv2d_layer(self.lat2, None, t2, res_up=up3)   # interpolate(up3) + lat2(t2)
-            y2 = layers.conv2d_layer(self.out2, None, up2)
+            hd = self._composed_heads()
+            y4 = head(hd["y4"], t4)
+            y3 = head(hd["y3"], t3, res_up=head(hd["a4"], t4))            # out3(up(t4) + lat3(t3))
+            c3 = head(hd["c3"], t3, res_up=head(hd["c4"], t4))            # out2(up(t4) + lat3(t3))        @1/4
+            y2 = head(hd["y2"], t2, res_up=c3)                            # out2(up(up3) + lat2(t2))        @1/2
         return ops.from_nhwc(y4), ops.from_nhwc(y3), ops.from_nhwc(y2)
 
     def forward(self, x: torch.Tensor):
