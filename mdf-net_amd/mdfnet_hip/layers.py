@@ -30,19 +30,33 @@ def hip_eval(mod, x):
     return (not mod.training) and x.is_cuda
 
 
-def conv2d_layer(conv, bn, x, relu=False, res=None, res_scale=1.0, res_up=None):
-    """Conv2d [+ BatchNorm2d eval] [+ ReLU] [+ residual / upsample-add] as one kernel.  x, res: [B,H,W,C] NHWC."""
-    k = conv.kernel_size[0]
-    tensors = [conv.weight, conv.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
+import contextlib
+import threading
 
-    def build():
-        wp = ops.pack_conv2d_weight(conv.weight)
-        if bn is not None:
-            alpha, beta = ops.fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
-            if conv.bias is not None:
-                beta = (beta + conv.bias.float() * alpha).contiguous()
-            return wp, alpha, beta
-        return wp, None, (None if conv.bias is None else conv.bias.detach().float().contiguous())
+_mode = threading.local()
 
-    wp, alpha, beta = cache_of(conv).get(tensors, build)
-    return ops.conv2d_nhwc(x, wp, conv.in_channels, conv.out_channels, k, conv.stride[0], alpha, beta, relu, res, res_scale, res_up)
+
+@contextlib.contextmanager
+def model_mode(training):
+    """CoreNet.forward announces its mode so that the plain-function slots (depth_regression, homo_warping, ...) follow the
+    model's mode even under torch.no_grad()."""
+    prev = getattr(_mode, "training", None)
+    _mode.training = bool(training)
+    try:
+        yield
+    finally:
+        _mode.training = prev
+
+
+def use_hip(mod, *tensors):
+    """Slot dispatch.  Inference (module in eval mode / no autograd graph wanted) runs the hand-written kernels and
+    REFUSES CPU tensors -- there is no CPU fallback.  Training (module.training, an enclosing CoreNet in training mode,
+    or inputs that require grad) runs the stock-op path of mdfnet_hip/stockops.py.  `mod` is None for plain functions."""
+    ts = [t for t in tensors if isinstance(t, torch.Tensor)]
+    training = mod.training if mod is not None else bool(getattr(_mode, "training", False))
+    if training or (torch.is_grad_enabled() and any(t.requires_grad for t in ts)):
+        return False
+    if not all(t.is_cuda for t in ts):
+        raise RuntimeError("inference slots run on hand-written MI355X kernels only (got a CPU tensor); there is no CPU "
+                           "fallback -- model.train() selects the stock-op training path")
+    return True

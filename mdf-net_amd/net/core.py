@@ -2,7 +2,7 @@
 dicts and state_dict keys; the stage loop runs on one HIP stream with the hot operators as fused kernels."""
 import torch
 
-from mdfnet_hip import hostmirror
+from mdfnet_hip import hostmirror, layers
 
 
 class CoreNet(torch.nn.Module):
@@ -16,8 +16,15 @@ class CoreNet(torch.nn.Module):
         print("{} parameters: {}".format(self._get_name(), sum(p.data.nelement() for p in self.parameters())))
 
     def forward(self, origin_imgs, extrinsics, intrinsics, depth_range):
+        with layers.model_mode(self.training):
+            return self._forward(origin_imgs, extrinsics, intrinsics, depth_range)
+
+    def _forward(self, origin_imgs, extrinsics, intrinsics, depth_range):
         """imgs [B,V,3,H,W] (view 0 = reference), E [B,V,4,4], K [B,V,3,3], range [B,2]
         -> train: {"depth": [1/8, 1/4, 1/2, 1/1]};  eval: {"depth": [B,H,W], "confidence": [B,H,W]}."""
+        if not self.training and not origin_imgs.is_cuda:
+            raise RuntimeError("CoreNet inference runs on hand-written MI355X kernels only: move the model and inputs to a "
+                               "GPU (there is no CPU fallback; model.train() selects the stock-op training path)")
         if origin_imgs.is_cuda:
             # one device->host hop for the control-plane tensors (cameras, range); the slots then find host
             # mirrors and never synchronise again

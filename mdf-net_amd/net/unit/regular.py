@@ -7,7 +7,9 @@ from typing import Tuple
 import torch
 import torch.nn as nn
 
-from mdfnet_hip import ops
+import torch.nn.functional as F
+
+from mdfnet_hip import layers, ops
 from mdfnet_hip.layers import cache_of as _cache
 from .base import ConvBNReLU3D
 
@@ -54,8 +56,19 @@ class RegularNet_3Scales(nn.Module):
         x1 = run_layer((self.conv232[3], self.conv232[4]), y, res=x1)     # x1 + relu(bn(convT(y)))
         return run_layer((self.conv10[0], self.conv10[1]), x1, res=x)     # x + relu(bn(convT(x1)))
 
+    def _stock_forward(self, x):
+        """Training path (autograd, batch-stat BN): the same layer program with the stock modules."""
+        x = self.conv01(x)
+        x1 = self.conv12(x)
+        x1 = x1 + self.conv232(x1)
+        x = x + self.conv10(x1)
+        return F.softmax(self.prob(x).squeeze(1), dim=1)
+
     def forward(self, x: torch.Tensor, depth_hypos=None):
         """cost [B,C,D,H,W] -> prob [B,D,H,W]; with depth_hypos also returns the soft-argmin depth."""
+        if not layers.use_hip(self, x):
+            prob = self._stock_forward(x)
+            return prob if depth_hypos is None else (prob, torch.sum(prob * depth_hypos, 1))
         with torch.no_grad():
             return ops.prob_head(self.features(ops.to_ndhwc(x)), self.prob.weight, depth_hypos)
 
@@ -87,6 +100,18 @@ class RegularNet_4Scales(nn.Module):
         x2 = run_layer((self.trconv32[0], self.trconv32[1]), x3, res=x2)
         return run_layer((self.trconv21[0], self.trconv21[1]), x2, res=x1)
 
+    def _stock_forward(self, x):
+        x1 = self.conv01(x)
+        x2 = self.conv12(x1)
+        x3 = self.conv23(x2)
+        x3 = x3 + self.conv343(x3)
+        x2 = x2 + self.trconv32(x3)
+        x1 = x1 + self.trconv21(x2)
+        return F.softmax(self.prob(x1).squeeze(1), dim=1)
+
     def forward(self, x: torch.Tensor, depth_hypos=None):
+        if not layers.use_hip(self, x):
+            prob = self._stock_forward(x)
+            return prob if depth_hypos is None else (prob, torch.sum(prob * depth_hypos, 1))
         with torch.no_grad():
             return ops.prob_head(self.features(ops.to_ndhwc(x)), self.prob.weight, depth_hypos)

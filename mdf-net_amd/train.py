@@ -1,0 +1,90 @@
+"""Training driver (counterpart of the reference's train.py:11-110): same CLI (-p/-d/-l), Adam lr 1e-3 with the poly
+decay lr*(1-(e-1)/E)^0.9, per-epoch checkpoint {'epoch','model'} without a `module.` prefix, epoch_loss.txt.
+Data parallel = one process per GPU (`torchrun --nproc-per-node N train.py ...`): flat-bucket gradient all-reduce
+over RCCL (mdfnet_hip/ddp.py) instead of nn.DataParallel.  The model's training mode runs the stock-op path
+(mdfnet_hip/stockops.py); the hand-written kernels serve inference."""
+import argparse
+import logging
+import os
+import time
+
+import torch
+import torch.optim as optim
+from torch.utils.data import DataLoader
+from torch.utils.data.distributed import DistributedSampler
+
+from mdfnet_hip import ddp, shard
+from net import loss as loss_mod
+from tools.data_io import tocuda
+
+
+def train_one_epoch(model, bucket, optimizer, loss_criterion, batches, device, log=print, epoch=0):
+    model.train()
+    total = 0.0
+    for it, data in enumerate(batches):
+        data = tocuda(data, device)
+        t0 = time.time()
+        out = model(data["imgs"], data["extrinsics"], data["intrinsics"], data["depth_range"])
+        loss = loss_criterion(out, data["ref_depths"], data["depth_range"])
+        bucket.zero_grad()
+        loss.backward()
+        bucket.allreduce_gradients()
+        optimizer.step()
+        cur = loss.detach().item()
+        total += cur
+        log("\r" + "epoch: " + str(epoch) + " batch: " + str(it + 1) + "/" + str(len(batches))
+            + " time:{: .3f}".format(time.time() - t0) + " loss:{: .5f}\t".format(cur), end="", flush=True)
+    return total / max(len(batches), 1)
+
+
+def main():
+    import config
+    parser = argparse.ArgumentParser(description="train parameter setting")
+    parser.add_argument("-p", "--pre_model", default=None, type=str)
+    parser.add_argument("-d", "--dataset", default="dtu", type=str, choices=["dtu", "blendedmvs"])
+    parser.add_argument("-l", "--cmd_label", default="", type=str)
+    args = parser.parse_args()
+    rank, world, local = shard.init()
+    if args.dataset == "dtu":
+        load_args, train_args = config.LoadDTU(), config.TrainArgs()
+        from load.dtutrain import LoadDataset
+        dataset = LoadDataset(datasetpath=load_args.train_root, pairpath=load_args.train_pair, scencelist=load_args.train_label,
+                              lighting_label=load_args.train_lighting_label, nviews=train_args.nviews,
+                              robust_train=train_args.robust)
+    else:
+        load_args, train_args = config.LoadBlendedMVS(), config.BlendedMVSArgs()
+        from load.blendedtrain import LoadDataset
+        dataset = LoadDataset(datasetpath=load_args.train_root, nviews=train_args.nviews, robust_train=train_args.robust)
+    device = train_args.DEVICE
+    model = config.model
+    start_epoch = train_args.start_epoch
+    if args.pre_model is not None:
+        ckpt = torch.load(args.pre_model, map_location="cpu")
+        start_epoch = ckpt["epoch"] + 1
+        model.load_state_dict(ckpt["model"])
+    model.to(device)
+    bucket = ddp.FlatBucket(model)
+    bucket.broadcast_parameters(0)
+    optimizer = optim.Adam([{"params": model.parameters(), "initial_lr": train_args.lr}], lr=train_args.lr)
+    criterion = loss_mod.Loss().to(device)
+    per_rank = max(train_args.batch_size // world, 1)       # the reference's batch is the GLOBAL batch (DataParallel scatter)
+    sampler = DistributedSampler(dataset, world, rank, shuffle=True, drop_last=True) if world > 1 else None
+    batches = DataLoader(dataset, batch_size=per_rank, shuffle=(sampler is None), sampler=sampler,
+                         num_workers=train_args.nworks, drop_last=True, pin_memory=True)
+    for epoch in range(start_epoch, train_args.max_epoch + 1):
+        if sampler is not None:
+            sampler.set_epoch(epoch)
+        optimizer.param_groups[0]["lr"] = train_args.lr * ((1 - (epoch - 1) / train_args.max_epoch) ** train_args.factor)
+        mean_loss = train_one_epoch(model, bucket, optimizer, criterion, batches, device, epoch=epoch)
+        mean_loss = shard.sum_over_ranks(mean_loss, device if device.type == "cuda" else "cpu") / world
+        bucket.broadcast_buffers(0)
+        if rank == 0:
+            logging.info("epoch: " + str(epoch) + " loss:" + str(mean_loss))
+            with open(os.path.join(train_args.pth_path, "epoch_loss.txt"), "a") as f:
+                f.write(str(mean_loss) + "\n")
+            torch.save({"epoch": epoch, "model": model.state_dict()},
+                       os.path.join(train_args.pth_path, args.dataset + "_" + str(epoch) + ".pth"))
+
+
+if __name__ == "__main__":
+    main()

@@ -62,9 +62,13 @@ def test_regulariser_vs_reference_golden(golden, seeded_sd, stage):
     np.testing.assert_allclose(d2.cpu().numpy(), g[f"reg{stage}_depth"], rtol=0, atol=3e-4)
 
 
-def test_train_mode_fails_loudly(seeded_sd):
+def test_train_mode_uses_stock_path_with_autograd(seeded_sd):
+    """model.train() selects the stock-op training path (batch-stat BN, autograd) -- an explicit mode, not a fallback."""
     model = build_model()
     model.load_state_dict(seeded_sd)
     model.train().to(DEV)
-    with pytest.raises(NotImplementedError):
-        model.Regular[1](torch.zeros(1, 16, 8, 8, 8, device=DEV))
+    x = torch.randn(1, 16, 8, 8, 8, device=DEV, requires_grad=True)
+    prob = model.Regular[1](x)
+    assert prob.shape == (1, 8, 8, 8) and prob.requires_grad
+    prob.sum().backward()
+    assert x.grad is not None and model.Regular[1].prob.weight.grad is not None
