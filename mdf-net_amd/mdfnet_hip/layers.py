@@ -60,3 +60,21 @@ def use_hip(mod, *tensors):
         raise RuntimeError("inference slots run on hand-written MI355X kernels only (got a CPU tensor); there is no CPU "
                            "fallback -- model.train() selects the stock-op training path")
     return True
+
+
+def conv2d_layer(conv, bn, x, relu=False, res=None, res_scale=1.0, res_up=None):
+    """Conv2d [+ BatchNorm2d eval] [+ ReLU] [+ residual / upsample-add] as one kernel.  x, res: [B,H,W,C] NHWC."""
+    k = conv.kernel_size[0]
+    tensors = [conv.weight, conv.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
+
+    def build():
+        wp = ops.pack_conv2d_weight(conv.weight)
+        if bn is not None:
+            alpha, beta = ops.fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+            if conv.bias is not None:
+                beta = (beta + conv.bias.float() * alpha).contiguous()
+            return wp, alpha, beta
+        return wp, None, (None if conv.bias is None else conv.bias.detach().float().contiguous())
+
+    wp, alpha, beta = cache_of(conv).get(tensors, build)
+    return ops.conv2d_nhwc(x, wp, conv.in_channels, conv.out_channels, k, conv.stride[0], alpha, beta, relu, res, res_scale, res_up)

@@ -67,8 +67,8 @@ def test_train_mode_uses_stock_path_with_autograd(seeded_sd):
     model = build_model()
     model.load_state_dict(seeded_sd)
     model.train().to(DEV)
-    x = torch.randn(1, 16, 8, 8, 8, device=DEV, requires_grad=True)
+    x = torch.randn(2, 16, 16, 16, 16, device=DEV, requires_grad=True)
     prob = model.Regular[1](x)
-    assert prob.shape == (1, 8, 8, 8) and prob.requires_grad
+    assert prob.shape == (2, 16, 16, 16) and prob.requires_grad
     prob.sum().backward()
     assert x.grad is not None and model.Regular[1].prob.weight.grad is not None
