@@ -62,12 +62,18 @@ struct Frag<2> {
   __device__ __forceinline__ void zero() { v[0] = v[1] = 0.f; }
 };
 
-template <int CIN, int COUT, int MODE, int MT>
+// SPLITK = 4: the four waves of a block share ONE wave tile and each takes every 4th tap; partial accumulators are summed
+// through LDS.  For tiny volumes (a few thousand voxels, 27*64 deep K) this turns ~90 serial-latency-bound blocks into 4x
+// as many quarter-length ones.
+template <int CIN, int COUT, int MODE, int MT, int SPLITK>
 __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
   constexpr int KPL = (CIN >= 16) ? 4 : 2;   // k values per lane per chunk
   constexpr int CK = 4 * KPL;                // cin per chunk
   constexpr int NCH = CIN / CK;
-  constexpr int NT = (COUT + 15) / 16;
+  // transposed: GEMM rows are [pw][cout] (both output w-parities of an input voxel in one wave -> one contiguous
+  // 2*COUT store per input voxel, and no padded rows for COUT = 8)
+  constexpr int ROWS = (MODE == kTr) ? 2 * COUT : COUT;
+  constexpr int NT = (ROWS + 15) / 16;
   static_assert(CIN % CK == 0, "CIN must be a multiple of the chunk");
 
   const int lane = threadIdx.x & 63;
@@ -75,11 +81,11 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
   const int q = lane >> 4;    // k sub-slot / cout quad
   const int n16 = lane & 15;  // voxel inside the m-tile (B operand, C/D column)
   const unsigned tile_blk = mdf::xcd_remap(blockIdx.x, p.nblk);
-  const long long m0 = ((long long)tile_blk * 4 + wave) * (MT * 16);
+  const long long m0 = (SPLITK > 1 ? (long long)tile_blk : (long long)tile_blk * 4 + wave) * (MT * 16);
 
   // transposed: parity class of this block
-  const int pc = (MODE == kTr) ? blockIdx.y : 0;
-  const int pd = (pc >> 2) & 1, ph = (pc >> 1) & 1, pw = pc & 1;
+  const int pc = (MODE == kTr) ? blockIdx.y : 0;   // 4 classes: (pd, ph); both pw live in the wave
+  const int pd = (pc >> 1) & 1, ph = pc & 1;
 
   // per-lane voxel bookkeeping for each m-tile
   int in_off[MT];       // float offset of the base input voxel (channel 0)
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
     vmask[t] = live[t] ? vm : 0u;
     in_off[t] = (int)((((long long)b * p.Di + bd) * p.Hi + bh) * p.Wi + bw) * CIN;
     if (MODE == kTr)
-      out_vox[t] = (((long long)b * p.Do + (2 * md + pd)) * p.Ho + (2 * mh + ph)) * p.Wo + (2 * mw + pw);
+      out_vox[t] = (((long long)b * p.Do + (2 * md + pd)) * p.Ho + (2 * mh + ph)) * p.Wo + 2 * mw;   // pw added in the epilogue
     else
       out_vox[t] = m;
   }
@@ -130,14 +136,24 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
   const float* xq = p.x + KPL * q;                       // this lane's cin slot inside a chunk
   const float* wl = p.wpack + (size_t)lane * KPL;        // this lane's slot inside a packed 64-lane fragment
 
-  for (int tap = 0; tap < 27; ++tap) {
-    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-    int od, oh, ow;
+  // transposed: output parity p uses kernel taps with (k + p) odd: p=0 -> k=1 (input i') ; p=1 -> k=0 (input i'+1),
+  // k=2 (input i').  Only the class's valid (kd, kh) pairs are enumerated (1, 2 or 4 of them) x 2 input w-offsets, so a
+  // split-K stride hands every wave real work.  Along w: offset 0 feeds pw=0 (kw=1) and pw=1 (kw=2); offset +1 feeds pw=1 (kw=0).
+  const int nkh = 1 + ph;
+  const int ntaps = (MODE == kTr) ? (1 + pd) * nkh * 2 : 27;
+  for (int j = (SPLITK > 1 ? wave : 0); j < ntaps; j += (SPLITK > 1 ? SPLITK : 1)) {
+    int kd, kh, kw, od, oh, ow, tap;
     if (MODE == kTr) {
-      // output parity p uses kernel taps with (k + p) odd: p=0 -> k=1 ; p=1 -> k=0 (input i'+1), k=2 (input i')
-      if ((((kd + pd) & 1) == 0) || (((kh + ph) & 1) == 0) || (((kw + pw) & 1) == 0)) continue;
-      od = (kd == 0); oh = (kh == 0); ow = (kw == 0);
+      ow = j & 1;
+      const int jh = (j >> 1) % nkh, jd = (j >> 1) / nkh;
+      kd = pd ? 2 * jd : 1;
+      kh = ph ? 2 * jh : 1;
+      od = (kd == 0); oh = (kh == 0);
+      kw = ow ? 0 : 1;                  // validity-mask slot of the w offset: bit 0 <-> offset +1, bit 1 <-> offset 0
+      tap = (kd * 3 + kh) * 2 + ow;     // slot in the packed weights
     } else {
+      tap = j;
+      kd = tap / 9; kh = (tap / 3) % 3; kw = tap % 3;
       od = kd - 1; oh = kh - 1; ow = kw - 1;
     }
     const int tapoff = ((od * p.Hi + oh) * p.Wi + ow) * CIN;
@@ -159,16 +175,41 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
+          for (int nt = 0; nt < NT; ++nt) {
+            // transposed, offset +1: rows of parity pw = 0 are structurally zero -> skip n-tiles made only of such rows
+            if (MODE == kTr && ow == 1 && (nt + 1) * 16 <= COUT) continue;
             acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[nt].v[s], bf[t].v[s], acc[t][nt], 0, 0, 0);
+          }
     }
+  }
+
+  if (SPLITK > 1) {
+    // partial sums -> LDS [wave][t*NT+nt][lane]; pair p is finished (summed + epilogue) by wave p % 4
+    __shared__ f32x4 part[4][MT * NT][64];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) part[wave][t * NT + nt][lane] = acc[t][nt];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if (((t * NT + nt) & 3) == wave) {
+          const f32x4 a0 = part[0][t * NT + nt][lane], a1 = part[1][t * NT + nt][lane];
+          const f32x4 a2 = part[2][t * NT + nt][lane], a3 = part[3][t * NT + nt][lane];
+          acc[t][nt] = (a0 + a1) + (a2 + a3);
+        }
+      }
   }
 
   // epilogue: lane owns couts nt*16 + 4q .. +3 of voxel out_vox[t]
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int c0 = nt * 16 + 4 * q;
-    if (c0 >= COUT) continue;
+    const int r0 = nt * 16 + 4 * q;   // first GEMM row of this lane
+    if (r0 >= ROWS) continue;
+    const int pw_out = (MODE == kTr) ? r0 / COUT : 0;
+    const int c0 = (MODE == kTr) ? r0 % COUT : r0;
     float4 al = make_float4(1.f, 1.f, 1.f, 1.f), be = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.alpha) {
       al = *reinterpret_cast<const float4*>(p.alpha + c0);
@@ -177,13 +218,14 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       if (!live[t]) continue;
+      if (SPLITK > 1 && ((t * NT + nt) & 3) != wave) continue;  // another wave finishes this pair
       float4 o;
       o.x = acc[t][nt][0] * al.x + be.x;
       o.y = acc[t][nt][1] * al.y + be.y;
       o.z = acc[t][nt][2] * al.z + be.z;
       o.w = acc[t][nt][3] * al.w + be.w;
       if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-      const size_t oi = (size_t)out_vox[t] * COUT + c0;
+      const size_t oi = (size_t)(out_vox[t] + pw_out) * COUT + c0;
       if (p.res) {
         const float4 rr = *reinterpret_cast<const float4*>(p.res + oi);
         o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
@@ -214,36 +256,70 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
-template <int CIN, int COUT, int MODE, int MT>
+// ConvTranspose3d weights [Cin][Cout][3][3][3] -> wpack[tap' = (kd*3+kh)*2+ow][chunk][nt][q][n][s] with GEMM row
+// r = nt*16+n = pw*Cout + cout and kernel tap kw(pw, ow): (0,0)->1, (1,0)->2, (1,1)->0, (0,1)-> structurally zero.
+__global__ void pack_weights_tr_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout) {
+  const int KPL = (Cin >= 16) ? 4 : 2, CK = 4 * KPL, NCH = Cin / CK, NT = (2 * Cout + 15) / 16;
+  const int total = 18 * NCH * NT * 64 * KPL;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int r = i;
+    const int s = r % KPL; r /= KPL;
+    const int n = r % 16; r /= 16;
+    const int qq = r % 4; r /= 4;
+    const int nt = r % NT; r /= NT;
+    const int ch = r % NCH; r /= NCH;
+    const int tap = r;
+    const int kd = tap / 6, kh = (tap / 2) % 3, ow = tap & 1;
+    const int row = nt * 16 + n, cin = ch * CK + KPL * qq + s;
+    float v = 0.f;
+    if (row < 2 * Cout) {
+      const int pw = row / Cout, cout = row % Cout;
+      const int kw = (pw == 0) ? (ow == 0 ? 1 : -1) : (ow == 0 ? 2 : 0);
+      if (kw >= 0) v = w[((size_t)cin * Cout + cout) * 27 + (kd * 3 + kh) * 3 + kw];
+    }
+    wp[i] = v;
+  }
+}
+
+template <int CIN, int COUT, int MODE, int MT, int SPLITK>
 int launch_conv(ConvParams& p, hipStream_t st) {
-  const long long per_blk = 4LL * MT * 16;
+  const long long per_blk = (SPLITK > 1 ? 1LL : 4LL) * MT * 16;
   p.nblk = (unsigned)((p.m_total + per_blk - 1) / per_blk);
-  dim3 grid(p.nblk, MODE == kTr ? 8 : 1), block(256);
-  hipLaunchKernelGGL((conv3d_kernel<CIN, COUT, MODE, MT>), grid, block, 0, st, p);
+  dim3 grid(p.nblk, MODE == kTr ? 4 : 1), block(256);
+  hipLaunchKernelGGL((conv3d_kernel<CIN, COUT, MODE, MT, SPLITK>), grid, block, 0, st, p);
   return mdf::check_launch("conv3d_kernel");
 }
 
 template <int CIN, int COUT, int MODE>
 int launch_conv_mt(ConvParams& p, hipStream_t st) {
-  constexpr int MTMAX = (COUT > 32) ? 2 : 4;
+  constexpr int ROWS = (MODE == kTr) ? 2 * COUT : COUT;
+  constexpr int MTMAX = (ROWS > 32) ? 2 : 4;
   // small volumes: shrink the wave tile so the grid still covers the 256 CUs a few times over
-  const long long tiles_big = p.m_total / (64LL * MTMAX) * (MODE == kTr ? 8 : 1);
-  if (tiles_big >= 1024) return launch_conv<CIN, COUT, MODE, MTMAX>(p, st);
-  return launch_conv<CIN, COUT, MODE, 1>(p, st);
+  const long long tiles_big = p.m_total / (64LL * MTMAX) * (MODE == kTr ? 4 : 1);
+  if (tiles_big >= 1024) return launch_conv<CIN, COUT, MODE, MTMAX, 1>(p, st);
+  // few tiles and a deep K (27*CIN >= 864): split the taps over the block's waves
+  const long long tiles_1 = p.m_total / 16 * (MODE == kTr ? 4 : 1);
+  if (MODE != kTr && CIN >= 32 && tiles_1 < 4096) return launch_conv<CIN, COUT, MODE, 1, 4>(p, st);  // (transposed classes have only 2-8 taps)
+  return launch_conv<CIN, COUT, MODE, 1, 1>(p, st);
 }
 
 }  // namespace
 
 extern "C" int64_t mdf_conv3d_packed_size(int Cin, int Cout) {
   if (Cin < 8 || Cout < 1) return 0;
-  return (int64_t)27 * Cin * (((Cout + 15) / 16) * 16);
+  const int64_t plain = (int64_t)27 * Cin * (((Cout + 15) / 16) * 16);
+  const int64_t transposed = (int64_t)18 * Cin * (((2 * Cout + 15) / 16) * 16);
+  return plain > transposed ? plain : transposed;   // one size serves both packings
 }
 
 extern "C" int mdf_conv3d_pack_weights(const float* w, float* wpack, int Cin, int Cout, int transposed, void* stream) {
   MDF_REQUIRE(w && wpack, "null pointer argument");
   MDF_REQUIRE(Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64, "Cin=%d not in {8,16,32,64}", Cin);
   MDF_REQUIRE(Cout >= 1 && Cout <= 64, "Cout=%d out of range", Cout);
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, wpack, Cin, Cin, Cout, 27, transposed);
+  if (transposed)
+    hipLaunchKernelGGL(pack_weights_tr_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, wpack, Cin, Cout);
+  else
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, wpack, Cin, Cin, Cout, 27, 0);
   return mdf::check_launch("pack_weights_kernel");
 }
 
