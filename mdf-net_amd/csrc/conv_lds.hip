@@ -12,6 +12,7 @@
 // LDS image of one plane:  [cin / KPL][S] vectors of KPL floats, S = plane-tile voxels rounded to 16 (mod 32), so
 // the lane groups of ds_read_b128 (and the two halves of ds_read_b64) fall on disjoint banks for every tap shift.
 // GEMM orientation and weight packing are those of conv3d.hip:  D[cout][voxel] = W[cout][k] * X[k][voxel].
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -32,6 +33,7 @@ struct LdsConvParams {
   int tiles_h, tiles_w, dchunks, dch;  // item space (3-D: tile x depth chunk)
   int n_items;
   int n_tiles, tiles_per_item;         // 2-D: an item is a run of consecutive tiles
+  int prefetch_early;                  // 3-D: issue the next plane's loads before (1) or after (0) the MFMA block
 };
 
 template <int N> struct VecT;
@@ -190,7 +192,10 @@ __device__ __forceinline__ void step(const float* const (&planes)[KD], const flo
 }
 
 template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT>
-__global__ __launch_bounds__(256) void conv_lds_kernel(const LdsConvParams p) {
+// Register budget: the unrolled, pipelined tap loop wants ~280 registers (one 64-bit address pair per weight tap), which
+// leaves ONE wave per SIMD.  Capping at 256 (two resident blocks per CU) is worth 6-10 % for the single-n-tile kernels
+// (A/B in one process, scripts/bench_conv3d.py); with 2+ n-tiles the cap makes hipcc spill, so those stay uncapped.
+__global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(const LdsConvParams p) {
   typedef Cfg<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT> C;
   constexpr int KPL = C::KPL, NG = C::NG, S = C::S, PW = C::PW, PH = C::PH;
   typedef typename VecT<KPL>::type vec_t;
@@ -315,6 +320,12 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(const LdsConvParams p) {
 
     for (int d = d0; d < d1; ++d) {
       const bool more = (KD > 1) && (d + 1 < d1);
+      // fetch the plane the next step needs (d+1+PD) into registers; consumed after this step's MFMAs
+      vec_t pf[C::NFILL];
+      if (more && p.prefetch_early) {
+#pragma unroll
+        for (int k = 0; k < C::NFILL; ++k) pf[k] = load_elem(tid + k * 256, d + 1 + C::PD);
+      }
       if (mt_live > 0) {
         const float* planes[KD];
 #pragma unroll
@@ -327,13 +338,11 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(const LdsConvParams p) {
           default: step<C, KD, KHW, SHW, COUT, MT>(planes, wl, p, row_vox, w0, q, n16); break;
         }
       }
-      if (more) {
-        // fetch the plane the next step needs (d+1+PD).  Issued AFTER the MFMA block: vmcnt retires in order, so
-        // plane loads queued ahead of the weight-fragment loads would stall the first MFMA of the step; the other
-        // resident block of the CU computes while this one refills.
-        vec_t pf[C::NFILL];
+      if (more && !p.prefetch_early) {
 #pragma unroll
         for (int k = 0; k < C::NFILL; ++k) pf[k] = load_elem(tid + k * 256, d + 1 + C::PD);
+      }
+      if (more) {
         __syncthreads();  // all waves finished reading plane d-PD: its slot is free
 #pragma unroll
         for (int k = 0; k < C::NFILL; ++k) store_elem(tid + k * 256, slot_of(d + 1 + C::PD), pf[k]);
@@ -393,7 +402,16 @@ int launch_lds(LdsConvParams& p, hipStream_t st) {
     attr_done = true;
   }
   int grid = max_grid;
+  if (const char* g = getenv("MDF_CONV_GRID")) { if (atoi(g) > 0) grid = atoi(g); }   // dev: residency experiments
   if (grid > p.n_items) grid = p.n_items;
+  if (getenv("MDF_CONV_DEBUG")) {
+    int nb = -1;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT>, 256, C::LDS_BYTES);
+    hipFuncAttributes fa{};
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT>));
+    fprintf(stderr, "[conv_lds<%d,%d,%d,%d,%d,%d,%d>] LDS %zu B dyn + %zu static, regs %d, occupancy API: %d blocks/CU (%s), grid %d, items %d\n",
+            CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, C::LDS_BYTES, fa.sharedSizeBytes, fa.numRegs, nb, hipGetErrorString(e), grid, p.n_items);
+  }
   hipLaunchKernelGGL((conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT>), dim3(grid), dim3(256), C::LDS_BYTES, st, p);
   return mdf::check_launch("conv_lds_kernel");
 }
@@ -412,6 +430,10 @@ int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha
   LdsConvParams p{};
   p.x = x; p.wpack = wpack; p.alpha = alpha; p.beta = beta; p.res = res; p.res_scale = res_scale; p.res_up = res_up; p.y = y;
   p.B = B; p.D = D; p.H = H; p.W = W; p.relu = relu;
+  {
+    const char* e = getenv("MDF_CONV_PREFETCH_EARLY");   // A/B switch (dev): default = after the MFMA block
+    p.prefetch_early = e ? atoi(e) : 0;
+  }
   const int pad = (KHW - 1) / 2;
   p.Ho = (H + 2 * pad - KHW) / stride + 1;
   p.Wo = (W + 2 * pad - KHW) / stride + 1;

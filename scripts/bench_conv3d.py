@@ -22,6 +22,8 @@ for name, ci, co, mode, D, H, W in L:
     tr = mode == "tr"
     x = torch.randn(1, D, H, W, ci, device=dev)
     wt = torch.randn(*((ci, co) if tr else (co, ci)), 3, 3, 3, device=dev) / (27 * ci) ** 0.5
+    if "--zeros" in sys.argv:      # clock/power experiment: same instruction stream on all-zero operands
+        x.zero_(); wt.zero_()
     wp = ops.pack_conv3d_weight(wt, tr)
     al, be = torch.rand(co, device=dev) + 0.5, torch.randn(co, device=dev) * 0.1
     st = 1 if mode == "s1" else 2
@@ -34,12 +36,23 @@ for name, ci, co, mode, D, H, W in L:
         err = (y - ref).abs().max().item()
     torch.cuda.synchronize()
     n = 10
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        y = ops.conv3d_ndhwc(x, wp, ci, co, st, tr, al, be, True)
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / n
+    def timeit():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            ops.conv3d_ndhwc(x, wp, ci, co, st, tr, al, be, True)
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+    ab = os.environ.get("MDF_AB")   # e.g. MDF_AB=MDF_CONV_PREFETCH_EARLY : interleaved A/B of an env switch in ONE process
+    if ab:
+        ta, tb = [], []
+        for _ in range(5):
+            os.environ[ab] = os.environ.get("MDF_AB_VAL0", "0"); ta.append(timeit())
+            os.environ[ab] = os.environ.get("MDF_AB_VAL", "1"); tb.append(timeit())
+        ms = min(ta)
+        print(f"   A/B {ab}: 0 -> {min(ta)*1e3:.1f} us (med {sorted(ta)[2]*1e3:.1f}), 1 -> {min(tb)*1e3:.1f} us (med {sorted(tb)[2]*1e3:.1f})")
+    else:
+        ms = timeit()
     nvox = D * H * W if tr else y.shape[1] * y.shape[2] * y.shape[3]
     fl = 2.0 * 27 * ci * co * nvox
     tot_ms += ms; tot_fl += fl
