@@ -98,6 +98,16 @@ def profile_pass(model, inputs, steps=3):
     return out
 
 
+def measured_traffic():
+    """HBM bytes per forward per kernel family, measured offline with rocprofv3 PMC (FETCH_SIZE / WRITE_SIZE in separate
+    passes, gfx950 corrections applied; scripts/summarize_traffic.py) and committed under profiles/."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return json.load(f).get("families", {})
+
+
 def cpu_baseline(sample_views=1):
     """Oracle (CPU port of the reference algorithm) on the host cores; bounded sample of the same workload."""
     from mdfnet_hip import synth
@@ -190,6 +200,15 @@ def main():
         if kernels:
             # dominant kernel = the MFMA implicit-GEMM conv kernel (one template family, conv_lds.hip/conv3d.hip), summed
             # over its 2-D and 3-D launches: algorithmic flops / summed launch time
+            traffic = measured_traffic()
+            fam_of = {"conv": "mfma_conv", "warp": "warp_aggregate", "prob": "prob_head"}
+            for k in kernels:
+                key = next((v for pre, v in fam_of.items() if k["kernel"].startswith(pre)), None)
+                if key in traffic:
+                    k["traffic"] = {"hbm_bytes_per_step": round(traffic[key]["hbm_bytes_per_forward"]),
+                                    "read": round(traffic[key]["read_bytes_per_forward"]),
+                                    "write": round(traffic[key]["write_bytes_per_forward"]),
+                                    "source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 on gfx950)"}
             mf = [k for k in kernels if k["bound"] == "mfma" and "achieved" in k]
             if mf:
                 ms = sum(k["ms_per_step"] for k in mf)
@@ -197,7 +216,10 @@ def main():
                 ach = gf / ms
                 rec["roofline"] = {"kernel": "fp32-MFMA implicit-GEMM conv family (conv_lds_kernel + conv3d_kernel)", "bound": "mfma",
                                    "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "ms_per_step": round(ms, 3),
+                                   "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                                   "traffic": (round(traffic["mfma_conv"]["hbm_bytes_per_forward"]) if "mfma_conv" in traffic else None),
+                                   "traffic_unit": "HBM bytes per step over all launches of the family (PMC, offline)",
+                                   "ms_per_step": round(ms, 3),
                                    "launches_per_step": sum(k["launches_per_step"] for k in mf),
                                    "algorithmic_gflop_per_step": round(gf, 1)}
             rec["kernels"] = kernels
