@@ -62,11 +62,78 @@ def gen_io():
     print("io.npz written", raw.size, "bytes of PFM")
 
 
+def filter_scene(h=96, w=128, nsrc=10, seed=3):
+    """Synthetic multi-view depth maps of a slanted plane + bumps, with per-view noise/outliers, DTU-like cameras.
+    Returns float32 numpy arrays: depths [V,h,w], conf [h,w], K [V,3,3], E [V,4,4] (view 0 = reference)."""
+    rng = np.random.RandomState(seed)
+    intr, extr, _ = synth.make_cameras(w, h, nsrc + 1, batch=1, rot_deg=3.0, seed=seed)
+    K, E = intr[0].numpy().astype(np.float64), extr[0].numpy().astype(np.float64)
+    # world surface z = f(x, y): intersect each pixel ray iteratively (3 fixed-point steps are plenty for a gentle surface)
+    def surface(xw, yw):
+        return 650.0 + 0.15 * xw - 0.1 * yw + 12.0 * np.sin(xw / 35.0) * np.cos(yw / 28.0)
+    depths = []
+    ys, xs = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    for v in range(nsrc + 1):
+        Kinv, Einv = np.linalg.inv(K[v]), np.linalg.inv(E[v])
+        d = np.full((h, w), 650.0)
+        for _ in range(20):   # additive fixed point: the ray's z-component is ~1
+            cam = (Kinv @ np.stack([xs.ravel(), ys.ravel(), np.ones(h * w)])) * d.ravel()
+            wld = (Einv @ np.vstack([cam, np.ones(h * w)]))[:3]
+            d = d + (surface(wld[0], wld[1]) - wld[2]).reshape(h, w)
+        noise = rng.normal(0, 1.0, (h, w)) + (rng.rand(h, w) < 0.08) * rng.normal(0, 25.0, (h, w))
+        depths.append((d + noise).astype(np.float32))
+    conf = (0.55 + 0.45 * rng.rand(h, w)).astype(np.float32)
+    return np.stack(depths), conf, intr[0].numpy(), extr[0].numpy()
+
+
+def gen_filter():
+    """Goldens for the consistency filter from the reference's own functions (tools/filter/dynamic_filter_gpu.py:166-238).
+    That module imports `plyfile` (absent here) only to WRITE the .ply at the end of filter(); an empty placeholder
+    module object lets the import proceed -- none of the functions called below touches it."""
+    import types
+    sys.modules.setdefault("plyfile", types.SimpleNamespace(PlyData=None, PlyElement=None))
+    fdir = os.path.join(REF, "tools", "filter")
+    sys.path.insert(0, fdir)
+    env = dict(os.environ)
+    import dynamic_filter_gpu as ref_f          # sets CUDA_VISIBLE_DEVICES; irrelevant on this CPU-only box
+    os.environ.clear(); os.environ.update(env)
+    sys.path.remove(fdir)
+    depths, conf, K, E = filter_scene()
+    T = torch.from_numpy
+    g = {"depths": depths, "conf": conf, "K": K, "E": E}
+    nsrc = depths.shape[0] - 1
+    counts = [torch.zeros(1, *conf.shape) for _ in range(9)]
+    nvalid, acc = 0, 0
+    for v in range(1, nsrc + 1):
+        masks, last, rep = ref_f.check_geometric_consistency(T(depths[0]), T(K[0]), T(E[0]), T(depths[v]), T(K[v]), T(E[v]), 4, 1300.)
+        g[f"masks{v}"] = np.packbits(torch.stack(masks)[:, 0].numpy(), axis=0)       # 9 masks -> 2 bytes per pixel
+        g[f"rep{v}"] = rep[0].numpy()
+        for i in range(9):
+            counts[i] = counts[i] + masks[i].float()
+        nvalid = nvalid + last
+        acc = acc + rep
+    drep, xr, yr, xs_, ys_ = ref_f.reproject_with_depth(T(depths[0]), T(K[0]), T(E[0]), T(depths[1]), T(K[1]), T(E[1]))
+    g["reproj1"] = torch.stack([drep[0], xr[0], yr[0], xs_[0], ys_[0]]).numpy()
+    # fusion exactly as filter():91-103
+    geo = 0
+    for i in range(2, 11):
+        geo = geo + (counts[i - 2] >= i)
+    g["depth_avg"] = ((acc + T(depths[0])) / (nvalid + 1))[0].numpy()
+    g["geo_mask"] = (geo >= 5)[0].numpy()
+    g["photo_mask"] = (T(conf) > 0.8).numpy()
+    g["final_mask"] = np.logical_and(g["photo_mask"], g["geo_mask"])
+    np.savez_compressed(os.path.join(OUT, "filter.npz"), **g)
+    print("filter.npz: geo", int(g["geo_mask"].sum()), "photo", int(g["photo_mask"].sum()), "final", int(g["final_mask"].sum()),
+          "of", conf.size)
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     if "--only-io" in sys.argv:
         return gen_io()
+    if "--only-filter" in sys.argv:
+        return gen_filter()
     cfg, base, agg, regress, dh, scale, ref_loss = load_reference()
     model = cfg.model
     sd = synth.seeded_state_dict(model.state_dict(), seed=1)
@@ -200,6 +267,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "train_tiny.npz"), **tg)
     print("train loss", float(loss))
     gen_io()
+    gen_filter()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 
