@@ -142,6 +142,19 @@ int mdf_hypos_fit_fwd(int mode, const float* prob, const float* depth, const flo
 int mdf_hypos_from_fit_fwd(int mode, const float* s, const float* depth, const float* range, float log_thresh,
                            float* hypos_out, int B, int D_out, int h, int w, int upsample, void* stream);
 
+/* ---- N1  depth-map consistency filter + fusion (tools/filter/dynamic_filter_gpu.py:63-103,166-238) ----------
+ * One fused pass over a reference view and its n_src source views: reprojection, bilinear depth gather, the nine
+ * dynamic thresholds (dist < i/thre1, rel < i/thre2, i = 2..10), geo = #(count_i >= i) >= nconditions,
+ * photo = conf > photo_threshold, masked average depth.  Bit-exact vs the reference's CPU arithmetic.
+ *   depth_ref, conf [h,w]; src_depths HOST array of n_src DEVICE pointers [h,w];
+ *   mats [n_src][68] = per view: inverse(K_ref)[9], E_src@inverse(E_ref)[16], K_src[9], inverse(K_src)[9],
+ *                       E_ref@inverse(E_src)[16], K_ref[9]  (row-major, computed by the host with the reference's calls)
+ *   depth_avg [h,w]; masks [3,h,w] uint8 = (photo, geo, final)
+ *   view_masks [n_src,h,w] uint16 (bit i <-> threshold i+2) or NULL; rep_out [n_src,h,w] (depth_reprojected) or NULL   */
+int mdf_consistency_fuse_fwd(const float* depth_ref, const float* conf, const float* const* src_depths, const float* mats,
+                             int n_src, int h, int w, float photo_threshold, int nconditions, float thre1, float thre2,
+                             float* depth_avg, unsigned char* masks, unsigned short* view_masks, float* rep_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

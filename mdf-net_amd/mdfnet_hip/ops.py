@@ -366,3 +366,46 @@ def to_nhwc(t):
 
 def from_nhwc(cl):
     return cl.permute(0, 3, 1, 2)
+
+
+# --------------------------------------------------------------------------- N1: consistency filter / fusion
+def consistency_mats(k_ref, e_ref, src_ks, src_es):
+    """HOST: the six matrices per source view the fused kernel consumes, with the reference's own torch calls
+    (dynamic_filter_gpu.py:205,210,226,229) on the CPU.  -> [n_src, 68] float32."""
+    k_ref, e_ref = k_ref.detach().to("cpu", torch.float32), e_ref.detach().to("cpu", torch.float32)
+    rows = []
+    with _single_thread():
+        kr_inv, er_inv = torch.inverse(k_ref), torch.inverse(e_ref)
+        for k, e in zip(src_ks, src_es):
+            k, e = k.detach().to("cpu", torch.float32), e.detach().to("cpu", torch.float32)
+            rows.append(torch.cat([kr_inv.reshape(-1), torch.matmul(e, er_inv).reshape(-1), k.reshape(-1),
+                                   torch.inverse(k).reshape(-1), torch.matmul(e_ref, torch.inverse(e)).reshape(-1),
+                                   k_ref.reshape(-1)]))
+    return torch.stack(rows).contiguous()
+
+
+def consistency_fuse(depth_ref, conf, k_ref, e_ref, src_depths, src_ks, src_es, photo_threshold=0.8, nconditions=5,
+                     thre1=4.0, thre2=1300.0, per_view=False):
+    """Fused filter for one reference view.  depth maps / conf: [h,w] GPU tensors; cameras: any device.
+    -> dict(depth_avg [h,w], photo_mask, geo_mask, final_mask [h,w] bool[, view_masks [n,9,h,w] bool, rep [n,h,w]])."""
+    _need_gpu(depth_ref, conf, *src_depths)
+    h, w = depth_ref.shape
+    dev = depth_ref.device
+    srcs = [_f32c(d) for d in src_depths]
+    mats = consistency_mats(k_ref, e_ref, src_ks, src_es).to(dev, non_blocking=True)
+    depth_avg = torch.empty((h, w), device=dev, dtype=torch.float32)
+    masks = torch.empty((3, h, w), device=dev, dtype=torch.uint8)
+    vm = torch.empty((len(srcs), h, w), device=dev, dtype=torch.int16) if per_view else None
+    rep = torch.empty((len(srcs), h, w), device=dev, dtype=torch.float32) if per_view else None
+    _abi("mdf_consistency_fuse_fwd", (_f32c(depth_ref).data_ptr(), _f32c(conf).data_ptr(), _src_array(srcs), mats.data_ptr(),
+                                      len(srcs), h, w, ctypes.c_float(photo_threshold), int(nconditions),
+                                      ctypes.c_float(thre1), ctypes.c_float(thre2), depth_avg.data_ptr(), masks.data_ptr(),
+                                      None if vm is None else vm.data_ptr(), None if rep is None else rep.data_ptr(),
+                                      _stream(depth_avg),),
+         tag=f"{w}x{h} nsrc{len(srcs)}", work={"bytes": 4.0 * h * w * (len(srcs) + 3) + 3.0 * h * w, "bound": "hbm"})
+    out = {"depth_avg": depth_avg, "photo_mask": masks[0].bool(), "geo_mask": masks[1].bool(), "final_mask": masks[2].bool()}
+    if per_view:
+        bits = vm.to(torch.int32) & 0xFFFF
+        out["view_masks"] = torch.stack([((bits >> i) & 1).bool() for i in range(9)], dim=1)
+        out["rep"] = rep
+    return out

@@ -36,11 +36,71 @@ def reproject_with_depth(depth_ref, k_ref, e_ref, depth_src, k_src, e_src):
     return depth_rep, xy[:, 0].reshape(1, h, w).float(), xy[:, 1].reshape(1, h, w).float(), x_src, y_src
 
 
-def check_geometric_consistency(depth_ref, k_ref, e_ref, depth_src, k_src, e_src, thre1=4, thre2=1300.0):
+def _fma(a, b, c):
+    return (a.double() * b.double() + c.double()).float()
+
+
+def _mm(m, rows):
+    """[r,k] x k rows of [N] with the rounding order of torch's CPU matmul on the build host (verified bit-exact on the
+    goldens): acc = m0*x0, then acc = fma(m_j, x_j, acc)."""
+    out = []
+    for i in range(m.shape[0]):
+        acc = m[i, 0] * rows[0]
+        for j in range(1, m.shape[1]):
+            acc = _fma(m[i, j].expand_as(rows[j]), rows[j], acc)
+        out.append(acc)
+    return out
+
+
+def reproject_explicit(depth_ref, k_ref, e_ref, depth_src, k_src, e_src):
+    """reproject_with_depth with every elementwise step written out (host-independent: the ATen form above depends on the
+    host BLAS's accumulation order).  Only the 3x3/4x4 inverses and products come from torch (same calls as the product's
+    host side).  Bit-identical to the reference's output on the build container (tests/test_filter_oracle_cpu.py)."""
+    h, w = depth_ref.shape
+    ys, xs = torch.meshgrid(torch.arange(0, h), torch.arange(0, w), indexing="ij")
+    x, y = xs.reshape(-1).float(), ys.reshape(-1).float()
+    d = depth_ref.reshape(-1)
+    one = torch.ones_like(x)
+    kr_inv, t_rs = torch.inverse(k_ref), torch.matmul(e_src, torch.inverse(e_ref))
+    ks_inv, t_sr = torch.inverse(k_src), torch.matmul(e_ref, torch.inverse(e_src))
+    c = _mm(kr_inv, [x * d, y * d, one * d])
+    s = _mm(t_rs, c + [one])[:3]
+    q = _mm(k_src, s)
+    x_src, y_src = q[0] / q[2], q[1] / q[2]
+    gx = 2 * x_src / (w - 1) - 1
+    gy = 2 * y_src / (h - 1) - 1
+    ix = (gx + 1) * torch.tensor((w - 1) / 2, dtype=torch.float32)
+    iy = (gy + 1) * torch.tensor((h - 1) / 2, dtype=torch.float32)
+    x0, y0 = torch.floor(ix), torch.floor(iy)
+    fw = ix - x0
+    fe = 1 - fw
+    fn = iy - y0
+    fs = 1 - fn
+    src = depth_src.reshape(-1)
+
+    def tap(xf, yf):
+        m = (xf >= 0) & (xf <= w - 1) & (yf >= 0) & (yf <= h - 1)
+        xi = torch.nan_to_num(xf, nan=0.0, posinf=0.0, neginf=0.0).clamp(0, w - 1).long()
+        yi = torch.nan_to_num(yf, nan=0.0, posinf=0.0, neginf=0.0).clamp(0, h - 1).long()
+        return src[yi * w + xi] * m
+
+    samp = tap(x0, y0) * (fs * fe)
+    samp = _fma(tap(x0 + 1, y0), fs * fw, samp)
+    samp = _fma(tap(x0, y0 + 1), fn * fe, samp)
+    samp = _fma(tap(x0 + 1, y0 + 1), fn * fw, samp)
+    b = _mm(ks_inv, [x_src * samp, y_src * samp, one * samp])
+    r = _mm(t_sr, b + [one])[:3]
+    u = _mm(k_ref, r)
+    shp = (1, h, w)
+    return r[2].reshape(shp), (u[0] / u[2]).reshape(shp), (u[1] / u[2]).reshape(shp), x_src.reshape(shp), y_src.reshape(shp)
+
+
+def check_geometric_consistency(depth_ref, k_ref, e_ref, depth_src, k_src, e_src, thre1=4, thre2=1300.0, explicit=False):
     """dynamic_filter_gpu.py:166-191 -> (9 masks for i = 2..10, last mask, depth_reprojected zeroed outside it)."""
     h, w = depth_ref.shape
     ys, xs = torch.meshgrid(torch.arange(0, h), torch.arange(0, w), indexing="ij")
-    depth_rep, xr, yr, _, _ = reproject_with_depth(depth_ref, k_ref, e_ref, depth_src, k_src, e_src)
+    fn_ = reproject_explicit if explicit else reproject_with_depth
+    depth_rep, xr, yr, _, _ = fn_(depth_ref, k_ref, e_ref, depth_src, k_src, e_src)
     dist = torch.sqrt((xr - xs.unsqueeze(0)) ** 2 + (yr - ys.unsqueeze(0)) ** 2)
     rel = torch.abs(depth_rep - depth_ref) / depth_ref
     masks = [torch.logical_and(dist < i / thre1, rel < i / thre2) for i in range(2, 11)]
@@ -50,13 +110,13 @@ def check_geometric_consistency(depth_ref, k_ref, e_ref, depth_src, k_src, e_src
 
 
 def fuse_view(depth_ref, conf, k_ref, e_ref, src_depths, src_ks, src_es, photo_threshold=0.8, nconditions=5, thre1=4,
-              thre2=1300.0):
+              thre2=1300.0, explicit=False):
     """filter():63-103 for one reference view -> dict(geo_mask, photo_mask, final_mask, depth_avg, counts[9], nvalid)."""
     counts = [torch.zeros(1, *depth_ref.shape) for _ in range(9)]
     nvalid = torch.zeros(1, *depth_ref.shape)
     acc = torch.zeros(1, *depth_ref.shape)
     for d, k, e in zip(src_depths, src_ks, src_es):
-        masks, last, rep = check_geometric_consistency(depth_ref, k_ref, e_ref, d, k, e, thre1, thre2)
+        masks, last, rep = check_geometric_consistency(depth_ref, k_ref, e_ref, d, k, e, thre1, thre2, explicit)
         for i in range(9):
             counts[i] = counts[i] + masks[i].float()
         nvalid = nvalid + last

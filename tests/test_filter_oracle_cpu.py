@@ -16,10 +16,14 @@ def test_reproject_and_masks_match_reference(golden):
     d, K, E = g["depths"], g["K"], g["E"]
     out = FO.reproject_with_depth(T(d[0]), T(K[0]), T(E[0]), T(d[1]), T(K[1]), T(E[1]))
     assert np.array_equal(torch.stack([o[0] for o in out]).numpy(), g["reproj1"], equal_nan=True)
+    exp = FO.reproject_explicit(T(d[0]), T(K[0]), T(E[0]), T(d[1]), T(K[1]), T(E[1]))   # host-independent restatement
+    assert np.array_equal(torch.stack([o[0] for o in exp]).numpy(), g["reproj1"], equal_nan=True)
     for v in range(1, d.shape[0]):
         masks, last, rep = FO.check_geometric_consistency(T(d[0]), T(K[0]), T(E[0]), T(d[v]), T(K[v]), T(E[v]))
         assert np.array_equal(torch.stack(masks)[:, 0].numpy(), _unpack(g[f"masks{v}"], *d.shape[1:]))
         assert np.array_equal(rep[0].numpy(), g[f"rep{v}"])
+        m2, _, rep2 = FO.check_geometric_consistency(T(d[0]), T(K[0]), T(E[0]), T(d[v]), T(K[v]), T(E[v]), explicit=True)
+        assert np.array_equal(torch.stack(m2)[:, 0].numpy(), _unpack(g[f"masks{v}"], *d.shape[1:])) and torch.equal(rep2, rep)
         counts = [int(m.sum()) for m in masks]
         assert counts == sorted(counts) and counts[0] < counts[-1]      # the nine thresholds actually differentiate
 
