@@ -195,6 +195,7 @@ template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT>
 // Register budget: the unrolled, pipelined tap loop wants ~280 registers (one 64-bit address pair per weight tap), which
 // leaves ONE wave per SIMD.  Capping at 256 (two resident blocks per CU) is worth 6-10 % for the single-n-tile kernels
 // (A/B in one process, scripts/bench_conv3d.py); with 2+ n-tiles the cap makes hipcc spill, so those stay uncapped.
+// (Tighter caps for the 2-D kernels were tried: they spill the MFMA-heavy ones and do not help the latency-bound ones.)
 __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(const LdsConvParams p) {
   typedef Cfg<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT> C;
   constexpr int KPL = C::KPL, NG = C::NG, S = C::S, PW = C::PW, PH = C::PH;
