@@ -106,10 +106,12 @@ int mdf_conv3d_pack_weights(const float* w, float* wpack, int Cin, int Cout, int
  *      y = [res + res_scale *] ( [up2(res_up) +] [relu]( conv(x) * alpha + beta ) )
  *      (alpha NULL: beta is the conv bias or NULL; res_up [B,Ho/2,Wo/2,Cout]: its bilinear x2 upsample,
  *      align_corners=False, is added -- the FPN top-down step backbone.py:60,62 fused into the lateral conv).
- *   x [B,H,W,Cin] NHWC; y [B,Ho,Wo,Cout] NHWC; wpack from mdf_conv_pack_weights (Cin 3 or 1 is zero-padded to 4).   */
+ *   x [B,H,W,Cin] NHWC, or planar [B,Cin,H,W] when planar_in != 0 (Cin < 4 only: the RGB images as eval.py hands
+ *   them over, so no layout copy is needed); y [B,Ho,Wo,Cout] NHWC; wpack from mdf_conv_pack_weights (Cin 3 or 1 is
+ *   zero-padded to 4).                                                                                            */
 int mdf_conv2d_fwd(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
                    float res_scale, const float* res_up, float* y, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int relu,
-                   void* stream);
+                   int planar_in, void* stream);
 int64_t mdf_conv_packed_size(int Cin, int Cout, int ntaps);
 /* w: [Cout,Cin,k,k] (ntaps = k*k) or [Cout,Cin,3,3,3] (ntaps = 27), device -> device. */
 int mdf_conv_pack_weights(const float* w, float* wpack, int Cin, int Cout, int ntaps, void* stream);

@@ -33,6 +33,7 @@ struct LdsConvParams {
   int tiles_h, tiles_w, dchunks, dch;  // item space (3-D: tile x depth chunk)
   int n_items;
   int n_tiles, tiles_per_item;         // 2-D: an item is a run of consecutive tiles
+  int planar_in;                       // 2-D, CIN_MEM != CIN: input is planar [B,CIN_MEM,H,W] (e.g. the RGB images as they arrive)
   int prefetch_early;                  // 3-D: issue the next plane's loads before (1) or after (0) the MFMA block
 };
 
@@ -242,8 +243,14 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
         const float* src = p.x + (((size_t)tb * p.H + ih) * p.W + iw) * CIN_MEM + g * KPL;
         if (CIN_MEM == CIN) return *reinterpret_cast<const vec_t*>(src);
         float o[KPL];
+        if (p.planar_in) {   // NCHW input: channel planes; consecutive lanes (pixels) read consecutive floats
 #pragma unroll
-        for (int k = 0; k < KPL; ++k) o[k] = (g * KPL + k < CIN_MEM) ? src[k] : 0.f;
+          for (int k = 0; k < KPL; ++k)
+            o[k] = (g * KPL + k < CIN_MEM) ? p.x[(((size_t)tb * CIN_MEM + g * KPL + k) * p.H + ih) * p.W + iw] : 0.f;
+        } else {
+#pragma unroll
+          for (int k = 0; k < KPL; ++k) o[k] = (g * KPL + k < CIN_MEM) ? src[k] : 0.f;
+        }
         return *reinterpret_cast<vec_t*>(o);
       };
       auto store2 = [&](int idx, int slot, const vec_t& val) {
@@ -437,10 +444,10 @@ int launch_lds(LdsConvParams& p, hipStream_t st) {
 
 int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
                           float res_scale, const float* res_up, float* y, int B, int D, int H, int W, int Cin, int Cin_mem, int Cout, int KD,
-                          int KHW, int stride, int relu, void* stream) {
+                          int KHW, int stride, int relu, void* stream, int planar_in) {
   LdsConvParams p{};
   p.x = x; p.wpack = wpack; p.alpha = alpha; p.beta = beta; p.res = res; p.res_scale = res_scale; p.res_up = res_up; p.y = y;
-  p.B = B; p.D = D; p.H = H; p.W = W; p.relu = relu;
+  p.B = B; p.D = D; p.H = H; p.W = W; p.relu = relu; p.planar_in = planar_in;
   {
     const char* e = getenv("MDF_CONV_PREFETCH_EARLY");   // A/B switch (dev): default = after the MFMA block
     p.prefetch_early = e ? atoi(e) : 0;

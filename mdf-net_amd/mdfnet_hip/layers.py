@@ -62,7 +62,7 @@ def use_hip(mod, *tensors):
     return True
 
 
-def conv2d_layer(conv, bn, x, relu=False, res=None, res_scale=1.0, res_up=None):
+def conv2d_layer(conv, bn, x, relu=False, res=None, res_scale=1.0, res_up=None, planar_in=False):
     """Conv2d [+ BatchNorm2d eval] [+ ReLU] [+ residual / upsample-add] as one kernel.  x, res: [B,H,W,C] NHWC."""
     k = conv.kernel_size[0]
     tensors = [conv.weight, conv.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
@@ -77,4 +77,5 @@ def conv2d_layer(conv, bn, x, relu=False, res=None, res_scale=1.0, res_up=None):
         return wp, None, (None if conv.bias is None else conv.bias.detach().float().contiguous())
 
     wp, alpha, beta = cache_of(conv).get(tensors, build)
-    return ops.conv2d_nhwc(x, wp, conv.in_channels, conv.out_channels, k, conv.stride[0], alpha, beta, relu, res, res_scale, res_up)
+    return ops.conv2d_nhwc(x, wp, conv.in_channels, conv.out_channels, k, conv.stride[0], alpha, beta, relu, res, res_scale, res_up,
+                           planar_in)

@@ -340,10 +340,14 @@ def pack_conv2d_weight(w):
 
 
 def conv2d_nhwc(x, wpack, cin, cout, ksize, stride=1, alpha=None, beta=None, relu=False, res=None, res_scale=1.0,
-                res_up=None):
-    """y = [res + res_scale *] ([up2(res_up) +] [relu](conv(x)*alpha + beta)).  x [B,H,W,Cin] contiguous."""
+                res_up=None, planar_in=False):
+    """y = [res + res_scale *] ([up2(res_up) +] [relu](conv(x)*alpha + beta)).  x [B,H,W,Cin] contiguous
+    (or planar [B,Cin,H,W] with planar_in=True, Cin < 4)."""
     _need_gpu(x, wpack)
-    b, h, w, c = x.shape
+    if planar_in:
+        b, c, h, w = x.shape
+    else:
+        b, h, w, c = x.shape
     assert c == cin and x.is_contiguous()
     pad = (ksize - 1) // 2
     ho, wo = (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
@@ -351,7 +355,7 @@ def conv2d_nhwc(x, wpack, cin, cout, ksize, stride=1, alpha=None, beta=None, rel
     _abi("mdf_conv2d_fwd", (x.data_ptr(), wpack.data_ptr(), None if alpha is None else alpha.data_ptr(),
                             None if beta is None else beta.data_ptr(), None if res is None else res.data_ptr(),
                             ctypes.c_float(res_scale), None if res_up is None else res_up.data_ptr(), y.data_ptr(),
-                            b, h, w, cin, cout, ksize, stride, int(relu), _stream(y),),
+                            b, h, w, cin, cout, ksize, stride, int(relu), int(planar_in), _stream(y),),
          tag=f"{cin}->{cout} k{ksize}s{stride} {h}x{w}x{b}",
          work={"flops": 2.0 * ksize * ksize * cin * cout * b * ho * wo, "bytes": 4.0 * (x.numel() + y.numel()),
                "bound": "mfma"})

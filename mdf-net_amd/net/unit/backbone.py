@@ -63,7 +63,10 @@ class FPN_4Scales(nn.Module):
             wp, bias, cin, cout = h
             return ops.conv2d_nhwc(t, wp, cin, cout, 1, 1, None, bias, False, None, 1.0, res_up)
         with torch.no_grad():
-            t2 = seq(self.conv12, seq(self.conv01, ops.to_nhwc(x)))
+            # the first conv reads the planar NCHW images as they arrive (no 113 MB layout copy at cfg2)
+            first = self.conv01[0]
+            t1 = layers.conv2d_layer(first.conv, first.bn, x.float().contiguous(), relu=True, planar_in=True)
+            t2 = seq(self.conv12, seq(self.conv01[1:], t1))
             t3 = seq(self.conv23, t2)
             t4 = seq(self.conv34, t3)
             hd = self._composed_heads()

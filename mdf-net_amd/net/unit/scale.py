@@ -18,8 +18,10 @@ def scale_cam(intrinsics, extrinsics, stage):
     k[:, :, :2, :] = k[:, :, :2, :] / float(2 ** (3 - stage))
     p = e.clone()
     p[:, :, :3, :4] = torch.matmul(k, e[:, :, :3, :4])
-    out = []
-    for host in p.unbind(1):
-        host = host.contiguous()
-        out.append(hostmirror.put(host.to(dev, non_blocking=True), host) if dev.type != "cpu" else host)
+    if dev.type == "cpu":
+        views = [v.contiguous() for v in p.unbind(1)]
+        return views[0], tuple(views[1:])
+    host = p.permute(1, 0, 2, 3).contiguous()            # [V,B,4,4]: ONE host->device copy, the views share its storage
+    on_dev = host.to(dev, non_blocking=True)
+    out = [hostmirror.put(on_dev[v], host[v]) for v in range(host.shape[0])]
     return out[0], tuple(out[1:])
