@@ -56,6 +56,11 @@ template <> __device__ __forceinline__ float vec_zero<1>() { return 0.f; }
 // the last block of a launch resets both, so every launch starts from zero.  Launches of conv_lds_kernel must not
 // overlap on different streams of one device (the product issues everything on one stream).
 __device__ unsigned g_sched[2];
+#ifdef MDF_STAMPS
+// diagnostic build only (scripts/diag_conv_stamps.sh): cycles spent by wave 0 of every block in each phase
+__device__ unsigned long long g_stamps[8];   // sched, prologue, compute, refill, total, blocks, items, dsteps
+#define STAMP() __builtin_readcyclecounter()
+#endif
 
 constexpr int round_s(int n) {  // smallest s >= n with s % 32 == 16
   int s = (n + 15) / 16 * 16;
@@ -210,7 +215,14 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
   const int lane_lds = (q * S + wave * SHW * PW + n16 * SHW) * KPL;
 
   int* item_slot = reinterpret_cast<int*>(lds + C::RING * C::PLANE);
+#ifdef MDF_STAMPS
+  unsigned long long t_sched = 0, t_pro = 0, t_comp = 0, t_fill = 0, n_items_done = 0, n_dsteps = 0;
+  const unsigned long long t_begin_all = STAMP();
+#endif
   for (int pass = 0;; ++pass) {
+#ifdef MDF_STAMPS
+    const unsigned long long ts0 = STAMP();
+#endif
     int item = 0;
     if constexpr (KD == 1) {
       // 2-D tiles all cost the same: static contiguous partition, no scheduling atomics (one global counter serialises at
@@ -223,6 +235,10 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
       item = *item_slot;
       if (item >= p.n_items) break;
     }
+#ifdef MDF_STAMPS
+    const unsigned long long ts1 = STAMP();
+    t_sched += ts1 - ts0; ++n_items_done;
+#endif
     if constexpr (KD == 1) {
       // ------------------------------------------------------------------ 2-D: one run of consecutive tiles, double-buffered
       const int t_begin = (int)((long long)blockIdx.x * p.n_tiles / gridDim.x);
@@ -306,14 +322,23 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
     const int mt_live = row_live ? (cols + 15) / 16 : 0;  // wave-uniform
 
     // ---- plane fill helpers -------------------------------------------------------------------------
+    // fill mapping: cin-group fastest, so consecutive lanes read consecutive 16-B pieces of a voxel / of neighbouring
+    // voxels (coalesced global loads; the in-kernel stamps showed 10K cycles per plane with the voxel-fastest mapping whose
+    // lanes were 128 B apart).  The price is bank conflicts on the few LDS stores, which is far cheaper.
+    constexpr int GF = (NG < 4) ? NG : 4;   // groups walked fastest: 64 contiguous bytes per voxel, <= 4-way store conflicts
+    auto split = [](int idx, int& v, int& g) {
+      const int glo = idx % GF, r = idx / GF;
+      v = r % (PH * PW);
+      g = (r / (PH * PW)) * GF + glo;
+    };
     auto load_elem = [&](int idx, int dz) -> vec_t {
-      const int g = idx / (PH * PW), v = idx - g * (PH * PW);
+      int v, g;
+      split(idx, v, g);
       const int row = v / PW, col = v - row * PW;
       const int ih = ih0 + row, iw = iw0 + col;
       if (idx >= NG * PH * PW || dz < 0 || dz >= p.D || ih < 0 || ih >= p.H || iw < 0 || iw >= p.W) return vec_zero<KPL>();
       const float* src = p.x + ((((size_t)b * p.D + dz) * p.H + ih) * p.W + iw) * CIN_MEM + g * KPL;
       if (CIN_MEM == CIN) return *reinterpret_cast<const vec_t*>(src);
-      // channel-padded input (e.g. RGB -> 4): KPL == 1
       float o[KPL];
 #pragma unroll
       for (int k = 0; k < KPL; ++k) o[k] = (g * KPL + k < CIN_MEM) ? src[k] : 0.f;
@@ -321,21 +346,40 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
     };
     auto store_elem = [&](int idx, int slot, const vec_t& val) {
       if (idx < NG * PH * PW) {
-        const int g = idx / (PH * PW), v = idx - g * (PH * PW);
+        int v, g;
+        split(idx, v, g);
         *reinterpret_cast<vec_t*>(lds + slot * C::PLANE + (g * S + v) * KPL) = val;
       }
     };
     auto slot_of = [](int dz) { return (KD == 1) ? 0 : ((dz % KD) + KD) % KD; };
 
     // prologue: planes d0-PD .. d0+PD
-#pragma unroll 1
-    for (int dz = d0 - C::PD; dz <= d0 + C::PD; ++dz) {
+    if constexpr (CIN <= 16) {
+      vec_t pro[KD][C::NFILL];   // all KD planes in flight at once: one memory latency instead of KD
 #pragma unroll
-      for (int k = 0; k < C::NFILL; ++k) store_elem(tid + k * 256, slot_of(dz), load_elem(tid + k * 256, dz));
+      for (int j = 0; j < KD; ++j)
+#pragma unroll
+        for (int k = 0; k < C::NFILL; ++k) pro[j][k] = load_elem(tid + k * 256, d0 - C::PD + j);
+#pragma unroll
+      for (int j = 0; j < KD; ++j)
+#pragma unroll
+        for (int k = 0; k < C::NFILL; ++k) store_elem(tid + k * 256, slot_of(d0 - C::PD + j), pro[j][k]);
+    } else {                     // CIN = 32: 84 more live registers make the kernel spill (measured), so plane by plane
+#pragma unroll 1
+      for (int dz = d0 - C::PD; dz <= d0 + C::PD; ++dz) {
+#pragma unroll
+        for (int k = 0; k < C::NFILL; ++k) store_elem(tid + k * 256, slot_of(dz), load_elem(tid + k * 256, dz));
+      }
     }
     __syncthreads();
+#ifdef MDF_STAMPS
+    t_pro += STAMP() - ts1;
+#endif
 
     for (int d = d0; d < d1; ++d) {
+#ifdef MDF_STAMPS
+      const unsigned long long tc0 = STAMP();
+#endif
       const bool more = (KD > 1) && (d + 1 < d1);
       // fetch the plane the next step needs (d+1+PD) into registers; consumed after this step's MFMAs
       vec_t pf[C::NFILL];
@@ -355,6 +399,10 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
           default: step<C, KD, KHW, SHW, COUT, MT>(planes, wl, p, row_vox, w0, q, n16); break;
         }
       }
+#ifdef MDF_STAMPS
+      const unsigned long long tc1 = STAMP();
+      t_comp += tc1 - tc0; ++n_dsteps;
+#endif
       if (more && !p.prefetch_early) {
 #pragma unroll
         for (int k = 0; k < C::NFILL; ++k) pf[k] = load_elem(tid + k * 256, d + 1 + C::PD);
@@ -365,9 +413,19 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
         for (int k = 0; k < C::NFILL; ++k) store_elem(tid + k * 256, slot_of(d + 1 + C::PD), pf[k]);
         __syncthreads();
       }
+#ifdef MDF_STAMPS
+      t_fill += STAMP() - tc1;
+#endif
     }
     }  // 3-D path
   }
+#ifdef MDF_STAMPS
+  if (tid == 0) {
+    atomicAdd(&g_stamps[0], t_sched); atomicAdd(&g_stamps[1], t_pro); atomicAdd(&g_stamps[2], t_comp);
+    atomicAdd(&g_stamps[3], t_fill); atomicAdd(&g_stamps[4], STAMP() - t_begin_all); atomicAdd(&g_stamps[5], 1ull);
+    atomicAdd(&g_stamps[6], n_items_done); atomicAdd(&g_stamps[7], n_dsteps);
+  }
+#endif
   if (KD > 1 && tid == 0) {
     const unsigned done = atomicAdd(&g_sched[1], 1u);
     if (done == gridDim.x - 1) {  // last block out: re-arm the counters for the next launch
@@ -435,6 +493,18 @@ int launch_lds(LdsConvParams& p, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef MDF_STAMPS
+extern "C" int mdf_debug_read_stamps(unsigned long long* out8, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8);
+  if (e != hipSuccess) return -3;
+  if (reset) {
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z);
+  }
+  return 0;
+}
+#endif
 
 // Internal entry used by mdf_conv3d_fwd (stride-1 3x3x3) and mdf_conv2d_fwd.  Returns MDF_EUNSUPPORTED when the
 // configuration has no LDS-kernel instantiation (caller falls back to conv v1 / reports the error).
