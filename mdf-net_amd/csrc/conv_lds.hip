@@ -448,7 +448,9 @@ int launch_lds(LdsConvParams& p, hipStream_t st) {
   // partially-filled tile columns) while keeping >= 3 planes per chunk (prologue = KD-1 extra planes).
   // 2-D: items = runs of consecutive tiles (double-buffered inside the run), ~8 runs per resident block.
   if (KD > 1) {
-    long long want = (6LL * max_grid + tiles - 1) / tiles;
+    long long per_block = 6;
+    if (const char* e = getenv("MDF_CONV_ITEMS_PER_BLOCK")) { if (atoi(e) > 0) per_block = atoi(e); }   // dev A/B
+    long long want = (per_block * max_grid + tiles - 1) / tiles;
     if (want < 1) want = 1;
     int dch = (int)(p.D / want);
     if (dch < 3) dch = 3;

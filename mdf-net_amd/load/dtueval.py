@@ -31,4 +31,5 @@ class LoadDataset(torch.utils.data.Dataset):
             extrinsics.append(e)
         return {"imgs": np.stack(imgs).transpose([0, 3, 1, 2]), "intrinsics": np.stack(intrinsics),
                 "extrinsics": np.stack(extrinsics), "depth_range": np.array([425.0, 935.0]),
+                "view_ids": np.array([ref_view] + src_views[:self.nviews - 1], dtype=np.int64), "scan": folder,
                 "filename": folder + "/{}/" + "{:0>8}".format(ref_view) + "{}"}

@@ -35,4 +35,5 @@ class LoadDataset(torch.utils.data.Dataset):
             ranges.append(r)
         return {"imgs": np.stack(imgs).transpose([0, 3, 1, 2]), "intrinsics": np.stack(intrinsics),
                 "extrinsics": np.stack(extrinsics), "depth_range": ranges[0],
+                "view_ids": np.array([ref_view] + src_views[:self.nviews - 1], dtype=np.int64), "scan": scene,
                 "filename": scene + "/{}/" + "{:0>8}".format(ref_view) + "{}"}

@@ -15,11 +15,29 @@ class CoreNet(torch.nn.Module):
         self.Depth_regress, self.Confidence_regress = Regress
         print("{} parameters: {}".format(self._get_name(), sum(p.data.nelement() for p in self.parameters())))
 
-    def forward(self, origin_imgs, extrinsics, intrinsics, depth_range):
+    def forward(self, origin_imgs, extrinsics, intrinsics, depth_range, feature_cache=None, view_keys=None):
+        """Same call as the reference (net/core.py:30).  Optional, for whole-scan evaluation: a dict
+        `feature_cache` and per-view hashable `view_keys` [V] (batch 1) -- feature pyramids are then computed once per
+        image and reused while it serves as a source view of other items; results are identical."""
         with layers.model_mode(self.training):
-            return self._forward(origin_imgs, extrinsics, intrinsics, depth_range)
+            return self._forward(origin_imgs, extrinsics, intrinsics, depth_range, feature_cache, view_keys)
 
-    def _forward(self, origin_imgs, extrinsics, intrinsics, depth_range):
+    def _pyramids(self, imgs, feature_cache, view_keys):
+        nb, nv = imgs.shape[:2]
+        if feature_cache is not None and view_keys is not None and nb == 1 and not self.training:
+            missing = [v for v in range(nv) if view_keys[v] not in feature_cache]
+            if missing:
+                f = self.Backbone(imgs[0, missing])                      # only the images not seen yet, batched
+                for j, v in enumerate(missing):
+                    feature_cache[view_keys[v]] = tuple(lv[j:j + 1] for lv in f)
+            return [feature_cache[view_keys[v]] for v in range(nv)]
+        if getattr(self.Backbone, "batch_views", False) and not self.training:
+            # eval BatchNorm is per-sample: one batched pass over the B*V images == V separate calls (core.py:42)
+            f = self.Backbone(imgs.reshape(nb * nv, *imgs.shape[2:]))
+            return [tuple(lv.reshape(nb, nv, *lv.shape[1:])[:, v] for lv in f) for v in range(nv)]
+        return [self.Backbone(v) for v in torch.unbind(imgs, 1)]
+
+    def _forward(self, origin_imgs, extrinsics, intrinsics, depth_range, feature_cache=None, view_keys=None):
         """imgs [B,V,3,H,W] (view 0 = reference), E [B,V,4,4], K [B,V,3,3], range [B,2]
         -> train: {"depth": [1/8, 1/4, 1/2, 1/1]};  eval: {"depth": [B,H,W], "confidence": [B,H,W]}."""
         if not self.training and not origin_imgs.is_cuda:
@@ -29,14 +47,7 @@ class CoreNet(torch.nn.Module):
             # one device->host hop for the control-plane tensors (cameras, range); the slots then find host
             # mirrors and never synchronise again
             hostmirror.ensure((extrinsics, intrinsics, depth_range))
-        imgs = origin_imgs.float()
-        nb, nv = imgs.shape[:2]
-        if getattr(self.Backbone, "batch_views", False) and not self.training:
-            # eval BatchNorm is per-sample: one batched pass over the B*V images == V separate calls (core.py:42)
-            f = self.Backbone(imgs.reshape(nb * nv, *imgs.shape[2:]))
-            pyramids = [tuple(lv.reshape(nb, nv, *lv.shape[1:])[:, v] for lv in f) for v in range(nv)]
-        else:
-            pyramids = [self.Backbone(v) for v in torch.unbind(imgs, 1)]
+        pyramids = self._pyramids(origin_imgs.float(), feature_cache, view_keys)
         depth = hypos = prob = None
         depths = []
         for stage, (make_hypos, aggregate, regular) in enumerate(zip(self.Depth_hypos, self.Homoaggre, self.Regular)):

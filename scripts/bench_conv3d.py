@@ -43,14 +43,15 @@ for name, ci, co, mode, D, H, W in L:
             ops.conv3d_ndhwc(x, wp, ci, co, st, tr, al, be, True)
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n
-    ab = os.environ.get("MDF_AB")   # e.g. MDF_AB=MDF_CONV_PREFETCH_EARLY : interleaved A/B of an env switch in ONE process
+    ab = os.environ.get("MDF_AB")   # e.g. MDF_AB=MDF_CONV_ITEMS_PER_BLOCK MDF_AB_VALS=2,3,6 : interleaved in ONE process
     if ab:
-        ta, tb = [], []
-        for _ in range(5):
-            os.environ[ab] = os.environ.get("MDF_AB_VAL0", "0"); ta.append(timeit())
-            os.environ[ab] = os.environ.get("MDF_AB_VAL", "1"); tb.append(timeit())
-        ms = min(ta)
-        print(f"   A/B {ab}: 0 -> {min(ta)*1e3:.1f} us (med {sorted(ta)[2]*1e3:.1f}), 1 -> {min(tb)*1e3:.1f} us (med {sorted(tb)[2]*1e3:.1f})")
+        vals = os.environ.get("MDF_AB_VALS", "0,1").split(",")
+        res = {v: [] for v in vals}
+        for _ in range(4):
+            for v in vals:
+                os.environ[ab] = v; res[v].append(timeit())
+        ms = min(res[vals[0]])
+        print(f"   A/B {ab}: " + "  ".join(f"{v} -> {min(t)*1e3:.1f} us" for v, t in res.items()))
     else:
         ms = timeit()
     nvox = D * H * W if tr else y.shape[1] * y.shape[2] * y.shape[3]

@@ -48,3 +48,33 @@ def test_eval_then_filter_then_ply(tmp_path, seeded_sd):
     k, e = data_io.read_cam_file(os.path.join(root, "scan1", "cams", "00000000_cam.txt"))
     masks, last, rep = filt.check_geometric_consistency(d, torch.from_numpy(k), torch.from_numpy(e), d, torch.from_numpy(k), torch.from_numpy(e))
     assert len(masks) == 9 and masks[0].shape == (1, 128, 160) and rep.shape == (1, 128, 160) and bool(last[:, 1:-1, 1:-1].all())
+
+
+def test_feature_cache_gives_identical_results_and_fewer_backbone_calls(tmp_path, seeded_sd):
+    """N3: with the cross-item feature cache every image goes through the pyramid once; depth maps are bit-identical."""
+    import importlib.util
+    from load import synthetic
+    from load.dtueval import LoadDataset
+    from tools import data_io
+    root = synthetic.write_dtu_eval_set(str(tmp_path / "dtu"), scans=(1,), nviews_total=6, width=160, height=128)
+    spec = importlib.util.spec_from_file_location("mdf_eval", os.path.join(os.path.dirname(data_io.__file__), "..", "eval.py"))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+    m = build_model()
+    m.load_state_dict(seeded_sd)
+    dev = torch.device("cuda", 0)
+    m.eval().to(dev)
+    calls = []
+    hk = m.Backbone.register_forward_hook(lambda mod, i, o: calls.append(i[0].shape[0]))
+    ds = LoadDataset(root, os.path.join(root, "pair.txt"), [1], nviews=4)
+    ev.run_eval(m, ds, dev, str(tmp_path / "a"), log=lambda *a: None, nworks=0, cache_features=False)
+    n_plain = sum(calls)
+    calls.clear()
+    ev.run_eval(m, ds, dev, str(tmp_path / "b"), log=lambda *a: None, nworks=0, cache_features=True)
+    n_cached = sum(calls)
+    hk.remove()
+    assert n_plain == 6 * 4 and n_cached == 6, (n_plain, n_cached)        # images through the backbone
+    for v in range(6):
+        a, _ = data_io.read_pfm(os.path.join(str(tmp_path / "a"), "scan1", "depth_est", "%08d.pfm" % v))
+        b, _ = data_io.read_pfm(os.path.join(str(tmp_path / "b"), "scan1", "depth_est", "%08d.pfm" % v))
+        assert np.array_equal(a, b)
