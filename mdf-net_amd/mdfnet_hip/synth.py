@@ -64,7 +64,7 @@ def make_images(width, height, nviews, batch=1, seed=0, smooth=True):
     big = np.repeat(np.repeat(big, 4, axis=2), 4, axis=3)
     out = np.empty((batch, nviews, 3, height, width), np.float32)
     for v in range(nviews):
-        sh = 8 * v
+        sh = 8 * (v % 32)
         out[:, v] = 0.7 * big[:, :, 16:16 + height, sh:sh + width]
     out += 0.3 * rng.rand(batch, nviews, 3, height, width).astype(np.float32)
     return torch.from_numpy(np.clip(out, 0.0, 0.999999).astype(np.float32))
