@@ -47,6 +47,28 @@ template <> __device__ __forceinline__ void vec_to<4>(const float4& v, float* o)
 template <> __device__ __forceinline__ void vec_to<2>(const float2& v, float* o) { o[0] = v.x; o[1] = v.y; }
 template <> __device__ __forceinline__ void vec_to<1>(const float& v, float* o) { o[0] = v; }
 
+// Weight fragments are fetched with BUFFER loads: the address is {SGPR resource, one lane-offset VGPR that never changes,
+// scalar/immediate fragment offset}.  With flat global loads every fragment needed its own 64-bit VGPR address (held in
+// registers or re-added on the VALU): 150-300 address pairs per kernel, the reason the pipelined tap loop sat at its
+// register cap and spilled (scripts/isa_stats.py).
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);   // raw buffer, dword format (gfx9)
+}
+template <int KPL> __device__ __forceinline__ void buf_load_to(__amdgpu_buffer_rsrc_t r, int voff, int soff, float* o);
+template <> __device__ __forceinline__ void buf_load_to<4>(__amdgpu_buffer_rsrc_t r, int voff, int soff, float* o) {
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w);
+}
+template <> __device__ __forceinline__ void buf_load_to<2>(__amdgpu_buffer_rsrc_t r, int voff, int soff, float* o) {
+  const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y);
+}
+template <> __device__ __forceinline__ void buf_load_to<1>(__amdgpu_buffer_rsrc_t r, int voff, int soff, float* o) {
+  o[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
 template <int KPL> __device__ __forceinline__ typename VecT<KPL>::type vec_zero();
 template <> __device__ __forceinline__ float4 vec_zero<4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 template <> __device__ __forceinline__ float2 vec_zero<2>() { return make_float2(0.f, 0.f); }
@@ -81,14 +103,22 @@ struct Cfg {
   static constexpr int PLANE = CIN * S;  // floats
   static constexpr int NFILL = (NG * PH * PW + 255) / 256;
   static constexpr int RING = (KD > 1) ? KD : 2;  // 3-D: rolling window of KD planes; 2-D: double-buffered tiles
+  static constexpr int NSTEP = KD * KHW * KHW * NCH;   // MFMA pipeline steps per output row-tile (tap x cin chunk)
+  // small layers keep ALL their weight fragments in registers for the whole kernel (<= 40 VGPRs; beyond that occupancy drops and it is a loss, measured) instead of re-fetching
+  // them from L1 for every tile: with 8-16 MFMAs per step there is nothing to hide that round trip behind
+  static constexpr bool WREG = (KD == 1) && (NSTEP * NT * KPL <= 40);
+  // epilogue scale/shift hoisted out of the tile loop where registers allow (the 3-D and 4-n-tile kernels sit at their caps)
+  static constexpr bool EPI_REG = (KD == 1) && (NT <= 2);
+  static constexpr int WN = WREG ? NSTEP : 1;
   static constexpr size_t LDS_BYTES = (size_t)RING * PLANE * sizeof(float) + 16;  // + the broadcast slot of the item id
 };
 
 // One output row-tile of one depth plane: MTL live m-tiles (16 voxels each) x all couts.  Fully unrolled over the
 // taps: LDS offsets are immediates, no bounds logic (halos are zero-filled in LDS).
 template <typename C, int KD, int KHW, int SHW, int COUT, int MTL>
-__device__ __forceinline__ void step(const float* const (&planes)[KD], const float* __restrict__ wl, const LdsConvParams& p,
-                                     size_t row_vox, int w0, int q, int n16) {
+__device__ __forceinline__ void step(const float* const (&planes)[KD], __amdgpu_buffer_rsrc_t wres, int wvoff, const LdsConvParams& p,
+                                     size_t row_vox, int w0, int q, int n16, const float (&wr)[C::WN][C::NT][C::KPL],
+                                     const float (&al)[C::NT][4], const float (&be)[C::NT][4]) {
   constexpr int KPL = C::KPL, NCH = C::NCH, NT = C::NT, S = C::S, PW = C::PW;
   typedef typename VecT<KPL>::type vec_t;
   f32x4 acc[MTL][NT];
@@ -101,14 +131,14 @@ __device__ __forceinline__ void step(const float* const (&planes)[KD], const flo
   // before its MFMAs (prefetch distance <= 1), leaving the matrix pipe idle for an L1/L2 round trip per step.
   // Weight fragments (global, L1-resident) run AHEAD_A steps ahead, LDS activation fragments one step ahead; the
   // order is pinned with sched_barrier, the counted s_waitcnt is left to the compiler.
-  constexpr int NSTEP = KD * KHW * KHW * NCH;
+  constexpr int NSTEP = C::NSTEP;
   constexpr int AHEAD_A = (NSTEP >= 3) ? 2 : (NSTEP - 1 > 0 ? NSTEP - 1 : 0);
   constexpr int NA = AHEAD_A + 1;
   float af[NA][NT][KPL], bf[2][MTL][KPL];
   auto load_a = [&](int i, int buf) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
-      vec_to<KPL>(*reinterpret_cast<const vec_t*>(wl + (size_t)(i * NT + nt) * (64 * KPL)), af[buf][nt]);
+      buf_load_to<KPL>(wres, wvoff, (i * NT + nt) * (64 * KPL * 4), af[buf][nt]);
   };
   auto load_b = [&](int i, int buf) {
     const int ch = i % NCH, tap = i / NCH;
@@ -117,12 +147,16 @@ __device__ __forceinline__ void step(const float* const (&planes)[KD], const flo
     for (int t = 0; t < MTL; ++t)
       vec_to<KPL>(*reinterpret_cast<const vec_t*>(planes[kd] + ((ch * 4) * S + kh * PW + kw + t * 16 * SHW) * KPL), bf[buf][t]);
   };
+  if constexpr (!C::WREG) {
 #pragma unroll
-  for (int i = 0; i < AHEAD_A; ++i) load_a(i, i % NA);
+    for (int i = 0; i < AHEAD_A; ++i) load_a(i, i % NA);
+  }
   load_b(0, 0);
 #pragma unroll
   for (int i = 0; i < NSTEP; ++i) {
-    if (i + AHEAD_A < NSTEP) load_a(i + AHEAD_A, (i + AHEAD_A) % NA);
+    if constexpr (!C::WREG) {
+      if (i + AHEAD_A < NSTEP) load_a(i + AHEAD_A, (i + AHEAD_A) % NA);
+    }
     if (i + 1 < NSTEP) load_b(i + 1, (i + 1) & 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -130,8 +164,10 @@ __device__ __forceinline__ void step(const float* const (&planes)[KD], const flo
 #pragma unroll
       for (int t = 0; t < MTL; ++t)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i % NA][nt][s], bf[i & 1][t][s], acc[t][nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) {
+          const float a = C::WREG ? wr[C::WREG ? i : 0][nt][s] : af[i % NA][nt][s];
+          acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[i & 1][t][s], acc[t][nt], 0, 0, 0);
+        }
     __builtin_amdgcn_sched_barrier(0);
   }
   // epilogue: lane owns couts nt*16 + 4q .. +3 of voxel (row, w0 + t*16 + n16)
@@ -139,12 +175,14 @@ __device__ __forceinline__ void step(const float* const (&planes)[KD], const flo
   for (int nt = 0; nt < NT; ++nt) {
     const int c0 = nt * 16 + 4 * q;
     if (c0 >= COUT) continue;
-    float al[4] = {1.f, 1.f, 1.f, 1.f}, be[4] = {0.f, 0.f, 0.f, 0.f};
+    float al_l[4], be_l[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (c0 + k < COUT) {
-        if (p.alpha) al[k] = p.alpha[c0 + k];
-        if (p.beta) be[k] = p.beta[c0 + k];
+      if constexpr (C::EPI_REG) {
+        al_l[k] = al[nt][k]; be_l[k] = be[nt][k];
+      } else {
+        al_l[k] = (c0 + k < COUT && p.alpha) ? p.alpha[c0 + k] : 1.f;
+        be_l[k] = (c0 + k < COUT && p.beta) ? p.beta[c0 + k] : 0.f;
       }
     }
 #pragma unroll
@@ -154,7 +192,7 @@ __device__ __forceinline__ void step(const float* const (&planes)[KD], const flo
       float o[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        o[k] = acc[t][nt][k] * al[k] + be[k];
+        o[k] = acc[t][nt][k] * al_l[k] + be_l[k];
         if (p.relu) o[k] = fmaxf(o[k], 0.f);
       }
       const size_t oi = (row_vox + ow) * COUT + c0;
@@ -210,11 +248,35 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, n16 = lane & 15;
-  const float* wl = p.wpack + (size_t)lane * KPL;
+  const __amdgpu_buffer_rsrc_t wres = make_rsrc(p.wpack, (unsigned)(C::NSTEP * C::NT * 64 * KPL * 4));
+  const int wvoff = lane * KPL * 4;   // bytes
   // lane-constant part of the B-fragment LDS address (floats)
   const int lane_lds = (q * S + wave * SHW * PW + n16 * SHW) * KPL;
 
   int* item_slot = reinterpret_cast<int*>(lds + C::RING * C::PLANE);
+  // per-lane constants for the whole kernel: epilogue scale/shift of the lane's 4 couts, and (small layers) all weights
+  float al[C::NT][4], be[C::NT][4];
+#pragma unroll
+  for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = nt * 16 + 4 * q + k;
+      al[nt][k] = (C::EPI_REG && c < COUT && p.alpha) ? p.alpha[c] : 1.f;
+      be[nt][k] = (C::EPI_REG && c < COUT && p.beta) ? p.beta[c] : 0.f;
+    }
+  float wr[C::WN][C::NT][KPL];
+  if constexpr (C::WREG) {
+#pragma unroll
+    for (int i = 0; i < C::NSTEP; ++i)
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt)
+        buf_load_to<KPL>(wres, wvoff, (i * C::NT + nt) * (64 * KPL * 4), wr[i][nt]);
+  } else {
+#pragma unroll
+    for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+      for (int k = 0; k < KPL; ++k) wr[0][nt][k] = 0.f;
+  }
 #ifdef MDF_STAMPS
   unsigned long long t_sched = 0, t_pro = 0, t_comp = 0, t_fill = 0, n_items_done = 0, n_dsteps = 0;
   const unsigned long long t_begin_all = STAMP();
@@ -251,8 +313,16 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
         th0 = (rest % p.tiles_h) * C::TH;
         tw0 = twi * C::TW;
       };
+      // fill mapping as in the 3-D path: cin-group fastest, so consecutive lanes read consecutive 16-B pieces (coalesced)
+      constexpr int GF2 = (NG < 4) ? NG : 4;
+      auto split2 = [](int idx, int& v, int& g) {
+        const int glo = idx % GF2, r = idx / GF2;
+        v = r % (PH * PW);
+        g = (r / (PH * PW)) * GF2 + glo;
+      };
       auto load2 = [&](int idx, int tb, int th0, int tw0) -> vec_t {
-        const int g = idx / (PH * PW), v = idx - g * (PH * PW);
+        int g, v;
+        split2(idx, v, g);
         const int row = v / PW, col = v - row * PW;
         const int ih = th0 * SHW - C::PAD + row, iw = tw0 * SHW - C::PAD + col;
         if (idx >= NG * PH * PW || ih < 0 || ih >= p.H || iw < 0 || iw >= p.W) return vec_zero<KPL>();
@@ -271,7 +341,8 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
       };
       auto store2 = [&](int idx, int slot, const vec_t& val) {
         if (idx < NG * PH * PW) {
-          const int g = idx / (PH * PW), v = idx - g * (PH * PW);
+          int g, v;
+          split2(idx, v, g);
           *reinterpret_cast<vec_t*>(lds + slot * C::PLANE + (g * S + v) * KPL) = val;
         }
       };
@@ -280,25 +351,39 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
 #pragma unroll
       for (int k = 0; k < C::NFILL; ++k) store2(tid + k * 256, 0, load2(tid + k * 256, tb, th0, tw0));
       __syncthreads();
+#ifdef MDF_STAMPS
+      t_pro += STAMP() - ts1;
+#endif
       for (int tl = t_begin; tl < t_end; ++tl) {
         const int slot = (tl - t_begin) & 1;
         const bool row_live2 = (th0 + wave) < p.Ho;
         const int cols2 = min(p.Wo - tw0, C::TW);
         const int mt_live2 = row_live2 ? (cols2 + 15) / 16 : 0;
+        const int cb = tb, ch0 = th0, cw0 = tw0;           // this tile's origin; (tb,th0,tw0) move on to the next one
+        const bool more2 = tl + 1 < t_end;
+        if (more2) tile_origin(tl + 1, tb, th0, tw0);
+#ifdef MDF_STAMPS
+        const unsigned long long tc0 = STAMP();
+#endif
         if (mt_live2 > 0) {
           const float* planes[1] = {lds + slot * C::PLANE + lane_lds};
-          const size_t row_vox = ((size_t)tb * p.Ho + (th0 + wave)) * p.Wo;
+          const size_t row_vox = ((size_t)cb * p.Ho + (ch0 + wave)) * p.Wo;
           switch (mt_live2) {
-            case 1: step<C, KD, KHW, SHW, COUT, 1>(planes, wl, p, row_vox, tw0, q, n16); break;
-            case 2: if (MT >= 2) step<C, KD, KHW, SHW, COUT, (MT >= 2 ? 2 : 1)>(planes, wl, p, row_vox, tw0, q, n16); break;
-            case 3: if (MT >= 3) step<C, KD, KHW, SHW, COUT, (MT >= 3 ? 3 : 1)>(planes, wl, p, row_vox, tw0, q, n16); break;
-            default: step<C, KD, KHW, SHW, COUT, MT>(planes, wl, p, row_vox, tw0, q, n16); break;
+            case 1: step<C, KD, KHW, SHW, COUT, 1>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be); break;
+            case 2: if (MT >= 2) step<C, KD, KHW, SHW, COUT, (MT >= 2 ? 2 : 1)>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be); break;
+            case 3: if (MT >= 3) step<C, KD, KHW, SHW, COUT, (MT >= 3 ? 3 : 1)>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be); break;
+            default: step<C, KD, KHW, SHW, COUT, MT>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be); break;
           }
         }
-        if (tl + 1 < t_end) {
+#ifdef MDF_STAMPS
+        const unsigned long long tc1 = STAMP();
+        t_comp += tc1 - tc0; ++n_dsteps;
+#endif
+        if (more2) {
           // next tile -> the other slot.  Every wave passed the barrier before this tile's compute, so nobody still
           // reads that slot; one barrier (after the writes) per tile.
-          tile_origin(tl + 1, tb, th0, tw0);
+          // (issuing these loads before the MFMA block was measured: no gain -- the wait only moves -- and 30 more live
+          // registers cost the k5 kernels an occupancy step)
           vec_t pf[C::NFILL];
 #pragma unroll
           for (int k = 0; k < C::NFILL; ++k) pf[k] = load2(tid + k * 256, tb, th0, tw0);
@@ -306,6 +391,9 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
           for (int k = 0; k < C::NFILL; ++k) store2(tid + k * 256, slot ^ 1, pf[k]);
           __syncthreads();
         }
+#ifdef MDF_STAMPS
+        t_fill += STAMP() - tc1;
+#endif
       }
       continue;
     } else {
@@ -393,10 +481,10 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
         for (int kd = 0; kd < KD; ++kd) planes[kd] = lds + slot_of(d + kd - C::PD) * C::PLANE + lane_lds;
         const size_t row_vox = (((size_t)b * p.D + d) * p.Ho + (h0 + wave)) * p.Wo;
         switch (mt_live) {
-          case 1: step<C, KD, KHW, SHW, COUT, 1>(planes, wl, p, row_vox, w0, q, n16); break;
-          case 2: if (MT >= 2) step<C, KD, KHW, SHW, COUT, (MT >= 2 ? 2 : 1)>(planes, wl, p, row_vox, w0, q, n16); break;
-          case 3: if (MT >= 3) step<C, KD, KHW, SHW, COUT, (MT >= 3 ? 3 : 1)>(planes, wl, p, row_vox, w0, q, n16); break;
-          default: step<C, KD, KHW, SHW, COUT, MT>(planes, wl, p, row_vox, w0, q, n16); break;
+          case 1: step<C, KD, KHW, SHW, COUT, 1>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be); break;
+          case 2: if (MT >= 2) step<C, KD, KHW, SHW, COUT, (MT >= 2 ? 2 : 1)>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be); break;
+          case 3: if (MT >= 3) step<C, KD, KHW, SHW, COUT, (MT >= 3 ? 3 : 1)>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be); break;
+          default: step<C, KD, KHW, SHW, COUT, MT>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be); break;
         }
       }
 #ifdef MDF_STAMPS

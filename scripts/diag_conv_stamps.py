@@ -33,3 +33,24 @@ for name, ci, co, D, H, W in [("32->16", 32, 16, 48, 148, 200), ("16->16", 16, 1
     print(f"{name:7s} {e0.elapsed_time(e1)/n*1e3:7.1f} us/launch | per block-launch: total {tot/blocks:9.0f} cyc = sched {sched/tot:5.1%} prologue {pro/tot:5.1%} "
           f"compute {comp/tot:5.1%} refill {fill/tot:5.1%} | items/block {items/blocks:5.1f}, d-steps/item {dsteps/max(items-blocks,1):4.1f}, "
           f"cyc/d-step compute {comp/dsteps:7.0f} refill {fill/dsteps:6.0f}, cyc/item sched {sched/items:6.0f} prologue {pro/max(items-blocks,1):6.0f}")
+
+print("2-D layers (per tile: compute = MFMA step incl. epilogue stores, refill = wait for the next tile's loads + LDS stores + barrier)")
+for name, ci, co, k, st, b, h, w in [("bb 8->8", 8, 8, 3, 1, 5, 1184, 1600), ("bb 8->16 k5s2", 8, 16, 5, 2, 5, 1184, 1600), ("bb 16->16", 16, 16, 3, 1, 5, 592, 800),
+                                     ("bb 32->32", 32, 32, 3, 1, 5, 296, 400), ("bb 32->64 k5s2", 32, 64, 5, 2, 5, 296, 400), ("bb 64->64", 64, 64, 3, 1, 5, 148, 200)]:
+    x = torch.randn(b, h, w, ci, device=dev)
+    wp = ops.pack_conv2d_weight(torch.randn(co, ci, k, k, device=dev) * 0.1)
+    for ev in ("0", "1"):
+        os.environ["MDF_CONV2D_PREFETCH_EARLY"] = ev
+        for _ in range(2): ops.conv2d_nhwc(x, wp, ci, co, k, st)
+        torch.cuda.synchronize()
+        buf = (ctypes.c_ulonglong * 8)()
+        lib.mdf_debug_read_stamps(buf, 1)
+        n = 5
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n): ops.conv2d_nhwc(x, wp, ci, co, k, st)
+        e1.record(); torch.cuda.synchronize()
+        lib.mdf_debug_read_stamps(buf, 1)
+        sched, pro, comp, fill, tot, blocks, items, tiles = [float(v) for v in buf]
+        print(f"{name:15s} early={ev} {e0.elapsed_time(e1)/n*1e3:7.1f} us | blocks/launch {blocks/n:6.0f} total {tot/blocks:9.0f} cyc: prologue {pro/tot:5.1%} compute {comp/tot:5.1%} "
+              f"refill {fill/tot:5.1%} | tiles/block {tiles/blocks:6.1f}, cyc/tile compute {comp/tiles:6.0f} refill {fill/tiles:6.0f}")
