@@ -48,11 +48,13 @@ def family(name, tag):
     if name == "mdf_conv3d_fwd":
         return "conv3d (regulariser): conv_lds_kernel / conv3d_kernel, fp32 MFMA implicit GEMM"
     if name == "mdf_conv2d_fwd":
-        return "conv2d (feature pyramid + refine): conv_lds_kernel, fp32 MFMA implicit GEMM"
+        return "conv2d (feature pyramid + refine + prob-head partial sums): conv_lds_kernel, fp32 MFMA implicit GEMM"
     if name == "mdf_warp_aggregate_vec_fwd":
         return "warp_kernel<kVec> (fused warp+aggregate)"
     if name == "mdf_prob_softmax_regress_fwd":
         return "prob_head_kernel"
+    if name == "mdf_prob_from_partials_fwd":
+        return "prob_from_partials_kernel (combine + softmax(D) + soft-argmin)"
     return name.replace("mdf_", "").replace("_fwd", "") + "_kernel"
 
 

@@ -121,6 +121,12 @@ int mdf_conv_pack_weights(const float* w, float* wpack, int Cin, int Cout, int n
  *   prob [B,D,h,w]; depth [B,h,w] or NULL; hypos as above (may be NULL when depth is NULL).       */
 int mdf_prob_softmax_regress_fwd(const float* x, const float* w, const float* hypos, int hypos_per_pixel,
                                  float* prob, float* depth, int B, int D, int h, int wd, int Cin, void* stream);
+/* Same head in partial-sum form (the fast path): first run mdf_conv2d_fwd over the B*D planes of x ([B*D,h,w,Cin]) with the
+ * 2-D weight w2[kd][cin][kh][kw] = w[0][cin][kd][kh][kw], kd = 0..2, plus a 4th all-zero output channel (Cout = 4),
+ * giving partials [B,D,h,w,4]; this call then forms logit[d] = P0[d-1] + P1[d] + P2[d+1], the softmax over D and the
+ * soft-argmin.  D <= 96.  partials 16-byte aligned.                                                               */
+int mdf_prob_from_partials_fwd(const float* partials, const float* hypos, int hypos_per_pixel, float* prob, float* depth,
+                               int B, int D, int h, int wd, void* stream);
 
 /* ---- a9  depth_regression (net/unit/regress.py:5-7): depth = sum_d prob*hypos ----------------- */
 int mdf_depth_regress_fwd(const float* prob, const float* hypos, int hypos_per_pixel, float* depth, int B, int D,

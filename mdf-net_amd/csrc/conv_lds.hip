@@ -89,6 +89,9 @@ constexpr int round_s(int n) {  // smallest s >= n with s % 32 == 16
   return (s % 32 == 16) ? s : s + 16;
 }
 
+#ifndef EARLY2_MAX_REGS
+#define EARLY2_MAX_REGS 32
+#endif
 template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT>
 struct Cfg {
   static constexpr int KPL = (CIN >= 16) ? 4 : (CIN == 8 ? 2 : 1);
@@ -110,6 +113,8 @@ struct Cfg {
   // epilogue scale/shift hoisted out of the tile loop where registers allow (the 3-D and 4-n-tile kernels sit at their caps)
   static constexpr bool EPI_REG = (KD == 1) && (NT <= 2);
   static constexpr int WN = WREG ? NSTEP : 1;
+  // 2-D: issue the next tile's global loads before this tile's MFMAs when the staging registers are cheap
+  static constexpr bool EARLY2 = (KD == 1) && (NFILL * KPL <= EARLY2_MAX_REGS);
   static constexpr size_t LDS_BYTES = (size_t)RING * PLANE * sizeof(float) + 16;  // + the broadcast slot of the item id
 };
 
@@ -365,6 +370,15 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
 #ifdef MDF_STAMPS
         const unsigned long long tc0 = STAMP();
 #endif
+        // next tile's global loads in flight during this tile's MFMAs (once the weights live in registers the tile's
+        // compute no longer hides anything else, and this wait was 45 % of the small-channel layers' time)
+        vec_t pf[C::NFILL];
+        if constexpr (C::EARLY2) {
+          if (more2) {
+#pragma unroll
+            for (int k = 0; k < C::NFILL; ++k) pf[k] = load2(tid + k * 256, tb, th0, tw0);
+          }
+        }
         if (mt_live2 > 0) {
           const float* planes[1] = {lds + slot * C::PLANE + lane_lds};
           const size_t row_vox = ((size_t)cb * p.Ho + (ch0 + wave)) * p.Wo;
@@ -382,11 +396,10 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
         if (more2) {
           // next tile -> the other slot.  Every wave passed the barrier before this tile's compute, so nobody still
           // reads that slot; one barrier (after the writes) per tile.
-          // (issuing these loads before the MFMA block was measured: no gain -- the wait only moves -- and 30 more live
-          // registers cost the k5 kernels an occupancy step)
-          vec_t pf[C::NFILL];
+          if constexpr (!C::EARLY2) {
 #pragma unroll
-          for (int k = 0; k < C::NFILL; ++k) pf[k] = load2(tid + k * 256, tb, th0, tw0);
+            for (int k = 0; k < C::NFILL; ++k) pf[k] = load2(tid + k * 256, tb, th0, tw0);
+          }
 #pragma unroll
           for (int k = 0; k < C::NFILL; ++k) store2(tid + k * 256, slot ^ 1, pf[k]);
           __syncthreads();
@@ -626,5 +639,6 @@ int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha
   LDS_CASE(64, 64, 64, 1, 1, 1, 1)
   LDS_CASE(32, 32, 32, 1, 1, 1, 2) LDS_CASE(32, 32, 16, 1, 1, 1, 2) LDS_CASE(16, 16, 16, 1, 1, 1, 4)   // composed FPN heads
   LDS_CASE(4, 1, 8, 1, 3, 1, 4) LDS_CASE(8, 8, 32, 1, 3, 1, 4) LDS_CASE(8, 8, 1, 1, 3, 1, 4)
+  LDS_CASE(16, 16, 4, 1, 3, 1, 4) LDS_CASE(8, 8, 4, 1, 3, 1, 4)   // prob head as per-plane partial sums (prob_head.hip)
   return MDF_EUNSUPPORTED;
 }

@@ -165,7 +165,69 @@ __global__ __launch_bounds__(256) void prob_head_tiled_kernel(const float* __res
   if (depth) depth[(size_t)b * hw + pix] = dep.result();
 }
 
+// ---- partial-sum form -----------------------------------------------------------------------------------------
+// logit[d] = P0[d-1] + P1[d] + P2[d+1] where P_kd[z] is the 2-D (kh,kw,cin) contraction of input plane z with the kd-th
+// slice of the 3x3x3 kernel.  The three slices are the output channels of an ordinary 2-D MFMA conv over the B*D planes
+// (conv_lds_kernel<Cin,Cin,4,1,3,1,4>, 4th channel zero), so every input voxel is read once and the 27*Cin-deep
+// contraction runs on the matrix cores; this kernel is the light rest: combine, softmax over D, soft-argmin.
+// One thread per pixel; the D logits stay in registers (DMAX = 8/24/48), each partial is read once, prob written once.
+template <int DMAX>
+__global__ __launch_bounds__(256) void prob_from_partials_kernel(const float4* __restrict__ part, const float* __restrict__ hypos,
+                                                                 int per_pixel, float* __restrict__ prob, float* __restrict__ depth,
+                                                                 int B, int D, int h, int w) {
+  const size_t hw = (size_t)h * w, n = (size_t)B * hw;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = (int)(i / hw);
+  const size_t pix = i % hw;
+  const float4* pp = part + (size_t)b * D * hw + pix;
+  float lg[DMAX];
+  float carry1 = 0.f, carry0 = 0.f;   // P0[d-1] + P1[d] (awaiting P2[d+1]);  P0[d] (feeds logit[d+1])
+  float mx = -INFINITY;
+#pragma unroll
+  for (int d = 0; d < DMAX; ++d) {
+    if (d < D) {
+      const float4 v = pp[(size_t)d * hw];
+      if (d >= 1) { lg[d - 1] = carry1 + v.z; mx = fmaxf(mx, lg[d - 1]); }
+      carry1 = carry0 + v.y;
+      carry0 = v.x;
+      if (d == D - 1) { lg[d] = carry1; mx = fmaxf(mx, lg[d]); }
+    }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int d = 0; d < DMAX; ++d)
+    if (d < D) { lg[d] = expf(lg[d] - mx); sum += lg[d]; }
+  mdf::CascadeSum dep;
+  float* pr = prob + (size_t)b * D * hw + pix;
+#pragma unroll
+  for (int d = 0; d < DMAX; ++d)
+    if (d < D) {
+      const float pv = lg[d] / sum;
+      pr[(size_t)d * hw] = pv;
+      if (depth) dep.add(pv * (per_pixel ? hypos[((size_t)b * D + d) * hw + pix] : hypos[(size_t)b * D + d]));
+    }
+  if (depth) depth[(size_t)b * hw + pix] = dep.result();
+}
+
 }  // namespace
+
+extern "C" int mdf_prob_from_partials_fwd(const float* partials, const float* hypos, int hypos_per_pixel, float* prob, float* depth,
+                                          int B, int D, int h, int wd, void* stream) {
+  MDF_REQUIRE(partials && prob, "null pointer argument");
+  MDF_REQUIRE(depth == nullptr || hypos != nullptr, "depth output needs hypos");
+  MDF_REQUIRE(B > 0 && D > 0 && h > 0 && wd > 0, "bad shape");
+  MDF_REQUIRE((reinterpret_cast<uintptr_t>(partials) & 15) == 0, "partials must be 16-byte aligned");
+  const size_t n = (size_t)B * h * wd;
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  const float4* pp = reinterpret_cast<const float4*>(partials);
+  if (D <= 8) hipLaunchKernelGGL((prob_from_partials_kernel<8>), grid, block, 0, (hipStream_t)stream, pp, hypos, hypos_per_pixel, prob, depth, B, D, h, wd);
+  else if (D <= 24) hipLaunchKernelGGL((prob_from_partials_kernel<24>), grid, block, 0, (hipStream_t)stream, pp, hypos, hypos_per_pixel, prob, depth, B, D, h, wd);
+  else if (D <= 48) hipLaunchKernelGGL((prob_from_partials_kernel<48>), grid, block, 0, (hipStream_t)stream, pp, hypos, hypos_per_pixel, prob, depth, B, D, h, wd);
+  else if (D <= 96) hipLaunchKernelGGL((prob_from_partials_kernel<96>), grid, block, 0, (hipStream_t)stream, pp, hypos, hypos_per_pixel, prob, depth, B, D, h, wd);
+  else return mdf::fail(MDF_EUNSUPPORTED, "partial-sum prob head is built for D <= 96, got %d (use mdf_prob_softmax_regress_fwd)", D);
+  return mdf::check_launch("prob_from_partials_kernel");
+}
 
 extern "C" int mdf_prob_softmax_regress_fwd(const float* x, const float* w, const float* hypos, int hypos_per_pixel,
                                             float* prob, float* depth, int B, int D, int h, int wd, int Cin,

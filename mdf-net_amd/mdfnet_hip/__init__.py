@@ -40,6 +40,7 @@ SIGNATURES = {
     "mdf_conv_packed_size": (c_i64, [c_int, c_int, c_int]),
     "mdf_conv_pack_weights": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp]),
     "mdf_prob_softmax_regress_fwd": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp, c_fp] + [c_int] * 5 + [c_fp]),
+    "mdf_prob_from_partials_fwd": (c_int, [c_fp, c_fp, c_int, c_fp, c_fp] + [c_int] * 4 + [c_fp]),
     "mdf_depth_regress_fwd": (c_int, [c_fp, c_fp, c_int, c_fp] + [c_int] * 4 + [c_fp]),
     "mdf_confidence_fwd": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 4 + [c_fp]),
     "mdf_hypos_fit_fwd": (c_int, [c_int, c_fp, c_fp, c_fp, c_int, c_fp, c_fp] + [c_int] * 4 + [c_fp]),

@@ -303,8 +303,20 @@ def conv3d_ndhwc(x, wpack, cin, cout, stride=1, transposed=False, alpha=None, be
     return y
 
 
-def prob_head(x, weight, depth_hypos=None):
-    """Conv3d(Cin->1,k3,p1) + softmax over D [+ soft-argmin].  x [B,D,h,w,Cin] -> prob [B,D,h,w] (, depth)."""
+def pack_prob_weight(weight):
+    """[1,Cin,3,3,3] `prob` conv weight -> packed 2-D weight whose output channels are the three kd slices (+ one zero
+    channel), for the partial-sum route of prob_head."""
+    w = weight.detach().float()
+    w2 = torch.zeros((4, w.shape[1], 3, 3), device=w.device, dtype=torch.float32)
+    w2[:3] = w[0].permute(1, 0, 2, 3)          # [kd, cin, kh, kw]
+    return pack_conv2d_weight(w2)
+
+
+def prob_head(x, weight, depth_hypos=None, direct=False, wpack=None):
+    """Conv3d(Cin->1,k3,p1) + softmax over D [+ soft-argmin].  x [B,D,h,w,Cin] -> prob [B,D,h,w] (, depth).
+    Default route: per-plane partial sums on the MFMA conv kernel + a light combine/softmax kernel (`wpack` = cached
+    pack_prob_weight(weight), packed here when absent); `direct` (or a shape the partial-sum kernels are not built for)
+    uses the self-contained direct kernel."""
     _need_gpu(x, weight)
     b, d, h, w, c = x.shape
     prob = torch.empty((b, d, h, w), device=x.device, dtype=torch.float32)
@@ -312,6 +324,13 @@ def prob_head(x, weight, depth_hypos=None):
     if depth_hypos is not None:
         hyp, pp = _hypos_arg(depth_hypos, h, w)
         depth = torch.empty((b, h, w), device=x.device, dtype=torch.float32)
+    if not direct and c in (8, 16) and d <= 96 and x.is_contiguous():
+        part = conv2d_nhwc(x.view(b * d, h, w, c), pack_prob_weight(weight) if wpack is None else wpack, c, 4, 3, 1,
+                           useful_cout=3)
+        _abi("mdf_prob_from_partials_fwd", (part.data_ptr(), None if hyp is None else hyp.data_ptr(), pp, prob.data_ptr(),
+                                            None if depth is None else depth.data_ptr(), b, d, h, w, _stream(prob),),
+             tag=f"partials->prob {d}x{h}x{w}", work={"bytes": 4.0 * (part.numel() + prob.numel()), "bound": "hbm"})
+        return prob if depth is None else (prob, depth)
     _abi("mdf_prob_softmax_regress_fwd", (x.data_ptr(), _f32c(weight.detach()).data_ptr(),
                                              None if hyp is None else hyp.data_ptr(), pp, prob.data_ptr(),
                                              None if depth is None else depth.data_ptr(), b, d, h, w, c, _stream(prob),),
@@ -340,7 +359,7 @@ def pack_conv2d_weight(w):
 
 
 def conv2d_nhwc(x, wpack, cin, cout, ksize, stride=1, alpha=None, beta=None, relu=False, res=None, res_scale=1.0,
-                res_up=None, planar_in=False):
+                res_up=None, planar_in=False, useful_cout=None):
     """y = [res + res_scale *] ([up2(res_up) +] [relu](conv(x)*alpha + beta)).  x [B,H,W,Cin] contiguous
     (or planar [B,Cin,H,W] with planar_in=True, Cin < 4)."""
     _need_gpu(x, wpack)
@@ -357,7 +376,7 @@ def conv2d_nhwc(x, wpack, cin, cout, ksize, stride=1, alpha=None, beta=None, rel
                             ctypes.c_float(res_scale), None if res_up is None else res_up.data_ptr(), y.data_ptr(),
                             b, h, w, cin, cout, ksize, stride, int(relu), int(planar_in), _stream(y),),
          tag=f"{cin}->{cout} k{ksize}s{stride} {h}x{w}x{b}",
-         work={"flops": 2.0 * ksize * ksize * cin * cout * b * ho * wo, "bytes": 4.0 * (x.numel() + y.numel()),
+         work={"flops": 2.0 * ksize * ksize * cin * (useful_cout or cout) * b * ho * wo, "bytes": 4.0 * (x.numel() + y.numel()),
                "bound": "mfma"})
     return y
 

@@ -70,7 +70,8 @@ class RegularNet_3Scales(nn.Module):
             prob = self._stock_forward(x)
             return prob if depth_hypos is None else (prob, torch.sum(prob * depth_hypos, 1))
         with torch.no_grad():
-            return ops.prob_head(self.features(ops.to_ndhwc(x)), self.prob.weight, depth_hypos)
+            wpack = layers.cache_of(self.prob).get((self.prob.weight,), lambda: ops.pack_prob_weight(self.prob.weight))
+            return ops.prob_head(self.features(ops.to_ndhwc(x)), self.prob.weight, depth_hypos, wpack=wpack)
 
 
 class RegularNet_4Scales(nn.Module):
@@ -114,4 +115,5 @@ class RegularNet_4Scales(nn.Module):
             prob = self._stock_forward(x)
             return prob if depth_hypos is None else (prob, torch.sum(prob * depth_hypos, 1))
         with torch.no_grad():
-            return ops.prob_head(self.features(ops.to_ndhwc(x)), self.prob.weight, depth_hypos)
+            wpack = layers.cache_of(self.prob).get((self.prob.weight,), lambda: ops.pack_prob_weight(self.prob.weight))
+            return ops.prob_head(self.features(ops.to_ndhwc(x)), self.prob.weight, depth_hypos, wpack=wpack)

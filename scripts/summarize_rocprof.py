@@ -8,7 +8,7 @@ stats = glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True)[
 rows = list(csv.DictReader(open(stats)))
 os.makedirs(os.path.dirname(dst), exist_ok=True)
 shutil.copy(stats, dst + "_kernel_stats.csv")
-ours = ("conv_lds_kernel", "prob_head_tiled", "conv3d_kernel", "warp_kernel", "prob_head_kernel", "regress_kernel", "confidence_kernel", "hypos_", "pack_weights",
+ours = ("conv_lds_kernel", "prob_head_tiled", "conv3d_kernel", "warp_kernel", "prob_head_kernel", "prob_from_partials", "regress_kernel", "confidence_kernel", "hypos_", "pack_weights",
         "corner_index", "conv2d_kernel", "refine_")
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 tune = sum(float(r["TotalDurationNs"]) for r in rows if r["Name"].startswith("naive_conv"))

@@ -12,7 +12,7 @@ def family(name):
         return "mfma_conv"
     if "warp_kernel" in name:
         return "warp_aggregate"
-    if "prob_head" in name:
+    if "prob_head" in name or "prob_from_partials" in name:
         return "prob_head"
     if any(k in name for k in ("regress_kernel", "confidence_kernel", "hypos_")):
         return "heads"

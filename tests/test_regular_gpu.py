@@ -72,3 +72,22 @@ def test_train_mode_uses_stock_path_with_autograd(seeded_sd):
     assert prob.shape == (2, 16, 16, 16) and prob.requires_grad
     prob.sum().backward()
     assert x.grad is not None and model.Regular[1].prob.weight.grad is not None
+
+
+@pytest.mark.parametrize("cin,D,h,w", [(8, 8, 37, 53), (16, 48, 20, 70), (8, 24, 16, 16), (16, 3, 9, 65), (8, 1, 5, 7), (8, 60, 6, 6)])
+def test_prob_head_routes_agree_with_conv3d_softmax(cin, D, h, w):
+    """`prob` conv + softmax(D) + soft-argmin (regular.py:66-69 + regress.py:5-7): the partial-sum MFMA route and the direct
+    kernel against torch's conv3d/softmax on the CPU, ragged tiles and D = 1 / 3 / >48 included."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(cin * 1000 + D)
+    x = torch.randn(2, cin, D, h, w, generator=g)
+    wt = torch.randn(1, cin, 3, 3, 3, generator=g) * 0.3
+    hyp = torch.sort(torch.rand(2, D, h, w, generator=g) * 500 + 400, dim=1)[0]
+    ref_p = F.softmax(F.conv3d(x, wt, padding=1).squeeze(1), dim=1)
+    ref_d = (ref_p * hyp).sum(1)
+    xd = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+    for direct in (False, True):
+        p, d = ops.prob_head(xd, wt.to(DEV), hyp.to(DEV), direct=direct)
+        np.testing.assert_allclose(p.cpu().numpy(), ref_p.numpy(), rtol=2e-4, atol=1e-7, err_msg=f"direct={direct}")
+        np.testing.assert_allclose(d.cpu().numpy(), ref_d.numpy(), rtol=1e-5, err_msg=f"direct={direct}")
+        assert torch.allclose(p.sum(1), torch.ones_like(p[:, 0]), atol=1e-5)
