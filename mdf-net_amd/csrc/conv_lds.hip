@@ -547,7 +547,7 @@ int launch_lds(LdsConvParams& p, hipStream_t st) {
   const int max_grid = 256 * (blocks_per_cu > 4 ? 4 : blocks_per_cu);
   // 3-D: items = tile x depth chunk, handed out dynamically; aim for >= ~6 items per resident block (smooths the cheaper
   // partially-filled tile columns) while keeping >= 3 planes per chunk (prologue = KD-1 extra planes).
-  // 2-D: items = runs of consecutive tiles (double-buffered inside the run), ~8 runs per resident block.
+  // 2-D: one run of consecutive tiles per block (double-buffered inside the run), grid = min(tiles/2, resident blocks).
   if (KD > 1) {
     long long per_block = 6;
     if (const char* e = getenv("MDF_CONV_ITEMS_PER_BLOCK")) { if (atoi(e) > 0) per_block = atoi(e); }   // dev A/B
@@ -566,7 +566,9 @@ int launch_lds(LdsConvParams& p, hipStream_t st) {
     if (tiles > 0x7fffffff) return mdf::fail(MDF_EARG, "conv_lds: too many tiles");
     p.n_tiles = (int)tiles;
     p.tiles_per_item = 0;
-    long long g = tiles / 6;                     // >= ~6 tiles per block so the double buffer has something to overlap
+    long long tpb = 2;   // small layers: residency (4 blocks/CU) beats long runs -- 30 -> 20 us on the refine-size convs (A/B)
+    if (const char* e = getenv("MDF_CONV2D_TILES_PER_BLOCK")) { if (atoi(e) > 0) tpb = atoi(e); }   // dev A/B
+    long long g = tiles / tpb;                   // >= tpb tiles per block
     if (g < 256) g = 256;
     if (g > max_grid) g = max_grid;
     if (g > tiles) g = tiles;

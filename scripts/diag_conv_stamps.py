@@ -35,7 +35,7 @@ for name, ci, co, D, H, W in [("32->16", 32, 16, 48, 148, 200), ("16->16", 16, 1
           f"cyc/d-step compute {comp/dsteps:7.0f} refill {fill/dsteps:6.0f}, cyc/item sched {sched/items:6.0f} prologue {pro/max(items-blocks,1):6.0f}")
 
 print("2-D layers (per tile: compute = MFMA step incl. epilogue stores, refill = wait for the next tile's loads + LDS stores + barrier)")
-for name, ci, co, k, st, b, h, w in [("bb 8->8", 8, 8, 3, 1, 5, 1184, 1600), ("bb 8->16 k5s2", 8, 16, 5, 2, 5, 1184, 1600), ("bb 16->16", 16, 16, 3, 1, 5, 592, 800),
+for name, ci, co, k, st, b, h, w in [("refine 8->8", 8, 8, 3, 1, 1, 592, 800), ("refine 8->32", 8, 32, 3, 1, 1, 592, 800), ("bb 8->8", 8, 8, 3, 1, 5, 1184, 1600), ("bb 8->16 k5s2", 8, 16, 5, 2, 5, 1184, 1600), ("bb 16->16", 16, 16, 3, 1, 5, 592, 800),
                                      ("bb 32->32", 32, 32, 3, 1, 5, 296, 400), ("bb 32->64 k5s2", 32, 64, 5, 2, 5, 296, 400), ("bb 64->64", 64, 64, 3, 1, 5, 148, 200)]:
     x = torch.randn(b, h, w, ci, device=dev)
     wp = ops.pack_conv2d_weight(torch.randn(co, ci, k, k, device=dev) * 0.1)
