@@ -256,6 +256,28 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
+// w-phase packing for Cout < 16 (conv_lds.hip, Cfg::RW): the conv rewritten with GEMM row r*Cout + c = channel c of output
+// phase r (RW phases along w) and KW' = KHW + RW - 1 taps along w; tap kw' of phase r is the original tap kw' - r.
+// wp[tap' = kdh*KW' + kw'][chunk][q][n][s], one n-tile.
+__global__ void pack_weights_rw_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cin_mem, int Cout, int nkdh,
+                                       int KHW, int RW) {
+  const int KPL = (Cin >= 16) ? 4 : (Cin == 8 ? 2 : 1), CK = 4 * KPL, NCH = Cin / CK, KW = KHW + RW - 1;
+  const int total = nkdh * KW * NCH * 64 * KPL;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int r = i;
+    const int s = r % KPL; r /= KPL;
+    const int n = r % 16; r /= 16;
+    const int qq = r % 4; r /= 4;
+    const int ch = r % NCH; r /= NCH;
+    const int kwp = r % KW, kdh = r / KW;
+    const int phase = n / Cout, cout = n % Cout, cin = ch * CK + KPL * qq + s;
+    const int kw = kwp - phase;
+    float v = 0.f;
+    if (phase < RW && cin < Cin_mem && kw >= 0 && kw < KHW) v = w[((size_t)cout * Cin_mem + cin) * (nkdh * KHW) + kdh * KHW + kw];
+    wp[i] = v;
+  }
+}
+
 // ConvTranspose3d weights [Cin][Cout][3][3][3] -> wpack[tap' = (kd*3+kh)*2+ow][chunk][nt][q][n][s] with GEMM row
 // r = nt*16+n = pw*Cout + cout and kernel tap kw(pw, ow): (0,0)->1, (1,0)->2, (1,1)->0, (0,1)-> structurally zero.
 __global__ void pack_weights_tr_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout) {
@@ -305,9 +327,13 @@ int launch_conv_mt(ConvParams& p, hipStream_t st) {
 
 }  // namespace
 
+// w-phase factor of a stride-1 k3 layer (0 = none): Cout 8 -> 2 outputs per MFMA column, Cout 4 -> 4
+static int rw_of(int Cout) { return Cout == 8 ? 2 : (Cout == 4 ? 4 : 0); }
+
 extern "C" int64_t mdf_conv3d_packed_size(int Cin, int Cout) {
   if (Cin < 8 || Cout < 1) return 0;
-  const int64_t plain = (int64_t)27 * Cin * (((Cout + 15) / 16) * 16);
+  int64_t plain = (int64_t)27 * Cin * (((Cout + 15) / 16) * 16);
+  if (rw_of(Cout)) plain += (int64_t)9 * (3 + rw_of(Cout) - 1) * Cin * 16;   // + the w-phase packing behind the plain one
   const int64_t transposed = (int64_t)18 * Cin * (((2 * Cout + 15) / 16) * 16);
   return plain > transposed ? plain : transposed;   // one size serves both packings
 }
@@ -318,8 +344,12 @@ extern "C" int mdf_conv3d_pack_weights(const float* w, float* wpack, int Cin, in
   MDF_REQUIRE(Cout >= 1 && Cout <= 64, "Cout=%d out of range", Cout);
   if (transposed)
     hipLaunchKernelGGL(pack_weights_tr_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, wpack, Cin, Cout);
-  else
+  else {
     hipLaunchKernelGGL(pack_weights_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, wpack, Cin, Cin, Cout, 27, 0);
+    if (rw_of(Cout))
+      hipLaunchKernelGGL(pack_weights_rw_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, wpack + (size_t)27 * Cin * 16, Cin, Cin, Cout, 9, 3,
+                         rw_of(Cout));
+  }
   return mdf::check_launch("pack_weights_kernel");
 }
 
@@ -327,7 +357,9 @@ static int padded_cin(int c) { return c <= 4 ? 4 : c; }
 
 extern "C" int64_t mdf_conv_packed_size(int Cin_mem, int Cout, int ntaps) {
   if (Cin_mem < 1 || Cout < 1 || ntaps < 1) return 0;
-  return (int64_t)ntaps * padded_cin(Cin_mem) * (((Cout + 15) / 16) * 16);
+  int64_t n = (int64_t)ntaps * padded_cin(Cin_mem) * (((Cout + 15) / 16) * 16);
+  if (ntaps == 9 && rw_of(Cout)) n += (int64_t)3 * (3 + rw_of(Cout) - 1) * padded_cin(Cin_mem) * 16;   // + w-phase packing (3x3 layers)
+  return n;
 }
 
 extern "C" int mdf_conv_pack_weights(const float* w, float* wpack, int Cin_mem, int Cout, int ntaps, void* stream) {
@@ -336,6 +368,9 @@ extern "C" int mdf_conv_pack_weights(const float* w, float* wpack, int Cin_mem, 
   MDF_REQUIRE(Cin == 4 || Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64, "Cin=%d not supported", Cin_mem);
   MDF_REQUIRE(Cout >= 1 && Cout <= 64 && ntaps >= 1 && ntaps <= 27, "Cout=%d ntaps=%d out of range", Cout, ntaps);
   hipLaunchKernelGGL(pack_weights_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, wpack, Cin, Cin_mem, Cout, ntaps, 0);
+  if (ntaps == 9 && rw_of(Cout))
+    hipLaunchKernelGGL(pack_weights_rw_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, wpack + (size_t)9 * Cin * 16, Cin, Cin_mem, Cout, 3, 3,
+                       rw_of(Cout));
   return mdf::check_launch("pack_weights_kernel");
 }
 

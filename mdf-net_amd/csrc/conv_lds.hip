@@ -92,21 +92,32 @@ constexpr int round_s(int n) {  // smallest s >= n with s % 32 == 16
 #ifndef EARLY2_MAX_REGS
 #define EARLY2_MAX_REGS 32
 #endif
-template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT>
+// RW > 1 ("w-phase" form, for Cout < 16): an MFMA output tile has 16 rows, so a Cout = 8 (4) layer would waste half
+// (three quarters) of every MFMA.  Instead RW = 2 (4) neighbouring output voxels along w share one MFMA column: GEMM row
+// r*Cout + c is channel c of output voxel RW*m + r, which is the same conv written with stride RW, Cout' = RW*Cout and a
+// kernel of KHW + RW - 1 taps along w (tap kw' of phase r is the original tap kw' - r, zero outside) -- KW' taps serve RW
+// outputs instead of RW*KHW: 4 vs 6 (RW 2), 6 vs 12 (RW 4) MFMAs.  The expanded weights are packed by conv3d.hip.
+template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT, int RW = 1>
 struct Cfg {
+  static_assert(RW == 1 || (SHW == 1 && COUT * RW <= 16 && COUT % 4 == 0), "w-phase form: stride 1, RW*Cout <= 16, Cout % 4 == 0");
+  static constexpr int RWF = RW;
+  static constexpr int KW = KHW + RW - 1;       // taps along w
+  static constexpr int SW = SHW * RW;           // input step along w between neighbouring MFMA columns
+  static constexpr int ROWS = COUT * RW;        // GEMM rows
   static constexpr int KPL = (CIN >= 16) ? 4 : (CIN == 8 ? 2 : 1);
   static constexpr int CK = 4 * KPL;
   static constexpr int NCH = CIN / CK;
   static constexpr int NG = CIN / KPL;  // k-groups per voxel
-  static constexpr int NT = (COUT + 15) / 16;
-  static constexpr int TH = 4, TW = 16 * MT;
+  static constexpr int NT = (ROWS + 15) / 16;
+  static constexpr int TH = 4, TW = 16 * MT;   // tile: TH rows x TW MFMA columns = TW*RW output voxels along w
+  static constexpr int TWO = TW * RW;
   static constexpr int PAD = (KHW - 1) / 2, PD = (KD - 1) / 2;
-  static constexpr int PH = (TH - 1) * SHW + KHW, PW = (TW - 1) * SHW + KHW;
+  static constexpr int PH = (TH - 1) * SHW + KHW, PW = (TW - 1) * SW + KW;
   static constexpr int S = round_s(PH * PW);
   static constexpr int PLANE = CIN * S;  // floats
   static constexpr int NFILL = (NG * PH * PW + 255) / 256;
   static constexpr int RING = (KD > 1) ? KD : 2;  // 3-D: rolling window of KD planes; 2-D: double-buffered tiles
-  static constexpr int NSTEP = KD * KHW * KHW * NCH;   // MFMA pipeline steps per output row-tile (tap x cin chunk)
+  static constexpr int NSTEP = KD * KHW * KW * NCH;   // MFMA pipeline steps per output row-tile (tap x cin chunk)
   // small layers keep ALL their weight fragments in registers for the whole kernel (<= 40 VGPRs; beyond that occupancy drops and it is a loss, measured) instead of re-fetching
   // them from L1 for every tile: with 8-16 MFMAs per step there is nothing to hide that round trip behind
   static constexpr bool WREG = (KD == 1) && (NSTEP * NT * KPL <= 40);
@@ -147,10 +158,10 @@ __device__ __forceinline__ void step(const float* const (&planes)[KD], __amdgpu_
   };
   auto load_b = [&](int i, int buf) {
     const int ch = i % NCH, tap = i / NCH;
-    const int kw = tap % KHW, kh = (tap / KHW) % KHW, kd = tap / (KHW * KHW);
+    const int kw = tap % C::KW, kh = (tap / C::KW) % KHW, kd = tap / (KHW * C::KW);
 #pragma unroll
     for (int t = 0; t < MTL; ++t)
-      vec_to<KPL>(*reinterpret_cast<const vec_t*>(planes[kd] + ((ch * 4) * S + kh * PW + kw + t * 16 * SHW) * KPL), bf[buf][t]);
+      vec_to<KPL>(*reinterpret_cast<const vec_t*>(planes[kd] + ((ch * 4) * S + kh * PW + kw + t * 16 * C::SW) * KPL), bf[buf][t]);
   };
   if constexpr (!C::WREG) {
 #pragma unroll
@@ -175,11 +186,14 @@ __device__ __forceinline__ void step(const float* const (&planes)[KD], __amdgpu_
         }
     __builtin_amdgcn_sched_barrier(0);
   }
-  // epilogue: lane owns couts nt*16 + 4q .. +3 of voxel (row, w0 + t*16 + n16)
+  // epilogue: lane owns GEMM rows nt*16 + 4q .. +3 of MFMA column t*16 + n16, i.e. couts c0..c0+3 of output voxel
+  // (row, w0 + (t*16 + n16)*RW + phase)
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int c0 = nt * 16 + 4 * q;
-    if (c0 >= COUT) continue;
+    const int row0 = nt * 16 + 4 * q;
+    if (row0 >= C::ROWS) continue;
+    const int phase = (C::RWF > 1) ? row0 / COUT : 0;
+    const int c0 = (C::RWF > 1) ? row0 % COUT : row0;
     float al_l[4], be_l[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -192,7 +206,7 @@ __device__ __forceinline__ void step(const float* const (&planes)[KD], __amdgpu_
     }
 #pragma unroll
     for (int t = 0; t < MTL; ++t) {
-      const int ow = w0 + t * 16 + n16;
+      const int ow = w0 + (t * 16 + n16) * C::RWF + phase;
       if (ow >= p.Wo) continue;
       float o[4];
 #pragma unroll
@@ -240,13 +254,13 @@ __device__ __forceinline__ void step(const float* const (&planes)[KD], __amdgpu_
   }
 }
 
-template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT>
+template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT, int RW = 1>
 // Register budget: the unrolled, pipelined tap loop wants ~280 registers (one 64-bit address pair per weight tap), which
 // leaves ONE wave per SIMD.  Capping at 256 (two resident blocks per CU) is worth 6-10 % for the single-n-tile kernels
 // (A/B in one process, scripts/bench_conv3d.py); with 2+ n-tiles the cap makes hipcc spill, so those stay uncapped.
 // (Tighter caps for the 2-D kernels were tried: they spill the MFMA-heavy ones and do not help the latency-bound ones.)
 __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(const LdsConvParams p) {
-  typedef Cfg<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT> C;
+  typedef Cfg<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW> C;
   constexpr int KPL = C::KPL, NG = C::NG, S = C::S, PW = C::PW, PH = C::PH;
   typedef typename VecT<KPL>::type vec_t;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -256,7 +270,7 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
   const __amdgpu_buffer_rsrc_t wres = make_rsrc(p.wpack, (unsigned)(C::NSTEP * C::NT * 64 * KPL * 4));
   const int wvoff = lane * KPL * 4;   // bytes
   // lane-constant part of the B-fragment LDS address (floats)
-  const int lane_lds = (q * S + wave * SHW * PW + n16 * SHW) * KPL;
+  const int lane_lds = (q * S + wave * SHW * PW + n16 * C::SW) * KPL;
 
   int* item_slot = reinterpret_cast<int*>(lds + C::RING * C::PLANE);
   // per-lane constants for the whole kernel: epilogue scale/shift of the lane's 4 couts, and (small layers) all weights
@@ -265,9 +279,10 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
   for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int c = nt * 16 + 4 * q + k;
-      al[nt][k] = (C::EPI_REG && c < COUT && p.alpha) ? p.alpha[c] : 1.f;
-      be[nt][k] = (C::EPI_REG && c < COUT && p.beta) ? p.beta[c] : 0.f;
+      const int row = nt * 16 + 4 * q + k;
+      const int c = (RW > 1) ? row % COUT : row;
+      al[nt][k] = (C::EPI_REG && row < C::ROWS && p.alpha) ? p.alpha[c] : 1.f;
+      be[nt][k] = (C::EPI_REG && row < C::ROWS && p.beta) ? p.beta[c] : 0.f;
     }
   float wr[C::WN][C::NT][KPL];
   if constexpr (C::WREG) {
@@ -316,7 +331,7 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
         const int rest = tl / p.tiles_w;
         tb = rest / p.tiles_h;
         th0 = (rest % p.tiles_h) * C::TH;
-        tw0 = twi * C::TW;
+        tw0 = twi * C::TWO;
       };
       // fill mapping as in the 3-D path: cin-group fastest, so consecutive lanes read consecutive 16-B pieces (coalesced)
       constexpr int GF2 = (NG < 4) ? NG : 4;
@@ -362,7 +377,7 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
       for (int tl = t_begin; tl < t_end; ++tl) {
         const int slot = (tl - t_begin) & 1;
         const bool row_live2 = (th0 + wave) < p.Ho;
-        const int cols2 = min(p.Wo - tw0, C::TW);
+        const int cols2 = (min(p.Wo - tw0, C::TWO) + RW - 1) / RW;   // live MFMA columns
         const int mt_live2 = row_live2 ? (cols2 + 15) / 16 : 0;
         const int cb = tb, ch0 = th0, cw0 = tw0;           // this tile's origin; (tb,th0,tw0) move on to the next one
         const bool more2 = tl + 1 < t_end;
@@ -415,11 +430,11 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
     const int tw = r % p.tiles_w; r /= p.tiles_w;
     const int th = r % p.tiles_h;
     const int b = r / p.tiles_h;
-    const int h0 = th * C::TH, w0 = tw * C::TW;           // output tile origin
+    const int h0 = th * C::TH, w0 = tw * C::TWO;          // output tile origin
     const int ih0 = h0 * SHW - C::PAD, iw0 = w0 * SHW - C::PAD;  // input tile origin
     const int d0 = dc * p.dch, d1 = min(d0 + p.dch, p.D);
     const bool row_live = (h0 + wave) < p.Ho;
-    const int cols = min(p.Wo - w0, C::TW);
+    const int cols = (min(p.Wo - w0, C::TWO) + RW - 1) / RW;   // live MFMA columns
     const int mt_live = row_live ? (cols + 15) / 16 : 0;  // wave-uniform
 
     // ---- plane fill helpers -------------------------------------------------------------------------
@@ -537,11 +552,11 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
   }
 }
 
-template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT>
+template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT, int RW = 1>
 int launch_lds(LdsConvParams& p, hipStream_t st) {
-  typedef Cfg<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT> C;
+  typedef Cfg<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW> C;
   p.tiles_h = (p.Ho + C::TH - 1) / C::TH;
-  p.tiles_w = (p.Wo + C::TW - 1) / C::TW;
+  p.tiles_w = (p.Wo + C::TWO - 1) / C::TWO;
   const long long tiles = (long long)p.B * p.tiles_h * p.tiles_w;
   const int blocks_per_cu = (int)(160 * 1024 / C::LDS_BYTES) < 1 ? 1 : (int)(160 * 1024 / C::LDS_BYTES);
   const int max_grid = 256 * (blocks_per_cu > 4 ? 4 : blocks_per_cu);
@@ -577,7 +592,7 @@ int launch_lds(LdsConvParams& p, hipStream_t st) {
   }
   static bool attr_done = false;  // benign race: the call is idempotent
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
     if (e != hipSuccess) return mdf::fail(MDF_EHIP, "hipFuncSetAttribute(dynamic LDS %zu): %s", C::LDS_BYTES, hipGetErrorString(e));
     attr_done = true;
@@ -587,13 +602,13 @@ int launch_lds(LdsConvParams& p, hipStream_t st) {
   if (grid > p.n_items) grid = p.n_items;
   if (getenv("MDF_CONV_DEBUG")) {
     int nb = -1;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT>, 256, C::LDS_BYTES);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW>, 256, C::LDS_BYTES);
     hipFuncAttributes fa{};
-    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT>));
-    fprintf(stderr, "[conv_lds<%d,%d,%d,%d,%d,%d,%d>] LDS %zu B dyn + %zu static, regs %d, occupancy API: %d blocks/CU (%s), grid %d, items %d\n",
-            CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, C::LDS_BYTES, fa.sharedSizeBytes, fa.numRegs, nb, hipGetErrorString(e), grid, p.n_items);
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW>));
+    fprintf(stderr, "[conv_lds<%d,%d,%d,%d,%d,%d,%d,rw%d>] LDS %zu B dyn + %zu static, regs %d, occupancy API: %d blocks/CU (%s), grid %d, items %d\n",
+            CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW, C::LDS_BYTES, fa.sharedSizeBytes, fa.numRegs, nb, hipGetErrorString(e), grid, p.n_items);
   }
-  hipLaunchKernelGGL((conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT>), dim3(grid), dim3(256), C::LDS_BYTES, st, p);
+  hipLaunchKernelGGL((conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW>), dim3(grid), dim3(256), C::LDS_BYTES, st, p);
   return mdf::check_launch("conv_lds_kernel");
 }
 
@@ -617,9 +632,17 @@ extern "C" int mdf_debug_read_stamps(unsigned long long* out8, int reset) {
   if (Cin == ci && Cin_mem == cim && Cout == co && KD == kd && KHW == k && stride == s)          \
     return launch_lds<ci, cim, co, kd, k, s, mt>(p, (hipStream_t)stream);
 
+// w-phase variants read the expanded packing that conv3d.hip appends after the plain one (mdf_conv_rw_of / pack functions)
+#define LDS_CASE_RW(ci, cim, co, kd, k, s, mt, rw)                                               \
+  if (use_rw && Cin == ci && Cin_mem == cim && Cout == co && KD == kd && KHW == k && stride == s && !res_up) { \
+    p.wpack = wpack + (size_t)kd * k * k * ci * 16;                                              \
+    return launch_lds<ci, cim, co, kd, k, s, mt, rw>(p, (hipStream_t)stream);                    \
+  }
+
 int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
                           float res_scale, const float* res_up, float* y, int B, int D, int H, int W, int Cin, int Cin_mem, int Cout, int KD,
                           int KHW, int stride, int relu, void* stream, int planar_in) {
+  static const bool use_rw = [] { const char* e = getenv("MDF_CONV_RW"); return e ? atoi(e) != 0 : true; }();   // dev A/B
   LdsConvParams p{};
   p.x = x; p.wpack = wpack; p.alpha = alpha; p.beta = beta; p.res = res; p.res_scale = res_scale; p.res_up = res_up; p.y = y;
   p.B = B; p.D = D; p.H = H; p.W = W; p.relu = relu; p.planar_in = planar_in;
@@ -630,6 +653,9 @@ int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha
   const int pad = (KHW - 1) / 2;
   p.Ho = (H + 2 * pad - KHW) / stride + 1;
   p.Wo = (W + 2 * pad - KHW) / stride + 1;
+  // Cout < 16: w-phase form (RW output voxels per MFMA column)
+  LDS_CASE_RW(16, 16, 8, 3, 3, 1, 2, 2) LDS_CASE_RW(8, 8, 8, 3, 3, 1, 2, 2)
+  LDS_CASE_RW(16, 16, 4, 1, 3, 1, 1, 4) LDS_CASE_RW(8, 8, 4, 1, 3, 1, 1, 4)
   // 3-D regulariser layers (stride 1)
   LDS_CASE(32, 32, 16, 3, 3, 1, 2) LDS_CASE(16, 16, 16, 3, 3, 1, 4) LDS_CASE(16, 16, 8, 3, 3, 1, 4) LDS_CASE(8, 8, 8, 3, 3, 1, 4)
   LDS_CASE(32, 32, 32, 3, 3, 1, 2)

@@ -14,11 +14,12 @@ DEV = "cuda:0"
 # (cin, cout, k, stride) = every 2-D layer shape of FPN_4Scales and RefineNet2
 COMBOS = [(3, 8, 3, 1), (8, 8, 3, 1), (8, 16, 5, 2), (16, 16, 3, 1), (16, 32, 5, 2), (32, 32, 3, 1), (32, 64, 5, 2),
           (64, 64, 3, 1), (64, 64, 1, 1), (32, 64, 1, 1), (64, 32, 1, 1), (16, 64, 1, 1), (64, 16, 1, 1),
-          (1, 8, 3, 1), (8, 32, 3, 1), (8, 1, 3, 1)]
+          (1, 8, 3, 1), (8, 32, 3, 1), (8, 1, 3, 1),
+          (16, 4, 3, 1), (8, 4, 3, 1)]       # prob-head partial sums: 4 outputs along w per MFMA column (w-phase form)
 
 
 @pytest.mark.parametrize("cin,cout,k,stride", COMBOS)
-@pytest.mark.parametrize("shape", [(1, 8, 16), (2, 13, 37), (1, 40, 136)])
+@pytest.mark.parametrize("shape", [(1, 8, 16), (2, 13, 37), (1, 40, 136), (3, 9, 131)])
 def test_conv2d_layer(cin, cout, k, stride, shape):
     b, h, w = shape
     rng = np.random.RandomState(cin * 7 + cout * 3 + k + h)

@@ -44,6 +44,29 @@ def test_conv3d_layer(cin, cout, mode, shape):
     np.testing.assert_allclose(ops.from_ndhwc(y2).cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("cin,cout", [(32, 16), (16, 16), (32, 32), (16, 8), (8, 8)])
+@pytest.mark.parametrize("shape", [(1, 6, 130, 201), (2, 5, 125, 131), (1, 3, 260, 197)])
+def test_conv3d_layer_lds_kernels(cin, cout, shape):
+    """Volumes of >= 150 000 voxels take the LDS-staged kernels (conv_lds.hip; Cout = 8 in the w-phase form): ragged tiles
+    in h and w (odd widths exercise the half-filled last w-phase pair), D not a multiple of the depth chunk, batch 2."""
+    b, d, h, w = shape
+    assert b * d * h * w >= 150000
+    g = torch.Generator().manual_seed(cin * 100 + cout + w)
+    x = torch.randn(b, cin, d, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, 3, generator=g) / np.sqrt(27 * cin)
+    alpha = torch.rand(cout, generator=g) + 0.5
+    beta = torch.rand(cout, generator=g) * 0.4 - 0.2
+    ref = F.conv3d(x, wt, None, 1, 1)
+    res = torch.randn(ref.shape, generator=g)
+    exp = F.relu(ref * alpha.view(1, -1, 1, 1, 1) + beta.view(1, -1, 1, 1, 1)) + res
+    wp = ops.pack_conv3d_weight(wt.to(DEV), False)
+    xd = ops.to_ndhwc(x.to(DEV))
+    y = ops.conv3d_ndhwc(xd, wp, cin, cout, 1, False, alpha.to(DEV), beta.to(DEV), True, ops.to_ndhwc(res.to(DEV)))
+    np.testing.assert_allclose(ops.from_ndhwc(y).cpu().numpy(), exp.numpy(), rtol=1e-4, atol=2e-5)
+    y2 = ops.conv3d_ndhwc(xd, wp, cin, cout, 1, False)
+    np.testing.assert_allclose(ops.from_ndhwc(y2).cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
+
+
 @pytest.mark.parametrize("stage", [0, 1, 2])
 def test_regulariser_vs_reference_golden(golden, seeded_sd, stage):
     g = golden("ops.npz")
