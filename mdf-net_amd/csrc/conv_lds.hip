@@ -656,6 +656,7 @@ int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha
   // Cout < 16: w-phase form (RW output voxels per MFMA column)
   LDS_CASE_RW(16, 16, 8, 3, 3, 1, 2, 2) LDS_CASE_RW(8, 8, 8, 3, 3, 1, 2, 2)
   LDS_CASE_RW(16, 16, 4, 1, 3, 1, 1, 4) LDS_CASE_RW(8, 8, 4, 1, 3, 1, 1, 4)
+  LDS_CASE_RW(8, 8, 8, 1, 3, 1, 2, 2) LDS_CASE_RW(4, 3, 8, 1, 3, 1, 2, 2) LDS_CASE_RW(4, 1, 8, 1, 3, 1, 2, 2)   // also the HBM-bound ones: 64-B stores, half the LDS reads
   // 3-D regulariser layers (stride 1)
   LDS_CASE(32, 32, 16, 3, 3, 1, 2) LDS_CASE(16, 16, 16, 3, 3, 1, 4) LDS_CASE(16, 16, 8, 3, 3, 1, 4) LDS_CASE(8, 8, 8, 3, 3, 1, 4)
   LDS_CASE(32, 32, 32, 3, 3, 1, 2)
