@@ -376,19 +376,20 @@ extern "C" int mdf_conv_pack_weights(const float* w, float* wpack, int Cin_mem, 
 
 int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
                           float res_scale, const float* res_up, float* y, int B, int D, int H, int W, int Cin, int Cin_mem, int Cout, int KD,
-                          int KHW, int stride, int relu, void* stream, int planar_in);
+                          int KHW, int stride, int relu, void* stream, int planar_in, int shuffle2);
 
 extern "C" int mdf_conv2d_fwd(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
                               float res_scale, const float* res_up, float* y, int B, int H, int W, int Cin_mem, int Cout, int ksize, int stride,
-                              int relu, int planar_in, void* stream) {
+                              int relu, int planar_in, int pixel_shuffle2, void* stream) {
   MDF_REQUIRE(x && wpack && y, "null pointer argument");
   MDF_REQUIRE(B > 0 && H > 0 && W > 0, "bad shape");
   MDF_REQUIRE((long long)B * H * W * Cin_mem < (1ll << 31), "input too large for 32-bit offsets");
   MDF_REQUIRE(res_up == nullptr || (stride == 1 && H % 2 == 0 && W % 2 == 0 && Cout % 4 == 0),
               "res_up needs stride 1, even H and W, Cout %% 4 == 0");
   MDF_REQUIRE(!planar_in || Cin_mem < 4, "planar (NCHW) input is supported for Cin < 4 only (the image layer)");
+  MDF_REQUIRE(!pixel_shuffle2 || (Cout == 32 && stride == 1 && !res && !res_up), "pixel_shuffle2 output is built for Cout = 32, stride 1, no residual");
   const int rc = mdf_conv_lds_dispatch(x, wpack, alpha, beta, res, res_scale, res_up, y, B, 1, H, W, padded_cin(Cin_mem), Cin_mem, Cout, 1,
-                                       ksize, stride, relu, stream, planar_in);
+                                       ksize, stride, relu, stream, planar_in, pixel_shuffle2);
   if (rc == MDF_EUNSUPPORTED)
     return mdf::fail(MDF_EUNSUPPORTED, "conv2d Cin=%d Cout=%d k=%d stride=%d is not built", Cin_mem, Cout, ksize, stride);
   return rc;
@@ -419,7 +420,7 @@ extern "C" int mdf_conv3d_fwd(const float* x, const float* wpack, const float* a
     return e ? atoll(e) : 150000LL;
   }();
   if (m == kS1 && p.m_total >= lds_min) {  // large stride-1 layers: LDS-staged planes (conv_lds.hip)
-    const int rc = mdf_conv_lds_dispatch(x, wpack, alpha, beta, res, 1.0f, nullptr, y, B, Di, Hi, Wi, Cin, Cin, Cout, 3, 3, 1, relu, stream, 0);
+    const int rc = mdf_conv_lds_dispatch(x, wpack, alpha, beta, res, 1.0f, nullptr, y, B, Di, Hi, Wi, Cin, Cin, Cout, 3, 3, 1, relu, stream, 0, 0);
     if (rc != MDF_EUNSUPPORTED) return rc;
   }
   // stride 1 (every Cin x Cout the nets use)

@@ -34,6 +34,7 @@ struct LdsConvParams {
   int n_items;
   int n_tiles, tiles_per_item;         // 2-D: an item is a run of consecutive tiles
   int planar_in;                       // 2-D, CIN_MEM != CIN: input is planar [B,CIN_MEM,H,W] (e.g. the RGB images as they arrive)
+  int shuffle2;                        // 2-D, Cout = 32: write PixelShuffle(2) of the result ([B,2Ho,2Wo,8]); rows packed sub-pixel-major
   int prefetch_early;                  // 3-D: issue the next plane's loads before (1) or after (0) the MFMA block
 };
 
@@ -214,7 +215,13 @@ __device__ __forceinline__ void step(const float* const (&planes)[KD], __amdgpu_
         o[k] = acc[t][nt][k] * al_l[k] + be_l[k];
         if (p.relu) o[k] = fmaxf(o[k], 0.f);
       }
-      const size_t oi = (row_vox + ow) * COUT + c0;
+      size_t oi = (row_vox + ow) * COUT + c0;
+      if constexpr (COUT == 32 && KD == 1 && C::RWF == 1) {
+        if (p.shuffle2) {   // GEMM row = sub*8 + oc (sub = dy*2+dx): the lane's 4 rows are 4 channels of output pixel (2h+dy, 2w+dx)
+          const int sub = c0 >> 3, oc0 = c0 & 7;
+          oi = ((2 * (row_vox / p.Wo) + (sub >> 1)) * (size_t)(2 * p.Wo) + 2 * ow + (sub & 1)) * 8 + oc0;
+        }
+      }
       if (COUT % 4 == 0) {
         if (p.res_up) {  // + F.interpolate(top, scale_factor=2, bilinear, align_corners=False)[row, ow]   (backbone.py:60,62)
           const int Hh = p.Ho >> 1, Wh = p.Wo >> 1;
@@ -641,11 +648,11 @@ extern "C" int mdf_debug_read_stamps(unsigned long long* out8, int reset) {
 
 int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
                           float res_scale, const float* res_up, float* y, int B, int D, int H, int W, int Cin, int Cin_mem, int Cout, int KD,
-                          int KHW, int stride, int relu, void* stream, int planar_in) {
+                          int KHW, int stride, int relu, void* stream, int planar_in, int shuffle2) {
   static const bool use_rw = [] { const char* e = getenv("MDF_CONV_RW"); return e ? atoi(e) != 0 : true; }();   // dev A/B
   LdsConvParams p{};
   p.x = x; p.wpack = wpack; p.alpha = alpha; p.beta = beta; p.res = res; p.res_scale = res_scale; p.res_up = res_up; p.y = y;
-  p.B = B; p.D = D; p.H = H; p.W = W; p.relu = relu; p.planar_in = planar_in;
+  p.B = B; p.D = D; p.H = H; p.W = W; p.relu = relu; p.planar_in = planar_in; p.shuffle2 = shuffle2;
   {
     const char* e = getenv("MDF_CONV_PREFETCH_EARLY");   // A/B switch (dev): default = after the MFMA block
     p.prefetch_early = e ? atoi(e) : 0;

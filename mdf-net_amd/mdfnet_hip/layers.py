@@ -62,13 +62,14 @@ def use_hip(mod, *tensors):
     return True
 
 
-def conv2d_layer(conv, bn, x, relu=False, res=None, res_scale=1.0, res_up=None, planar_in=False):
-    """Conv2d [+ BatchNorm2d eval] [+ ReLU] [+ residual / upsample-add] as one kernel.  x, res: [B,H,W,C] NHWC."""
+def conv2d_layer(conv, bn, x, relu=False, res=None, res_scale=1.0, res_up=None, planar_in=False, pixel_shuffle2=False):
+    """Conv2d [+ BatchNorm2d eval] [+ ReLU] [+ residual / upsample-add] [+ PixelShuffle(2)] as one kernel.  x, res: [B,H,W,C] NHWC."""
+    assert not (pixel_shuffle2 and (bn is not None or conv.bias is not None))
     k = conv.kernel_size[0]
     tensors = [conv.weight, conv.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
 
     def build():
-        wp = ops.pack_conv2d_weight(conv.weight)
+        wp = ops.pack_conv2d_weight(ops.shuffle2_rows(conv.weight) if pixel_shuffle2 else conv.weight)
         if bn is not None:
             alpha, beta = ops.fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
             if conv.bias is not None:
@@ -78,4 +79,4 @@ def conv2d_layer(conv, bn, x, relu=False, res=None, res_scale=1.0, res_up=None, 
 
     wp, alpha, beta = cache_of(conv).get(tensors, build)
     return ops.conv2d_nhwc(x, wp, conv.in_channels, conv.out_channels, k, conv.stride[0], alpha, beta, relu, res, res_scale, res_up,
-                           planar_in)
+                           planar_in, pixel_shuffle2=pixel_shuffle2)

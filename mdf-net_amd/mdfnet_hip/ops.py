@@ -359,9 +359,10 @@ def pack_conv2d_weight(w):
 
 
 def conv2d_nhwc(x, wpack, cin, cout, ksize, stride=1, alpha=None, beta=None, relu=False, res=None, res_scale=1.0,
-                res_up=None, planar_in=False, useful_cout=None):
+                res_up=None, planar_in=False, useful_cout=None, pixel_shuffle2=False):
     """y = [res + res_scale *] ([up2(res_up) +] [relu](conv(x)*alpha + beta)).  x [B,H,W,Cin] contiguous
-    (or planar [B,Cin,H,W] with planar_in=True, Cin < 4)."""
+    (or planar [B,Cin,H,W] with planar_in=True, Cin < 4).  pixel_shuffle2: y = PixelShuffle(2)(conv(x)) as [B,2Ho,2Wo,Cout/4]
+    (Cout = 32; wpack from pack_conv2d_weight(shuffle2_rows(weight)))."""
     _need_gpu(x, wpack)
     if planar_in:
         b, c, h, w = x.shape
@@ -370,15 +371,22 @@ def conv2d_nhwc(x, wpack, cin, cout, ksize, stride=1, alpha=None, beta=None, rel
     assert c == cin and x.is_contiguous()
     pad = (ksize - 1) // 2
     ho, wo = (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
-    y = torch.empty((b, ho, wo, cout), device=x.device, dtype=torch.float32)
+    y = torch.empty((b, 2 * ho, 2 * wo, cout // 4) if pixel_shuffle2 else (b, ho, wo, cout), device=x.device, dtype=torch.float32)
     _abi("mdf_conv2d_fwd", (x.data_ptr(), wpack.data_ptr(), None if alpha is None else alpha.data_ptr(),
                             None if beta is None else beta.data_ptr(), None if res is None else res.data_ptr(),
                             ctypes.c_float(res_scale), None if res_up is None else res_up.data_ptr(), y.data_ptr(),
-                            b, h, w, cin, cout, ksize, stride, int(relu), int(planar_in), _stream(y),),
+                            b, h, w, cin, cout, ksize, stride, int(relu), int(planar_in), int(pixel_shuffle2), _stream(y),),
          tag=f"{cin}->{cout} k{ksize}s{stride} {h}x{w}x{b}",
          work={"flops": 2.0 * ksize * ksize * cin * (useful_cout or cout) * b * ho * wo, "bytes": 4.0 * (x.numel() + y.numel()),
                "bound": "mfma"})
     return y
+
+
+def shuffle2_rows(weight):
+    """Reorder the output channels of a Conv2d that feeds nn.PixelShuffle(2): torch channel oc*4 + sub -> row sub*Cq + oc
+    (Cq = Cout/4), the order mdf_conv2d_fwd(pixel_shuffle2=1) expects."""
+    co = weight.shape[0]
+    return weight.detach().reshape(co // 4, 4, *weight.shape[1:]).transpose(0, 1).reshape(weight.shape).contiguous()
 
 
 def to_nhwc(t):

@@ -32,8 +32,7 @@ class RefineNet2(nn.Module):
                     t = layers.conv2d_layer(blk.conv[0], None, y, relu=True)
                     y = layers.conv2d_layer(blk.conv[2], None, t, res=y, res_scale=0.1)
                 y = layers.conv2d_layer(self.conv1, None, y, res=x0)                               # x0 + conv1(y)
-                y = layers.conv2d_layer(self.conv2[0], None, y)                                    # [B,h,w,32]
-                y = torch.nn.functional.pixel_shuffle(y.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).contiguous()
+                y = layers.conv2d_layer(self.conv2[0], None, y, pixel_shuffle2=True)               # conv + PixelShuffle(2): [B,2h,2w,8]
                 y = layers.conv2d_layer(self.conv2[2], None, y)                                    # [B,2h,2w,1]
                 return (lo + y.permute(0, 3, 1, 2) * span).squeeze(1)
         x0 = self.conv0((depth.detach().unsqueeze(1) - lo) / span)

@@ -66,3 +66,17 @@ def test_backbone_and_refine_vs_reference_golden(golden, seeded_sd):
         np.testing.assert_allclose(a.cpu().numpy(), g[k], rtol=1e-4, atol=2e-5)
         assert a.permute(0, 2, 3, 1).is_contiguous()        # NHWC memory for the aggregation kernel
     np.testing.assert_allclose(r.cpu().numpy(), g["refine_out"], rtol=0, atol=2e-3)   # mm; fp32 ulp at 600 = 6e-5, gain ~4
+
+
+@pytest.mark.parametrize("shape", [(1, 9, 21), (2, 16, 70)])
+def test_conv_with_fused_pixel_shuffle(shape):
+    """refine.py:18-19: Conv2d(8 -> 32) followed by nn.PixelShuffle(2), written directly as [B,2H,2W,8] by the conv epilogue."""
+    b, h, w = shape
+    g = torch.Generator().manual_seed(h * w)
+    x = torch.randn(b, 8, h, w, generator=g)
+    wt = torch.randn(32, 8, 3, 3, generator=g) * 0.2
+    exp = F.pixel_shuffle(F.conv2d(x, wt, None, 1, 1), 2)                      # [B,8,2h,2w]
+    wp = ops.pack_conv2d_weight(ops.shuffle2_rows(wt.to(DEV)))
+    y = ops.conv2d_nhwc(ops.to_nhwc(x.to(DEV)), wp, 8, 32, 3, 1, pixel_shuffle2=True)
+    assert y.shape == (b, 2 * h, 2 * w, 8)
+    np.testing.assert_allclose(y.permute(0, 3, 1, 2).cpu().numpy(), exp.numpy(), rtol=1e-4, atol=2e-5)
