@@ -150,11 +150,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); the product path has no CPU fallback")
+    # rehearsal knobs for a 1-GPU box (never set by the driver): several ranks on one card, gloo instead of RCCL
+    backend = os.environ.get("MDF_BENCH_DIST_BACKEND", "nccl")
+    if os.environ.get("MDF_BENCH_SHARE_GPU"):
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     from mdfnet_hip import synth
 
     model = build(dev)
@@ -181,7 +188,7 @@ def main():
         dt = time.perf_counter() - t0
     assert torch.isfinite(out["depth"]).all()
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -230,6 +237,7 @@ def main():
             rec["cpu_baseline"] = cpu
         print(json.dumps(rec), flush=True)
     if world > 1:
+        barrier()                      # rank 0's profile pass is over: leave together
         dist.destroy_process_group()
 
 

@@ -67,6 +67,29 @@ def test_conv3d_layer_lds_kernels(cin, cout, shape):
     np.testing.assert_allclose(ops.from_ndhwc(y2).cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("cin,cout", [(32, 16), (16, 8), (64, 32)])
+@pytest.mark.parametrize("shape", [(1, 6, 130, 201), (2, 4, 101, 187)])
+def test_conv_transpose3d_layer_lds_kernel(cin, cout, shape):
+    """ConvTranspose3d(k3,s2,p1,op1)+BN+ReLU+skip on >= 150 000 input voxels: the LDS-staged 8-parity-class form
+    (conv_lds.hip step_tr); ragged tiles, odd widths, D not a multiple of the depth chunk, batch 2."""
+    b, d, h, w = shape
+    assert b * d * h * w >= 150000
+    g = torch.Generator().manual_seed(cin + cout + w)
+    x = torch.randn(b, cin, d, h, w, generator=g)
+    wt = torch.randn(cin, cout, 3, 3, 3, generator=g) / np.sqrt(27 * cin / 8)
+    alpha = torch.rand(cout, generator=g) + 0.5
+    beta = torch.rand(cout, generator=g) * 0.4 - 0.2
+    ref = F.conv_transpose3d(x, wt, None, 2, 1, 1)
+    res = torch.randn(ref.shape, generator=g)
+    exp = F.relu(ref * alpha.view(1, -1, 1, 1, 1) + beta.view(1, -1, 1, 1, 1)) + res
+    wp = ops.pack_conv3d_weight(wt.to(DEV), True)
+    xd = ops.to_ndhwc(x.to(DEV))
+    y = ops.conv3d_ndhwc(xd, wp, cin, cout, 2, True, alpha.to(DEV), beta.to(DEV), True, ops.to_ndhwc(res.to(DEV)))
+    np.testing.assert_allclose(ops.from_ndhwc(y).cpu().numpy(), exp.numpy(), rtol=1e-4, atol=2e-5)
+    y2 = ops.conv3d_ndhwc(xd, wp, cin, cout, 2, True)
+    np.testing.assert_allclose(ops.from_ndhwc(y2).cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
+
+
 @pytest.mark.parametrize("stage", [0, 1, 2])
 def test_regulariser_vs_reference_golden(golden, seeded_sd, stage):
     g = golden("ops.npz")
