@@ -55,8 +55,14 @@ class CoreNet(torch.nn.Module):
             ref_proj, src_projs = self.scale(intrinsics, extrinsics, stage)
             hypos = make_hypos(depth, depth_range, prob, hypos, upsample=True)
             cost = aggregate(feats, ref_proj, src_projs, hypos)
-            prob = regular(cost)
-            depth = self.Depth_regress(prob, hypos)
+            if (not self.training and getattr(regular, "fused_regress", False)
+                    and getattr(self.Depth_regress, "mdf_builtin", False)):
+                # both slots are the built-in ones: the soft-argmin (core.py:64) rides in the regulariser's softmax kernel
+                # (same arithmetic as the standalone slot, asserted equal in tests/test_regular_gpu.py)
+                prob, depth = regular(cost, hypos)
+            else:
+                prob = regular(cost)
+                depth = self.Depth_regress(prob, hypos)
             depths.append(depth)
         depth = self.Refine(depth, depth_range)
         depths.append(depth)

@@ -9,6 +9,9 @@ def depth_regression(prob_volume, depth_hypos):
     return ops.depth_regress(prob_volume, depth_hypos)
 
 
+depth_regression.mdf_builtin = True   # lets CoreNet fuse it into the regulariser's last kernel
+
+
 def confidence_regress(prob_volume, last_confidence=None, n=4, pad=(0, 0, 0, 0, 1, 2)):
     """regress.py:9-25: sum of the 4 probabilities around trunc(E[d]).  Only the configuration the model
     uses (n=4, pad=(1,2) on D, no last_confidence) is built."""

@@ -64,6 +64,8 @@ class RegularNet_3Scales(nn.Module):
         x = x + self.conv10(x1)
         return F.softmax(self.prob(x).squeeze(1), dim=1)
 
+    fused_regress = True   # forward(cost, hypos) also returns the soft-argmin depth
+
     def forward(self, x: torch.Tensor, depth_hypos=None):
         """cost [B,C,D,H,W] -> prob [B,D,H,W]; with depth_hypos also returns the soft-argmin depth."""
         if not layers.use_hip(self, x):
@@ -109,6 +111,8 @@ class RegularNet_4Scales(nn.Module):
         x2 = x2 + self.trconv32(x3)
         x1 = x1 + self.trconv21(x2)
         return F.softmax(self.prob(x1).squeeze(1), dim=1)
+
+    fused_regress = True   # forward(cost, hypos) also returns the soft-argmin depth
 
     def forward(self, x: torch.Tensor, depth_hypos=None):
         if not layers.use_hip(self, x):

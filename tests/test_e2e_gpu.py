@@ -65,7 +65,7 @@ def test_stagewise_vs_reference_trace(golden, model, seeded_sd):
     hooks = []
     for st in range(3):
         hooks.append(model.Homoaggre[st].register_forward_hook(lambda m, i, o, st=st: tr.__setitem__(f"cost{st}", o)))
-        hooks.append(model.Regular[st].register_forward_hook(lambda m, i, o, st=st: tr.__setitem__(f"prob{st}", o)))
+        hooks.append(model.Regular[st].register_forward_hook(lambda m, i, o, st=st: tr.__setitem__(f"prob{st}", o[0] if isinstance(o, tuple) else o)))   # (prob, depth) when fused
         hooks.append(model.Depth_hypos[st].register_forward_hook(lambda m, i, o, st=st: tr.__setitem__(f"hypos{st}", o)))
     with torch.no_grad():
         model(imgs.to(DEV), extr.to(DEV), intr.to(DEV), dr.to(DEV))

@@ -103,6 +103,8 @@ def test_regulariser_vs_reference_golden(golden, seeded_sd, stage):
     np.testing.assert_allclose(depth.cpu().numpy(), g[f"reg{stage}_depth"], rtol=0, atol=5e-3)
     prob2 = model.Regular[stage](cost)
     assert torch.equal(prob2, prob)
+    # the fused soft-argmin (what CoreNet uses when both slots are built-in) == the standalone Regress slot on the same prob
+    assert torch.equal(model.Depth_regress(prob, hyp), depth)
     # standalone regress slot on the golden prob
     d2 = model.Depth_regress(T(g[f"reg{stage}_prob"]).to(DEV), hyp)
     np.testing.assert_allclose(d2.cpu().numpy(), g[f"reg{stage}_depth"], rtol=0, atol=3e-4)
