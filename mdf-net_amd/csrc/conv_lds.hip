@@ -13,6 +13,7 @@
 // the lane groups of ds_read_b128 (and the two halves of ds_read_b64) fall on disjoint banks for every tap shift.
 // GEMM orientation and weight packing are those of conv3d.hip:  D[cout][voxel] = W[cout][k] * X[k][voxel].
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 #include "common.h"
 
@@ -35,6 +36,7 @@ struct LdsConvParams {
   int n_items;
   int n_tiles, tiles_per_item;         // 2-D: an item is a run of consecutive tiles
   int planar_in;                       // 2-D, CIN_MEM != CIN: input is planar [B,CIN_MEM,H,W] (e.g. the RGB images as they arrive)
+  int sched_slot;                      // which pair of g_sched words this launch uses (one per stream)
   int shuffle2;                        // 2-D, Cout = 32: write PixelShuffle(2) of the result ([B,2Ho,2Wo,8]); rows packed sub-pixel-major
   int prefetch_early;                  // 3-D: issue the next plane's loads before (1) or after (0) the MFMA block
 };
@@ -76,10 +78,11 @@ template <> __device__ __forceinline__ float4 vec_zero<4>() { return make_float4
 template <> __device__ __forceinline__ float2 vec_zero<2>() { return make_float2(0.f, 0.f); }
 template <> __device__ __forceinline__ float vec_zero<1>() { return 0.f; }
 
-// Dynamic work distribution: [0] next item, [1] finished blocks.  Module-level device words (nothing is allocated);
-// the last block of a launch resets both, so every launch starts from zero.  Launches of conv_lds_kernel must not
-// overlap on different streams of one device (the product issues everything on one stream).
-__device__ unsigned g_sched[2];
+// Dynamic work distribution: per stream slot [0] next item, [1] finished blocks.  Module-level device words (nothing is
+// allocated); the last block of a launch resets both, so every launch starts from zero.  Launches on DIFFERENT streams
+// may overlap (two items in flight): each stream gets its own slot (host table below, kSchedSlots streams per process).
+constexpr int kSchedSlots = 128;   // > torch's per-device stream pool (2 x 32 + default)
+__device__ unsigned g_sched[2 * kSchedSlots];
 #ifdef MDF_STAMPS
 // diagnostic build only (scripts/diag_conv_stamps.sh): cycles spent by wave 0 of every block in each phase
 __device__ unsigned long long g_stamps[8];   // sched, prologue, compute, refill, total, blocks, items, dsteps
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
       if (pass > 0) break;
     } else {
       __syncthreads();  // previous item's readers are done with the ring (and with item_slot)
-      if (tid == 0) *item_slot = (int)atomicAdd(&g_sched[0], 1u);
+      if (tid == 0) *item_slot = (int)atomicAdd(&g_sched[2 * p.sched_slot], 1u);
       __syncthreads();
       item = *item_slot;
       if (item >= p.n_items) break;
@@ -681,10 +684,10 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
   }
 #endif
   if (KD > 1 && tid == 0) {
-    const unsigned done = atomicAdd(&g_sched[1], 1u);
+    const unsigned done = atomicAdd(&g_sched[2 * p.sched_slot + 1], 1u);
     if (done == gridDim.x - 1) {  // last block out: re-arm the counters for the next launch
-      g_sched[0] = 0u;
-      g_sched[1] = 0u;
+      g_sched[2 * p.sched_slot] = 0u;
+      g_sched[2 * p.sched_slot + 1] = 0u;
       __threadfence();
     }
   }
@@ -770,6 +773,18 @@ extern "C" int mdf_debug_read_stamps(unsigned long long* out8, int reset) {
   if (Cin == ci && Cin_mem == cim && Cout == co && KD == kd && KHW == k && stride == s)          \
     return launch_lds<ci, cim, co, kd, k, s, mt>(p, (hipStream_t)stream);
 
+// stream -> scheduler slot (launches on one stream are ordered, so they can share a slot; different streams must not)
+static int sched_slot_of(void* stream) {
+  static std::mutex mu;
+  static void* known[kSchedSlots];
+  static int n_known = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  for (int i = 0; i < n_known; ++i)
+    if (known[i] == stream) return i;
+  if (n_known < kSchedSlots) { known[n_known] = stream; return n_known++; }
+  return -1;
+}
+
 // w-phase variants read the expanded packing that conv3d.hip appends after the plain one (mdf_conv_rw_of / pack functions)
 #define LDS_CASE_RW(ci, cim, co, kd, k, s, mt, rw)                                               \
   if (use_rw && Cin == ci && Cin_mem == cim && Cout == co && KD == kd && KHW == k && stride == s && !res_up) { \
@@ -784,6 +799,8 @@ int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha
   LdsConvParams p{};
   p.x = x; p.wpack = wpack; p.alpha = alpha; p.beta = beta; p.res = res; p.res_scale = res_scale; p.res_up = res_up; p.y = y;
   p.B = B; p.D = D; p.H = H; p.W = W; p.relu = relu; p.planar_in = planar_in; p.shuffle2 = shuffle2;
+  p.sched_slot = sched_slot_of(stream);
+  if (p.sched_slot < 0) return mdf::fail(MDF_EUNSUPPORTED, "conv kernels support up to %d distinct HIP streams per process", kSchedSlots);
   {
     const char* e = getenv("MDF_CONV_PREFETCH_EARLY");   // A/B switch (dev): default = after the MFMA block
     p.prefetch_early = e ? atoi(e) : 0;

@@ -1,7 +1,8 @@
 """Evaluation driver (counterpart of the reference's eval.py:10-89): same CLI (-p/-d/-s), same outputs
 (<out>/<scan>/depth_est/%08d.pfm|.png, <out>/<scan>/confidence/%08d.pfm), same per-item print line — plus:
-one process per GPU with the item list sharded over ranks (`torchrun --nproc-per-node N eval.py ...`), a device
-synchronise before reading the clock (the reference's timing has none), and no collective on the data path."""
+one process per GPU with the item list sharded over ranks (`torchrun --nproc-per-node N eval.py ...`), two items in flight
+on two HIP streams (the printed per-item time is the interval between completions), the cross-item feature cache, and no
+collective on the data path."""
 import argparse
 import logging
 import os
@@ -27,48 +28,55 @@ class FeatureCache(dict):
         super().__setitem__(k, v)
 
 
-def run_eval(model, dataset, device, output_path, rank=0, world=1, nworks=1, log=print, cache_features=True):
+def run_eval(model, dataset, device, output_path, rank=0, world=1, nworks=1, log=print, cache_features=True, in_flight=2):
     """Shard `dataset` over ranks, run `model` item by item, write PFM/PNG.  Returns (n_items_this_rank, seconds).
     With cache_features (and a model that accepts it) every image goes through the feature pyramid once per scan instead
-    of once per item it appears in; outputs are identical."""
+    of once per item it appears in.  in_flight > 1 issues items round-robin on that many HIP streams
+    (mdfnet_hip/pipeline.py): the next item fills the idle tails of the current one and the PFM writes overlap with GPU
+    work.  Outputs are identical either way."""
+    from mdfnet_hip.pipeline import InFlight
     idx = shard.shard_items(len(dataset), rank, world)
     loader = DataLoader(Subset(dataset, idx), batch_size=1, num_workers=nworks, shuffle=False,
                         pin_memory=(device.type == "cuda"), drop_last=False)
     model.eval()
-    busy = 0.0
     import inspect
     cache = FeatureCache() if (cache_features and "feature_cache" in inspect.signature(model.forward).parameters) else None
+    state = {"last": time.time(), "n": 0}
+
+    def finished(tag, out):
+        it, data = tag
+        now = time.time()
+        dt, state["last"] = now - state["last"], now
+        state["n"] += 1
+        mem = torch.cuda.max_memory_allocated(device) / (1024 ** 2) if device.type == "cuda" else 0.0
+        log("batch: " + str(it + 1) + "/" + str(len(loader)) + " time: {:.3f}".format(dt) + " memory: " + str(mem) + "MB")
+        for name, depth, conf in zip(data["filename"], out["depth"], out["confidence"]):
+            dfile = os.path.join(output_path, name.format("depth_est", ".pfm"))
+            cfile = os.path.join(output_path, name.format("confidence", ".pfm"))
+            os.makedirs(os.path.dirname(dfile), exist_ok=True)
+            os.makedirs(os.path.dirname(cfile), exist_ok=True)
+            save_pfm(dfile, depth.cpu().numpy())
+            write_depth_img(os.path.join(output_path, name.format("depth_est", ".png")), depth.cpu().numpy())
+            save_pfm(cfile, conf.cpu().numpy())
+            logging.info("save depth file in: " + dfile)
+
+    pipe = InFlight(device, in_flight if device.type == "cuda" else 1, done=finished)
+    t_begin = time.time()
     with torch.no_grad():
         for it, data in enumerate(loader):
             batch = {k: v.to(device, non_blocking=True) for k, v in data.items() if isinstance(v, torch.Tensor)}
             if device.type == "cuda":   # the loader's CPU tensors ARE the host mirrors: no device->host hop later
                 for k in ("extrinsics", "intrinsics", "depth_range"):
                     hostmirror.put(batch[k], data[k])
-            if device.type == "cuda":
-                torch.cuda.synchronize(device)
-            t0 = time.time()
             if cache is not None and "view_ids" in data and batch["imgs"].shape[0] == 1:
                 keys = [(data["scan"][0], int(v)) for v in data["view_ids"][0]]
-                out = model(batch["imgs"], batch["extrinsics"], batch["intrinsics"], batch["depth_range"],
-                            feature_cache=cache, view_keys=keys)
+                fn = lambda b=batch, k=keys: model(b["imgs"], b["extrinsics"], b["intrinsics"], b["depth_range"],
+                                                   feature_cache=cache, view_keys=k)
             else:
-                out = model(batch["imgs"], batch["extrinsics"], batch["intrinsics"], batch["depth_range"])
-            if device.type == "cuda":
-                torch.cuda.synchronize(device)
-            dt = time.time() - t0
-            busy += dt
-            mem = torch.cuda.max_memory_allocated(device) / (1024 ** 2) if device.type == "cuda" else 0.0
-            log("batch: " + str(it + 1) + "/" + str(len(loader)) + " time: {:.3f}".format(dt) + " memory: " + str(mem) + "MB")
-            for name, depth, conf in zip(data["filename"], out["depth"], out["confidence"]):
-                dfile = os.path.join(output_path, name.format("depth_est", ".pfm"))
-                cfile = os.path.join(output_path, name.format("confidence", ".pfm"))
-                os.makedirs(os.path.dirname(dfile), exist_ok=True)
-                os.makedirs(os.path.dirname(cfile), exist_ok=True)
-                save_pfm(dfile, depth.cpu().numpy())
-                write_depth_img(os.path.join(output_path, name.format("depth_est", ".png")), depth.cpu().numpy())
-                save_pfm(cfile, conf.cpu().numpy())
-                logging.info("save depth file in: " + dfile)
-    return len(idx), busy
+                fn = lambda b=batch: model(b["imgs"], b["extrinsics"], b["intrinsics"], b["depth_range"])
+            pipe.submit(fn, tag=(it, data), keep=batch)
+        pipe.drain()
+    return len(idx), time.time() - t_begin
 
 
 def main():

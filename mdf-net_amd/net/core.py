@@ -28,9 +28,19 @@ class CoreNet(torch.nn.Module):
             missing = [v for v in range(nv) if view_keys[v] not in feature_cache]
             if missing:
                 f = self.Backbone(imgs[0, missing])                      # only the images not seen yet, batched
+                ev = torch.cuda.Event()
+                ev.record()                                              # on the stream that produced them
                 for j, v in enumerate(missing):
-                    feature_cache[view_keys[v]] = tuple(lv[j:j + 1] for lv in f)
-            return [feature_cache[view_keys[v]] for v in range(nv)]
+                    feature_cache[view_keys[v]] = (tuple(lv[j:j + 1] for lv in f), ev)
+            cur = torch.cuda.current_stream(imgs.device)
+            out = []
+            for v in range(nv):
+                pyr, ev = feature_cache[view_keys[v]]
+                cur.wait_event(ev)                                       # another item in flight may have produced it
+                for t in pyr:
+                    t.record_stream(cur)
+                out.append(pyr)
+            return out
         if getattr(self.Backbone, "batch_views", False) and not self.training:
             # eval BatchNorm is per-sample: one batched pass over the B*V images == V separate calls (core.py:42)
             f = self.Backbone(imgs.reshape(nb * nv, *imgs.shape[2:]))

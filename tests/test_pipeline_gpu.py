@@ -78,3 +78,28 @@ def test_feature_cache_gives_identical_results_and_fewer_backbone_calls(tmp_path
         a, _ = data_io.read_pfm(os.path.join(str(tmp_path / "a"), "scan1", "depth_est", "%08d.pfm" % v))
         b, _ = data_io.read_pfm(os.path.join(str(tmp_path / "b"), "scan1", "depth_est", "%08d.pfm" % v))
         assert np.array_equal(a, b)
+
+
+def test_items_in_flight_on_several_streams_give_identical_results(seeded_sd):
+    """mdfnet_hip/pipeline.py: independent items issued round-robin on 3 HIP streams (different scenes, so a mix-up would
+    show) return exactly what the one-at-a-time run returns; 320x256x5 so the stage-2 regulariser takes the LDS kernels
+    with their per-stream work-item counters."""
+    from mdfnet_hip import hostmirror, synth
+    from mdfnet_hip.pipeline import InFlight
+    m = build_model()
+    m.load_state_dict(seeded_sd)
+    dev = torch.device("cuda", 0)
+    m.eval().to(dev)
+    scenes = [tuple(t.to(dev) for t in synth.make_scene(320, 256, 5, rot_deg=2.0, seed=40 + i)) for i in range(4)]
+    with torch.no_grad():
+        ref = [m(*s) for s in scenes]
+        torch.cuda.synchronize()
+        got = {}
+        pipe = InFlight(dev, 3, done=lambda tag, out: got.__setitem__(tag, out))
+        for rep in range(3):
+            for i, s in enumerate(scenes):
+                pipe.submit(lambda s=s: m(s[0], s[1].clone(), s[2].clone(), s[3].clone()), tag=(rep, i))
+        pipe.drain()
+    assert len(got) == 12
+    for (rep, i), out in got.items():
+        assert torch.equal(out["depth"], ref[i]["depth"]) and torch.equal(out["confidence"], ref[i]["confidence"]), (rep, i)
