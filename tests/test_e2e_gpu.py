@@ -101,3 +101,25 @@ def test_other_configurations_same_host_parity(model, seeded_sd, w, h, v, b, rng
     assert np.isfinite(out["depth"].cpu().numpy()).all()
     # BASELINE's 1e-3 mm is quoted at DTU scale (span 510 mm): scale the bar with the depth range
     assert err.mean() <= 1e-3 * span / 510.0
+
+
+def test_full_size_cfg2_parity_vs_live_oracle(model, seeded_sd):
+    """BASELINE config 2 at its full size (1600x1184, 5 views, hypotheses 48/24/8): the product against the oracle run live on
+    this host's CPU (explicit-arithmetic warp, host-independent), the metric's own bar mean |d depth| <= 1e-3 mm; plus
+    run-to-run determinism."""
+    import time
+    imgs, extr, intr, dr = synth.make_scene(1600, 1184, 5, rot_deg=3.0, seed=100)
+    with torch.no_grad():
+        out = model(imgs.to(DEV), extr.to(DEV), intr.to(DEV), dr.to(DEV))
+        out2 = model(imgs.to(DEV), extr.to(DEV), intr.to(DEV), dr.to(DEV))
+    assert torch.equal(out["depth"], out2["depth"]) and torch.equal(out["confidence"], out2["confidence"])
+    t0 = time.time()
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    live = O.core_forward(seeded_sd, imgs, extr, intr, dr, warp=O.homo_warping_explicit)
+    err = np.abs(out["depth"].cpu().numpy() - live["depth"].numpy())
+    cerr = np.abs(out["confidence"].cpu().numpy() - live["confidence"].numpy())
+    print(f"\ncfg2 full size: mean|d depth| {err.mean():.3e} mm, max {err.max():.3e}, p99.9 {np.quantile(err, 0.999):.3e}; "
+          f"confidence mean|d| {cerr.mean():.3e}; oracle took {time.time() - t0:.1f} s")
+    assert out["depth"].shape == (1, 1184, 1600) and np.isfinite(err).all()
+    assert err.mean() <= 1e-3
+    assert cerr.mean() <= 1e-4
