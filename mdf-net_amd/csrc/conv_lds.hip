@@ -470,7 +470,12 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
       };
       // fill mapping as in the 3-D path: cin-group fastest, so consecutive lanes read consecutive 16-B pieces (coalesced)
       constexpr int GF2 = (NG < 4) ? NG : 4;
-      auto split2 = [](int idx, int& v, int& g) {
+      auto split2 = [&](int idx, int& v, int& g) {
+        if (CIN_MEM != CIN && p.planar_in) {   // NCHW image planes: pixel fastest (consecutive lanes = consecutive floats of a plane)
+          g = idx / (PH * PW);
+          v = idx - g * (PH * PW);
+          return;
+        }
         const int glo = idx % GF2, r = idx / GF2;
         v = r % (PH * PW);
         g = (r / (PH * PW)) * GF2 + glo;
