@@ -11,7 +11,7 @@ inputs = tuple(t.to(dev) for t in synth.make_scene(bench.WIDTH, bench.HEIGHT, be
 with torch.no_grad():
     for _ in range(3): ref = model(*inputs)
     torch.cuda.synchronize()
-    for n in (1, 2, 3, 1, 2):
+    for n in (1, 2, 3, 4):
         streams = [torch.cuda.Stream() for _ in range(n)]
         for s in streams: s.wait_stream(torch.cuda.current_stream())
         outs = []
