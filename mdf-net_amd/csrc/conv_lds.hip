@@ -710,13 +710,16 @@ int launch_lds(LdsConvParams& p, hipStream_t st) {
   // partially-filled tile columns) while keeping >= 3 planes per chunk (prologue = KD-1 extra planes).
   // 2-D: one run of consecutive tiles per block (double-buffered inside the run), grid = min(tiles/2, resident blocks).
   if (KD > 1) {
-    long long per_block = 6;
-    if (const char* e = getenv("MDF_CONV_ITEMS_PER_BLOCK")) { if (atoi(e) > 0) per_block = atoi(e); }   // dev A/B
-    long long want = (per_block * max_grid + tiles - 1) / tiles;
+    // Depth-chunk length: ~6 items per resident block (the dynamic queue then evens out the cheaper, partially filled tile
+    // columns), at least 3 planes per chunk (an item's prologue fetches KD-1 extra planes), chunks of equal length -- a
+    // 1-plane tail chunk (D = 4 -> 3 + 1) costs a whole prologue for a third of the work: 93 -> 77 us on 16->16 @4x296x400.
+    // (A makespan model "rounds x (chunk + prologue)" was tried and is wrong here: two resident blocks share one MFMA pipe,
+    // so fewer, longer items do not finish sooner.)
+    long long want = (6LL * max_grid + tiles - 1) / tiles;
     if (want < 1) want = 1;
-    int dch = (int)(p.D / want);
-    if (dch < 3) dch = 3;
-    if (dch > p.D) dch = p.D;
+    if (want > p.D / 3) want = p.D / 3;
+    if (want < 1) want = 1;
+    int dch = (int)((p.D + want - 1) / want);
     p.dch = dch;
     p.dchunks = (p.D + dch - 1) / dch;
     const long long items = tiles * p.dchunks;
