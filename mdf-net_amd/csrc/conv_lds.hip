@@ -653,12 +653,13 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
             case 1: step_tr<C, COUT, 1>(planes, wres, wvoff, p, b, d, h0 + wave, w0, q, n16); break;
             default: if (MT >= 2) step_tr<C, COUT, (MT >= 2 ? 2 : 1)>(planes, wres, wvoff, p, b, d, h0 + wave, w0, q, n16); break;
           }
-        } else
-        switch (mt_live) {
-          case 1: step<C, KD, KHW, SHW, COUT, 1>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be); break;
-          case 2: if (MT >= 2) step<C, KD, KHW, SHW, COUT, (MT >= 2 ? 2 : 1)>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be); break;
-          case 3: if (MT >= 3) step<C, KD, KHW, SHW, COUT, (MT >= 3 ? 3 : 1)>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be); break;
-          default: step<C, KD, KHW, SHW, COUT, MT>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be); break;
+        } else {
+          switch (mt_live) {
+            case 1: step<C, KD, KHW, SHW, COUT, 1>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be); break;
+            case 2: if (MT >= 2) step<C, KD, KHW, SHW, COUT, (MT >= 2 ? 2 : 1)>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be); break;
+            case 3: if (MT >= 3) step<C, KD, KHW, SHW, COUT, (MT >= 3 ? 3 : 1)>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be); break;
+            default: step<C, KD, KHW, SHW, COUT, MT>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be); break;
+          }
         }
       }
 #ifdef MDF_STAMPS
