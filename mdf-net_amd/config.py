@@ -45,7 +45,7 @@ class Args:
 class _TrainBase(Args):
     def __init__(self, batch_size, nworks):
         self.nviews, self.robust = 5, True
-        self.start_epoch, self.max_epoch = 1, 30
+        self.start_epoch, self.max_epoch = 1, int(os.environ.get("MDF_MAX_EPOCH", "30"))
         self.batch_size, self.nworks = batch_size, nworks
         self.lr, self.factor = 1e-3, 0.9
         self.pth_path = os.environ.get("MDF_PTH_PATH", "pth")

@@ -22,3 +22,12 @@ def get_cam_path(dataset_path, scan_folder, view_id, mode):
     if mode == "blendedmvs":
         return os.path.join(dataset_path, "{}/cams/{:0>8}_cam.txt".format(scan_folder, view_id))
     return None
+
+
+def get_depth_path(dataset_path, scan_folder, view_id, mode):
+    """Ground-truth depth maps (load/getpath.py:34-45)."""
+    if mode == "train":
+        return os.path.join(dataset_path, "Depths", scan_folder, "depth_map_{:0>4}.pfm".format(view_id))
+    if mode == "blendedmvs":
+        return os.path.join(dataset_path, "{}/rendered_depth_maps/{:0>8}.pfm".format(scan_folder, view_id))
+    return None

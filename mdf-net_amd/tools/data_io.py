@@ -71,6 +71,18 @@ def read_cam_file(filename, with_range=False):
     return intrinsic, extrinsic
 
 
+def resize_nearest(img, size):
+    """cv2.resize(img, (w, h), interpolation=cv2.INTER_NEAREST) without OpenCV (absent here; used by load/dtutrain.py:55-57
+    and load/blendedtrain.py:48-50 for the 1/8, 1/4, 1/2 ground-truth maps).  OpenCV's nearest neighbour is NOT
+    centre-aligned: source index = min(floor(dst_index * (src/dst)), src - 1) with the ratio in double precision
+    (resize.cpp, resizeNN).  For the power-of-two factors the loaders use on divisible sizes this is plain striding."""
+    w, h = int(size[0]), int(size[1])
+    sh, sw = img.shape[:2]
+    ys = np.minimum(np.floor(np.arange(h, dtype=np.float64) * (sh / h)).astype(np.int64), sh - 1)
+    xs = np.minimum(np.floor(np.arange(w, dtype=np.float64) * (sw / w)).astype(np.int64), sw - 1)
+    return np.ascontiguousarray(img[ys][:, xs])
+
+
 def read_img(filename):
     from PIL import Image
     return np.array(Image.open(filename), dtype=np.float32) / 255.0
