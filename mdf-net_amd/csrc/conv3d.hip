@@ -278,6 +278,34 @@ __global__ void pack_weights_rw_kernel(const float* __restrict__ w, float* __res
   }
 }
 
+// Winograd F(2x2,3x3) weights for conv_lds.hip step_wino: U[kd][a][b] = G g[kd] G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1];
+// fragments in the order the kernel walks them: [kd][chunk][ab = a*4+b][nt][lane = q*16+m][s], cout = nt*16+m, cin = chunk*16+4q+s.
+__global__ void pack_weights_wino_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout) {
+  const int NCH = Cin / 16, NT = (Cout + 15) / 16;
+  const int total = 3 * NCH * 16 * NT * 64 * 4;
+  const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int r = i;
+    const int s = r % 4; r /= 4;
+    const int m = r % 16; r /= 16;
+    const int qq = r % 4; r /= 4;
+    const int nt = r % NT; r /= NT;
+    const int ab = r % 16; r /= 16;
+    const int ch = r % NCH; r /= NCH;
+    const int kd = r;
+    const int a = ab >> 2, b = ab & 3;
+    const int cout = nt * 16 + m, cin = ch * 16 + 4 * qq + s;
+    float v = 0.f;
+    if (cout < Cout) {
+      const float* g = w + (((size_t)cout * Cin + cin) * 3 + kd) * 9;
+      for (int y = 0; y < 3; ++y)
+        for (int x = 0; x < 3; ++x) v += G[a][y] * G[b][x] * g[y * 3 + x];
+    }
+    wp[i] = v;
+  }
+}
+static bool wino_built(int Cin, int Cout) { return Cout == 16 && (Cin == 16 || Cin == 32); }
+
 // ConvTranspose3d weights [Cin][Cout][3][3][3] -> wpack[tap' = (kd*3+kh)*2+ow][chunk][nt][q][n][s] with GEMM row
 // r = nt*16+n = pw*Cout + cout and kernel tap kw(pw, ow): (0,0)->1, (1,0)->2, (1,1)->0, (0,1)-> structurally zero.
 __global__ void pack_weights_tr_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout) {
@@ -370,6 +398,7 @@ extern "C" int64_t mdf_conv3d_packed_size(int Cin, int Cout) {
   if (Cin < 8 || Cout < 1) return 0;
   int64_t plain = (int64_t)27 * Cin * (((Cout + 15) / 16) * 16);
   if (rw_of(Cout)) plain += (int64_t)9 * (3 + rw_of(Cout) - 1) * Cin * 16;   // + the w-phase packing behind the plain one
+  if (wino_built(Cin, Cout)) plain += (int64_t)48 * Cin * (((Cout + 15) / 16) * 16);   // + the Winograd-domain weights
   const int64_t transposed = (int64_t)18 * Cin * (((2 * Cout + 15) / 16) * 16)      // v1 form
                              + (int64_t)27 * Cin * (((Cout + 15) / 16) * 16);      // + LDS-staged 8-class form behind it
   return plain > transposed ? plain : transposed;   // one size serves both packings
@@ -388,6 +417,9 @@ extern "C" int mdf_conv3d_pack_weights(const float* w, float* wpack, int Cin, in
     if (rw_of(Cout))
       hipLaunchKernelGGL(pack_weights_rw_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, wpack + (size_t)27 * Cin * 16, Cin, Cin, Cout, 9, 3,
                          rw_of(Cout));
+    if (wino_built(Cin, Cout))
+      hipLaunchKernelGGL(pack_weights_wino_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w,
+                         wpack + (size_t)27 * Cin * (((Cout + 15) / 16) * 16) + (rw_of(Cout) ? (size_t)36 * Cin * 16 : 0), Cin, Cout);
   }
   return mdf::check_launch("pack_weights_kernel");
 }

@@ -102,29 +102,39 @@ constexpr int round_s(int n) {  // smallest s >= n with s % 32 == 16
 // r*Cout + c is channel c of output voxel RW*m + r, which is the same conv written with stride RW, Cout' = RW*Cout and a
 // kernel of KHW + RW - 1 taps along w (tap kw' of phase r is the original tap kw' - r, zero outside) -- KW' taps serve RW
 // outputs instead of RW*KHW: 4 vs 6 (RW 2), 6 vs 12 (RW 4) MFMAs.  The expanded weights are packed by conv3d.hip.
-template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT, int RW = 1>
+//
+// WG = 1 (Winograd form, 3-D stride-1 3x3x3 layers): F(2x2, 3x3) in (h, w), direct in d.  An MFMA column is a 2x2 output
+// tile; per input plane and 16-cin chunk a lane reads its tile's 4x4 patch from LDS, transforms it (B^T d B, 32 adds per
+// channel), and feeds 16 transform-domain GEMMs (one accumulator each); the output transform A^T M A runs in the epilogue.
+// 16 x 3 instead of 9 x 4 x 3 MFMAs per 4 outputs: 2.25x fewer.  fp32 Winograd F(2,3) costs no accuracy here: single-layer
+// error vs fp64 1.1e-6 (direct 1.8e-6), end-to-end depth deviation 3.9-4.4e-4 mm = the floor of any fp32 re-ordering
+// (scripts/study_winograd.py).  Geometry: RW = 2 supplies the w bookkeeping (4-wide patch, stride 2); a wave owns 2 rows.
+template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT, int RW = 1, int WG = 0>
 struct Cfg {
-  static_assert(RW == 1 || (SHW == 1 && COUT * RW <= 16 && COUT % 4 == 0), "w-phase form: stride 1, RW*Cout <= 16, Cout % 4 == 0");
+  static_assert(RW == 1 || WG == 1 || (SHW == 1 && COUT * RW <= 16 && COUT % 4 == 0), "w-phase form: stride 1, RW*Cout <= 16, Cout % 4 == 0");
+  static_assert(WG == 0 || (KD == 3 && KHW == 3 && SHW == 1 && RW == 2 && MT == 1 && CIN % 16 == 0 && COUT % 4 == 0), "Winograd form: 3x3x3 stride 1, RW = 2, MT = 1");
+  static constexpr bool WINO = (WG == 1);
   static constexpr int RWF = RW;
   static constexpr int KW = KHW + RW - 1;       // taps along w
   static constexpr int SW = SHW * RW;           // input step along w between neighbouring MFMA columns
-  static constexpr int ROWS = COUT * RW;        // GEMM rows
+  static constexpr int ROWS = WINO ? COUT : COUT * RW;        // GEMM rows
   static constexpr int KPL = (CIN >= 16) ? 4 : (CIN == 8 ? 2 : 1);
   static constexpr int CK = 4 * KPL;
   static constexpr int NCH = CIN / CK;
   static constexpr int NG = CIN / KPL;  // k-groups per voxel
   static constexpr int NT = (ROWS + 15) / 16;
-  static constexpr int TH = 4, TW = 16 * MT;   // tile: TH rows x TW MFMA columns = TW*RW output voxels along w
+  static constexpr int WROWS = WINO ? 2 : 1;    // output rows per wave
+  static constexpr int TH = 4 * WROWS, TW = 16 * MT;   // tile: TH rows x TW MFMA columns = TW*RW output voxels along w
   static constexpr int TWO = TW * RW;
   static constexpr int PAD = (KHW - 1) / 2, PD = (KD - 1) / 2;
-  static constexpr int PH = (TH - 1) * SHW + KHW, PW = (TW - 1) * SW + KW;
+  static constexpr int PH = WINO ? TH + 2 : (TH - 1) * SHW + KHW, PW = (TW - 1) * SW + KW;
   static constexpr int S = round_s(PH * PW);
   static constexpr int PLANE = CIN * S;  // floats
   static constexpr int NFILL = (NG * PH * PW + 255) / 256;
   static constexpr int RING = (KD > 1) ? KD : 2;  // 3-D: rolling window of KD planes; 2-D: double-buffered tiles
   // KD = KHW = 2 marks the transposed form (ConvTranspose3d k3 s2 p1 op1 as 2x2x2 input taps -> 8 output parities, step_tr)
   static constexpr bool TR = (KD == 2 && KHW == 2);
-  static constexpr int NSTEP = TR ? 27 * NCH : KD * KHW * KW * NCH;   // MFMA pipeline steps per output row-tile (tap x cin chunk)
+  static constexpr int NSTEP = WINO ? 48 * NCH : (TR ? 27 * NCH : KD * KHW * KW * NCH);   // MFMA pipeline steps per output row-tile (tap x cin chunk)
   // small layers keep ALL their weight fragments in registers for the whole kernel (<= 40 VGPRs; beyond that occupancy drops and it is a loss, measured) instead of re-fetching
   // them from L1 for every tile: with 8-16 MFMAs per step there is nothing to hide that round trip behind
   static constexpr bool WREG = (KD == 1) && (NSTEP * NT * KPL <= 40);
@@ -389,13 +399,126 @@ __device__ __forceinline__ void step_tr(const float* const (&planes)[2], __amdgp
   }
 }
 
-template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT, int RW = 1>
+// ---- Winograd form (Cfg::WINO) ---------------------------------------------------------------------------------
+// Weight fragments (pack_weights_wino_kernel, conv3d.hip): [kd][chunk][ab = a*4+b][nt][lane][4], U = G g_kd G^T.
+template <typename C, int COUT>
+__device__ __forceinline__ void step_wino(const float* const (&planes)[3], __amdgpu_buffer_rsrc_t wres, int wvoff, const LdsConvParams& p,
+                                          int b, int d, int h, int w0, int q, int n16) {
+  constexpr int NCH = C::NCH, NT = C::NT, S = C::S, PW = C::PW;
+  f32x4 acc[16][NT];
+#pragma unroll
+  for (int ab = 0; ab < 16; ++ab)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[ab][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int NF = 3 * NCH * 16;          // (kd, chunk, ab) steps
+  constexpr int AHEAD = 2, NA = 3;
+  float af[NA][NT][4];
+  auto load_a = [&](int i, int buf) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) buf_load_to<4>(wres, wvoff, (i * NT + nt) * (64 * 4 * 4), af[buf][nt]);
+  };
+#pragma unroll
+  for (int i = 0; i < AHEAD; ++i) load_a(i, i % NA);
+  static_for<0, 3 * NCH>([&](auto gc) {
+    constexpr int g = decltype(gc)::value;
+    constexpr int kd = g / NCH, ch = g % NCH;
+    // this lane's 4x4 input patch (rows 2*tile_row .. +3, cols 2*tile_col .. +3) x its 4 cins
+    float v[16][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 t = *reinterpret_cast<const float4*>(planes[kd] + ((ch * 4) * S + i * PW + j) * 4);
+        v[i * 4 + j][0] = t.x; v[i * 4 + j][1] = t.y; v[i * 4 + j][2] = t.z; v[i * 4 + j][3] = t.w;
+      }
+    // V = B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: rows (h) then columns (w), in place
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d0 = v[j][c], d1 = v[4 + j][c], d2 = v[8 + j][c], d3 = v[12 + j][c];
+        v[j][c] = d0 - d2; v[4 + j][c] = d1 + d2; v[8 + j][c] = d2 - d1; v[12 + j][c] = d1 - d3;
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const float e0 = v[a * 4][c], e1 = v[a * 4 + 1][c], e2 = v[a * 4 + 2][c], e3 = v[a * 4 + 3][c];
+        v[a * 4][c] = e0 - e2; v[a * 4 + 1][c] = e1 + e2; v[a * 4 + 2][c] = e2 - e1; v[a * 4 + 3][c] = e1 - e3;
+      }
+    }
+    static_for<0, 16>([&](auto abc) {
+      constexpr int ab = decltype(abc)::value;
+      constexpr int i = g * 16 + ab;
+      if constexpr (i + AHEAD < NF) load_a(i + AHEAD, (i + AHEAD) % NA);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[ab][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i % NA][nt][sidx], v[ab][sidx], acc[ab][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  });
+  // epilogue: Y = A^T M A per cout, A^T = [1 1 1 0; 0 1 -1 -1]; outputs (h + pr, w0 + 2*n16 + r)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int c0 = nt * 16 + 4 * q;
+    if (c0 >= COUT) continue;
+    float y[2][2][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float srow[2][4];
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const float m0 = acc[bb][nt][k], m1 = acc[4 + bb][nt][k], m2 = acc[8 + bb][nt][k], m3 = acc[12 + bb][nt][k];
+        srow[0][bb] = m0 + m1 + m2;
+        srow[1][bb] = m1 - m2 - m3;
+      }
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        y[pr][0][k] = srow[pr][0] + srow[pr][1] + srow[pr][2];
+        y[pr][1][k] = srow[pr][1] - srow[pr][2] - srow[pr][3];
+      }
+    }
+    float al_l[4], be_l[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      al_l[k] = (c0 + k < COUT && p.alpha) ? p.alpha[c0 + k] : 1.f;
+      be_l[k] = (c0 + k < COUT && p.beta) ? p.beta[c0 + k] : 0.f;
+    }
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      if (h + pr >= p.Ho) continue;
+      const size_t row_vox = (((size_t)b * p.D + d) * p.Ho + (h + pr)) * p.Wo;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int ow = w0 + 2 * n16 + r;
+        if (ow >= p.Wo) continue;
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          o[k] = y[pr][r][k] * al_l[k] + be_l[k];
+          if (p.relu) o[k] = fmaxf(o[k], 0.f);
+        }
+        const size_t oi = (row_vox + ow) * COUT + c0;
+        if (p.res) {
+          const float4 rr = *reinterpret_cast<const float4*>(p.res + oi);
+          o[0] = rr.x + o[0] * p.res_scale; o[1] = rr.y + o[1] * p.res_scale;
+          o[2] = rr.z + o[2] * p.res_scale; o[3] = rr.w + o[3] * p.res_scale;
+        }
+        *reinterpret_cast<float4*>(p.y + oi) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+}
+
+template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT, int RW = 1, int WG = 0>
 // Register budget: the unrolled, pipelined tap loop wants ~280 registers (one 64-bit address pair per weight tap), which
 // leaves ONE wave per SIMD.  Capping at 256 (two resident blocks per CU) is worth 6-10 % for the single-n-tile kernels
 // (A/B in one process, scripts/bench_conv3d.py); with 2+ n-tiles the cap makes hipcc spill, so those stay uncapped.
 // (Tighter caps for the 2-D kernels were tried: they spill the MFMA-heavy ones and do not help the latency-bound ones.)
-__global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(const LdsConvParams p) {
-  typedef Cfg<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW> C;
+// (Winograd form with 32+ input channels: its 141 KB of LDS allow one block per CU anyway, so it may use the whole register file)
+__global__ __launch_bounds__(256, ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 : 1)) void conv_lds_kernel(const LdsConvParams p) {
+  typedef Cfg<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW, WG> C;
   constexpr int KPL = C::KPL, NG = C::NG, S = C::S, PW = C::PW, PH = C::PH;
   typedef typename VecT<KPL>::type vec_t;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -405,7 +528,7 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
   const __amdgpu_buffer_rsrc_t wres = make_rsrc(p.wpack, (unsigned)(C::NSTEP * C::NT * 64 * KPL * 4));
   const int wvoff = lane * KPL * 4;   // bytes
   // lane-constant part of the B-fragment LDS address (floats)
-  const int lane_lds = (q * S + wave * SHW * PW + n16 * C::SW) * KPL;
+  const int lane_lds = (q * S + wave * (C::WINO ? 2 : SHW) * PW + n16 * C::SW) * KPL;
 
   int* item_slot = reinterpret_cast<int*>(lds + C::RING * C::PLANE);
   // per-lane constants for the whole kernel: epilogue scale/shift of the lane's 4 couts, and (small layers) all weights
@@ -573,7 +696,7 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
     const int h0 = th * C::TH, w0 = tw * C::TWO;          // output tile origin
     const int ih0 = h0 * SHW - C::PAD, iw0 = w0 * SHW - C::PAD;  // input tile origin
     const int d0 = dc * p.dch, d1 = min(d0 + p.dch, p.D);
-    const bool row_live = (h0 + wave) < p.Ho;
+    const bool row_live = (h0 + wave * C::WROWS) < p.Ho;
     const int cols = (min(p.Wo - w0, C::TWO) + RW - 1) / RW;   // live MFMA columns
     const int mt_live = row_live ? (cols + 15) / 16 : 0;  // wave-uniform
 
@@ -648,7 +771,9 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
 #pragma unroll
         for (int kd = 0; kd < KD; ++kd) planes[kd] = lds + slot_of(d + kd - C::PD) * C::PLANE + lane_lds;
         const size_t row_vox = (((size_t)b * p.D + d) * p.Ho + (h0 + wave)) * p.Wo;
-        if constexpr (C::TR) {
+        if constexpr (C::WINO) {
+          step_wino<C, COUT>(planes, wres, wvoff, p, b, d, h0 + 2 * wave, w0, q, n16);
+        } else if constexpr (C::TR) {
           switch (mt_live) {
             case 1: step_tr<C, COUT, 1>(planes, wres, wvoff, p, b, d, h0 + wave, w0, q, n16); break;
             default: if (MT >= 2) step_tr<C, COUT, (MT >= 2 ? 2 : 1)>(planes, wres, wvoff, p, b, d, h0 + wave, w0, q, n16); break;
@@ -699,9 +824,9 @@ __global__ __launch_bounds__(256, (COUT <= 16 ? 2 : 1)) void conv_lds_kernel(con
   }
 }
 
-template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT, int RW = 1>
+template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT, int RW = 1, int WG = 0>
 int launch_lds(LdsConvParams& p, hipStream_t st) {
-  typedef Cfg<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW> C;
+  typedef Cfg<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW, WG> C;
   p.tiles_h = (p.Ho + C::TH - 1) / C::TH;
   p.tiles_w = (p.Wo + C::TWO - 1) / C::TWO;
   const long long tiles = (long long)p.B * p.tiles_h * p.tiles_w;
@@ -742,7 +867,7 @@ int launch_lds(LdsConvParams& p, hipStream_t st) {
   }
   static bool attr_done = false;  // benign race: the call is idempotent
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW, WG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
     if (e != hipSuccess) return mdf::fail(MDF_EHIP, "hipFuncSetAttribute(dynamic LDS %zu): %s", C::LDS_BYTES, hipGetErrorString(e));
     attr_done = true;
@@ -752,13 +877,13 @@ int launch_lds(LdsConvParams& p, hipStream_t st) {
   if (grid > p.n_items) grid = p.n_items;
   if (getenv("MDF_CONV_DEBUG")) {
     int nb = -1;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW>, 256, C::LDS_BYTES);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW, WG>, 256, C::LDS_BYTES);
     hipFuncAttributes fa{};
-    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW>));
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW, WG>));
     fprintf(stderr, "[conv_lds<%d,%d,%d,%d,%d,%d,%d,rw%d>] LDS %zu B dyn + %zu static, regs %d, occupancy API: %d blocks/CU (%s), grid %d, items %d\n",
             CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW, C::LDS_BYTES, fa.sharedSizeBytes, fa.numRegs, nb, hipGetErrorString(e), grid, p.n_items);
   }
-  hipLaunchKernelGGL((conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW>), dim3(grid), dim3(256), C::LDS_BYTES, st, p);
+  hipLaunchKernelGGL((conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW, WG>), dim3(grid), dim3(256), C::LDS_BYTES, st, p);
   return mdf::check_launch("conv_lds_kernel");
 }
 
@@ -801,9 +926,17 @@ static int sched_slot_of(void* stream) {
     return launch_lds<ci, cim, co, kd, k, s, mt, rw>(p, (hipStream_t)stream);                    \
   }
 
+// Winograd variants read the transform-domain weights appended behind the plain (and w-phase) packing
+#define LDS_CASE_WG(ci, co)                                                                      \
+  if (use_wg && KD == 3 && KHW == 3 && stride == 1 && Cin == ci && Cin_mem == ci && Cout == co && !res_up) { \
+    p.wpack = wpack + (size_t)27 * ci * (((co + 15) / 16) * 16) + (co == 8 ? (size_t)36 * ci * 16 : 0); \
+    return launch_lds<ci, ci, co, 3, 3, 1, 1, 2, 1>(p, (hipStream_t)stream);                     \
+  }
+
 int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
                           float res_scale, const float* res_up, float* y, int B, int D, int H, int W, int Cin, int Cin_mem, int Cout, int KD,
                           int KHW, int stride, int relu, void* stream, int planar_in, int shuffle2) {
+  static const bool use_wg = [] { const char* e = getenv("MDF_CONV_WINOGRAD"); return e ? atoi(e) != 0 : true; }();   // dev A/B
   static const bool use_rw = [] { const char* e = getenv("MDF_CONV_RW"); return e ? atoi(e) != 0 : true; }();   // dev A/B
   LdsConvParams p{};
   p.x = x; p.wpack = wpack; p.alpha = alpha; p.beta = beta; p.res = res; p.res_scale = res_scale; p.res_up = res_up; p.y = y;
@@ -823,6 +956,8 @@ int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha
     LDS_CASE(32, 32, 16, 2, 2, 1, 2) LDS_CASE(64, 64, 32, 2, 2, 1, 1)
     return MDF_EUNSUPPORTED;
   }
+  // 3-D stride-1 layers with 16 output channels: Winograd F(2x2,3x3) in (h,w)
+  LDS_CASE_WG(16, 16) LDS_CASE_WG(32, 16)
   // Cout < 16: w-phase form (RW output voxels per MFMA column)
   LDS_CASE_RW(16, 16, 8, 3, 3, 1, 2, 2) LDS_CASE_RW(8, 8, 8, 3, 3, 1, 2, 2)
   LDS_CASE_RW(16, 16, 4, 1, 3, 1, 1, 4) LDS_CASE_RW(8, 8, 4, 1, 3, 1, 1, 4)
