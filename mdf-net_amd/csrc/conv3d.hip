@@ -280,9 +280,9 @@ __global__ void pack_weights_rw_kernel(const float* __restrict__ w, float* __res
 
 // Winograd F(2x2,3x3) weights for conv_lds.hip step_wino: U[kd][a][b] = G g[kd] G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1];
 // fragments in the order the kernel walks them: [kd][chunk][ab = a*4+b][nt][lane = q*16+m][s], cout = nt*16+m, cin = chunk*16+4q+s.
-__global__ void pack_weights_wino_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout) {
+__global__ void pack_weights_wino_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int nkd) {
   const int NCH = Cin / 16, NT = (Cout + 15) / 16;
-  const int total = 3 * NCH * 16 * NT * 64 * 4;
+  const int total = nkd * NCH * 16 * NT * 64 * 4;
   const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     int r = i;
@@ -297,14 +297,15 @@ __global__ void pack_weights_wino_kernel(const float* __restrict__ w, float* __r
     const int cout = nt * 16 + m, cin = ch * 16 + 4 * qq + s;
     float v = 0.f;
     if (cout < Cout) {
-      const float* g = w + (((size_t)cout * Cin + cin) * 3 + kd) * 9;
+      const float* g = w + (((size_t)cout * Cin + cin) * nkd + kd) * 9;
       for (int y = 0; y < 3; ++y)
         for (int x = 0; x < 3; ++x) v += G[a][y] * G[b][x] * g[y * 3 + x];
     }
     wp[i] = v;
   }
 }
-static bool wino_built(int Cin, int Cout) { return Cout == 16 && (Cin == 16 || Cin == 32); }
+static bool wino_built(int Cin, int Cout) { return (Cout == 16 || Cout == 32) && (Cin == 16 || Cin == 32) && Cout <= Cin; }   // 3-D
+static bool wino2d_built(int Cin, int Cout) { return (Cin == 16 && Cout == 16) || (Cin == 32 && Cout == 32); }
 
 // ConvTranspose3d weights [Cin][Cout][3][3][3] -> wpack[tap' = (kd*3+kh)*2+ow][chunk][nt][q][n][s] with GEMM row
 // r = nt*16+n = pw*Cout + cout and kernel tap kw(pw, ow): (0,0)->1, (1,0)->2, (1,1)->0, (0,1)-> structurally zero.
@@ -419,7 +420,7 @@ extern "C" int mdf_conv3d_pack_weights(const float* w, float* wpack, int Cin, in
                          rw_of(Cout));
     if (wino_built(Cin, Cout))
       hipLaunchKernelGGL(pack_weights_wino_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w,
-                         wpack + (size_t)27 * Cin * (((Cout + 15) / 16) * 16) + (rw_of(Cout) ? (size_t)36 * Cin * 16 : 0), Cin, Cout);
+                         wpack + (size_t)27 * Cin * (((Cout + 15) / 16) * 16) + (rw_of(Cout) ? (size_t)36 * Cin * 16 : 0), Cin, Cout, 3);
   }
   return mdf::check_launch("pack_weights_kernel");
 }
@@ -430,6 +431,7 @@ extern "C" int64_t mdf_conv_packed_size(int Cin_mem, int Cout, int ntaps) {
   if (Cin_mem < 1 || Cout < 1 || ntaps < 1) return 0;
   int64_t n = (int64_t)ntaps * padded_cin(Cin_mem) * (((Cout + 15) / 16) * 16);
   if (ntaps == 9 && rw_of(Cout)) n += (int64_t)3 * (3 + rw_of(Cout) - 1) * padded_cin(Cin_mem) * 16;   // + w-phase packing (3x3 layers)
+  if (ntaps == 9 && wino2d_built(Cin_mem, Cout)) n += (int64_t)16 * Cin_mem * (((Cout + 15) / 16) * 16);   // + Winograd-domain weights
   return n;
 }
 
@@ -442,6 +444,9 @@ extern "C" int mdf_conv_pack_weights(const float* w, float* wpack, int Cin_mem, 
   if (ntaps == 9 && rw_of(Cout))
     hipLaunchKernelGGL(pack_weights_rw_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, wpack + (size_t)9 * Cin * 16, Cin, Cin_mem, Cout, 3, 3,
                        rw_of(Cout));
+  if (ntaps == 9 && wino2d_built(Cin_mem, Cout))
+    hipLaunchKernelGGL(pack_weights_wino_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, wpack + (size_t)9 * Cin * (((Cout + 15) / 16) * 16),
+                       Cin, Cout, 1);
   return mdf::check_launch("pack_weights_kernel");
 }
 

@@ -55,6 +55,7 @@ template <> __device__ __forceinline__ void vec_to<1>(const float& v, float* o) 
 // scalar/immediate fragment offset}.  With flat global loads every fragment needed its own 64-bit VGPR address (held in
 // registers or re-added on the VALU): 150-300 address pairs per kernel, the reason the pipelined tap loop sat at its
 // register cap and spilled (scripts/isa_stats.py).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
@@ -112,7 +113,7 @@ constexpr int round_s(int n) {  // smallest s >= n with s % 32 == 16
 template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT, int RW = 1, int WG = 0>
 struct Cfg {
   static_assert(RW == 1 || WG == 1 || (SHW == 1 && COUT * RW <= 16 && COUT % 4 == 0), "w-phase form: stride 1, RW*Cout <= 16, Cout % 4 == 0");
-  static_assert(WG == 0 || (KD == 3 && KHW == 3 && SHW == 1 && RW == 2 && MT == 1 && CIN % 16 == 0 && COUT % 4 == 0), "Winograd form: 3x3x3 stride 1, RW = 2, MT = 1");
+  static_assert(WG == 0 || ((KD == 3 || KD == 1) && KHW == 3 && SHW == 1 && RW == 2 && MT == 1 && CIN % 16 == 0 && COUT % 4 == 0), "Winograd form: 3x3(x3) stride 1, RW = 2, MT = 1");
   static constexpr bool WINO = (WG == 1);
   static constexpr int RWF = RW;
   static constexpr int KW = KHW + RW - 1;       // taps along w
@@ -134,15 +135,15 @@ struct Cfg {
   static constexpr int RING = (KD > 1) ? KD : 2;  // 3-D: rolling window of KD planes; 2-D: double-buffered tiles
   // KD = KHW = 2 marks the transposed form (ConvTranspose3d k3 s2 p1 op1 as 2x2x2 input taps -> 8 output parities, step_tr)
   static constexpr bool TR = (KD == 2 && KHW == 2);
-  static constexpr int NSTEP = WINO ? 48 * NCH : (TR ? 27 * NCH : KD * KHW * KW * NCH);   // MFMA pipeline steps per output row-tile (tap x cin chunk)
+  static constexpr int NSTEP = WINO ? KD * 16 * NCH : (TR ? 27 * NCH : KD * KHW * KW * NCH);   // MFMA pipeline steps per output row-tile (tap x cin chunk)
   // small layers keep ALL their weight fragments in registers for the whole kernel (<= 40 VGPRs; beyond that occupancy drops and it is a loss, measured) instead of re-fetching
   // them from L1 for every tile: with 8-16 MFMAs per step there is nothing to hide that round trip behind
-  static constexpr bool WREG = (KD == 1) && (NSTEP * NT * KPL <= 40);
+  static constexpr bool WREG = (KD == 1) && !WINO && (NSTEP * NT * KPL <= 40);
   // epilogue scale/shift hoisted out of the tile loop where registers allow (the 3-D and 4-n-tile kernels sit at their caps)
   static constexpr bool EPI_REG = (KD == 1) && (NT <= 2);
   static constexpr int WN = WREG ? NSTEP : 1;
   // 2-D: issue the next tile's global loads before this tile's MFMAs when the staging registers are cheap
-  static constexpr bool EARLY2 = (KD == 1) && (NFILL * KPL <= EARLY2_MAX_REGS);
+  static constexpr bool EARLY2 = (KD == 1) && !WINO && (NFILL * KPL <= EARLY2_MAX_REGS);
   static constexpr size_t LDS_BYTES = (size_t)RING * PLANE * sizeof(float) + 16;  // + the broadcast slot of the item id
 };
 
@@ -401,8 +402,8 @@ __device__ __forceinline__ void step_tr(const float* const (&planes)[2], __amdgp
 
 // ---- Winograd form (Cfg::WINO) ---------------------------------------------------------------------------------
 // Weight fragments (pack_weights_wino_kernel, conv3d.hip): [kd][chunk][ab = a*4+b][nt][lane][4], U = G g_kd G^T.
-template <typename C, int COUT>
-__device__ __forceinline__ void step_wino(const float* const (&planes)[3], __amdgpu_buffer_rsrc_t wres, int wvoff, const LdsConvParams& p,
+template <typename C, int COUT, int NKD>
+__device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __amdgpu_buffer_rsrc_t wres, int wvoff, const LdsConvParams& p,
                                           int b, int d, int h, int w0, int q, int n16) {
   constexpr int NCH = C::NCH, NT = C::NT, S = C::S, PW = C::PW;
   f32x4 acc[16][NT];
@@ -410,8 +411,11 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[3], __amd
   for (int ab = 0; ab < 16; ++ab)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[ab][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  constexpr int NF = 3 * NCH * 16;          // (kd, chunk, ab) steps
-  constexpr int AHEAD = 2, NA = 3;
+  constexpr int NF = NKD * NCH * 16;        // (kd, chunk, ab) steps
+#ifndef MDF_WG_AHEAD
+#define MDF_WG_AHEAD 2
+#endif
+  constexpr int AHEAD = MDF_WG_AHEAD, NA = AHEAD + 1;
   float af[NA][NT][4];
   auto load_a = [&](int i, int buf) {
 #pragma unroll
@@ -419,29 +423,31 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[3], __amd
   };
 #pragma unroll
   for (int i = 0; i < AHEAD; ++i) load_a(i, i % NA);
-  static_for<0, 3 * NCH>([&](auto gc) {
+  static_for<0, NKD * NCH>([&](auto gc) {
     constexpr int g = decltype(gc)::value;
     constexpr int kd = g / NCH, ch = g % NCH;
-    // this lane's 4x4 input patch (rows 2*tile_row .. +3, cols 2*tile_col .. +3) x its 4 cins
-    float v[16][4];
+    // this lane's 4x4 input patch (rows 2*tile_row .. +3, cols 2*tile_col .. +3) x its 4 cins, as two packed pairs so the
+    // transform runs on v_pk_add_f32 (two channels per instruction)
+    f32x2_t v[16][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float4 t = *reinterpret_cast<const float4*>(planes[kd] + ((ch * 4) * S + i * PW + j) * 4);
-        v[i * 4 + j][0] = t.x; v[i * 4 + j][1] = t.y; v[i * 4 + j][2] = t.z; v[i * 4 + j][3] = t.w;
+        v[i * 4 + j][0] = (f32x2_t){t.x, t.y};
+        v[i * 4 + j][1] = (f32x2_t){t.z, t.w};
       }
     // V = B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: rows (h) then columns (w), in place
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < 2; ++c) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float d0 = v[j][c], d1 = v[4 + j][c], d2 = v[8 + j][c], d3 = v[12 + j][c];
+        const f32x2_t d0 = v[j][c], d1 = v[4 + j][c], d2 = v[8 + j][c], d3 = v[12 + j][c];
         v[j][c] = d0 - d2; v[4 + j][c] = d1 + d2; v[8 + j][c] = d2 - d1; v[12 + j][c] = d1 - d3;
       }
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        const float e0 = v[a * 4][c], e1 = v[a * 4 + 1][c], e2 = v[a * 4 + 2][c], e3 = v[a * 4 + 3][c];
+        const f32x2_t e0 = v[a * 4][c], e1 = v[a * 4 + 1][c], e2 = v[a * 4 + 2][c], e3 = v[a * 4 + 3][c];
         v[a * 4][c] = e0 - e2; v[a * 4 + 1][c] = e1 + e2; v[a * 4 + 2][c] = e2 - e1; v[a * 4 + 3][c] = e1 - e3;
       }
     }
@@ -454,7 +460,7 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[3], __amd
       for (int sidx = 0; sidx < 4; ++sidx)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          acc[ab][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i % NA][nt][sidx], v[ab][sidx], acc[ab][nt], 0, 0, 0);
+          acc[ab][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i % NA][nt][sidx], v[ab][sidx >> 1][sidx & 1], acc[ab][nt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     });
   });
@@ -639,7 +645,7 @@ __global__ __launch_bounds__(256, ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 :
 #endif
       for (int tl = t_begin; tl < t_end; ++tl) {
         const int slot = (tl - t_begin) & 1;
-        const bool row_live2 = (th0 + wave) < p.Ho;
+        const bool row_live2 = (th0 + wave * C::WROWS) < p.Ho;
         const int cols2 = (min(p.Wo - tw0, C::TWO) + RW - 1) / RW;   // live MFMA columns
         const int mt_live2 = row_live2 ? (cols2 + 15) / 16 : 0;
         const int cb = tb, ch0 = th0, cw0 = tw0;           // this tile's origin; (tb,th0,tw0) move on to the next one
@@ -660,11 +666,15 @@ __global__ __launch_bounds__(256, ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 :
         if (mt_live2 > 0) {
           const float* planes[1] = {lds + slot * C::PLANE + lane_lds};
           const size_t row_vox = ((size_t)cb * p.Ho + (ch0 + wave)) * p.Wo;
-          switch (mt_live2) {
-            case 1: step<C, KD, KHW, SHW, COUT, 1>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be); break;
-            case 2: if (MT >= 2) step<C, KD, KHW, SHW, COUT, (MT >= 2 ? 2 : 1)>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be); break;
-            case 3: if (MT >= 3) step<C, KD, KHW, SHW, COUT, (MT >= 3 ? 3 : 1)>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be); break;
-            default: step<C, KD, KHW, SHW, COUT, MT>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be); break;
+          if constexpr (C::WINO) {
+            step_wino<C, COUT, 1>(planes, wres, wvoff, p, cb, 0, ch0 + 2 * wave, cw0, q, n16);
+          } else {
+            switch (mt_live2) {
+              case 1: step<C, KD, KHW, SHW, COUT, 1>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be); break;
+              case 2: if (MT >= 2) step<C, KD, KHW, SHW, COUT, (MT >= 2 ? 2 : 1)>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be); break;
+              case 3: if (MT >= 3) step<C, KD, KHW, SHW, COUT, (MT >= 3 ? 3 : 1)>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be); break;
+              default: step<C, KD, KHW, SHW, COUT, MT>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be); break;
+            }
           }
         }
 #ifdef MDF_STAMPS
@@ -772,7 +782,7 @@ __global__ __launch_bounds__(256, ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 :
         for (int kd = 0; kd < KD; ++kd) planes[kd] = lds + slot_of(d + kd - C::PD) * C::PLANE + lane_lds;
         const size_t row_vox = (((size_t)b * p.D + d) * p.Ho + (h0 + wave)) * p.Wo;
         if constexpr (C::WINO) {
-          step_wino<C, COUT>(planes, wres, wvoff, p, b, d, h0 + 2 * wave, w0, q, n16);
+          step_wino<C, COUT, 3>(planes, wres, wvoff, p, b, d, h0 + 2 * wave, w0, q, n16);
         } else if constexpr (C::TR) {
           switch (mt_live) {
             case 1: step_tr<C, COUT, 1>(planes, wres, wvoff, p, b, d, h0 + wave, w0, q, n16); break;
@@ -932,6 +942,11 @@ static int sched_slot_of(void* stream) {
     p.wpack = wpack + (size_t)27 * ci * (((co + 15) / 16) * 16) + (co == 8 ? (size_t)36 * ci * 16 : 0); \
     return launch_lds<ci, ci, co, 3, 3, 1, 1, 2, 1>(p, (hipStream_t)stream);                     \
   }
+#define LDS_CASE_WG2(ci, co)                                                                     \
+  if (use_wg && KD == 1 && KHW == 3 && stride == 1 && Cin == ci && Cin_mem == ci && Cout == co && !res_up && !shuffle2) { \
+    p.wpack = wpack + (size_t)9 * ci * (((co + 15) / 16) * 16);                                  \
+    return launch_lds<ci, ci, co, 1, 3, 1, 1, 2, 1>(p, (hipStream_t)stream);                     \
+  }
 
 int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
                           float res_scale, const float* res_up, float* y, int B, int D, int H, int W, int Cin, int Cin_mem, int Cout, int KD,
@@ -957,7 +972,8 @@ int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha
     return MDF_EUNSUPPORTED;
   }
   // 3-D stride-1 layers with 16 output channels: Winograd F(2x2,3x3) in (h,w)
-  LDS_CASE_WG(16, 16) LDS_CASE_WG(32, 16)
+  LDS_CASE_WG(16, 16) LDS_CASE_WG(32, 16) LDS_CASE_WG(32, 32)
+  LDS_CASE_WG2(16, 16) LDS_CASE_WG2(32, 32)
   // Cout < 16: w-phase form (RW output voxels per MFMA column)
   LDS_CASE_RW(16, 16, 8, 3, 3, 1, 2, 2) LDS_CASE_RW(8, 8, 8, 3, 3, 1, 2, 2)
   LDS_CASE_RW(16, 16, 4, 1, 3, 1, 1, 4) LDS_CASE_RW(8, 8, 4, 1, 3, 1, 1, 4)
