@@ -115,6 +115,7 @@ struct Cfg {
   static_assert(RW == 1 || WG == 1 || (SHW == 1 && COUT * RW <= 16 && COUT % 4 == 0), "w-phase form: stride 1, RW*Cout <= 16, Cout % 4 == 0");
   static_assert(WG == 0 || ((KD == 3 || KD == 1) && KHW == 3 && SHW == 1 && RW == 2 && MT == 1 && CIN % 16 == 0 && COUT % 4 == 0), "Winograd form: 3x3(x3) stride 1, RW = 2, MT = 1");
   static constexpr bool WINO = (WG == 1);
+  static constexpr int CIN_ = CIN;
   static constexpr int RWF = RW;
   static constexpr int KW = KHW + RW - 1;       // taps along w
   static constexpr int SW = SHW * RW;           // input step along w between neighbouring MFMA columns
@@ -423,47 +424,85 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __a
   };
 #pragma unroll
   for (int i = 0; i < AHEAD; ++i) load_a(i, i % NA);
-  static_for<0, NKD * NCH>([&](auto gc) {
-    constexpr int g = decltype(gc)::value;
-    constexpr int kd = g / NCH, ch = g % NCH;
-    // this lane's 4x4 input patch (rows 2*tile_row .. +3, cols 2*tile_col .. +3) x its 4 cins, as two packed pairs so the
-    // transform runs on v_pk_add_f32 (two channels per instruction)
-    f32x2_t v[16][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 t = *reinterpret_cast<const float4*>(planes[kd] + ((ch * 4) * S + i * PW + j) * 4);
-        v[i * 4 + j][0] = (f32x2_t){t.x, t.y};
-        v[i * 4 + j][1] = (f32x2_t){t.z, t.w};
-      }
-    // V = B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: rows (h) then columns (w), in place
+  constexpr int NG_ = NKD * NCH;
+  // one block per CU (32+ channels: the LDS image allows no second one) means one wave per SIMD and nobody to hide this
+  // wave's LDS latency and transform arithmetic: software-pipeline them into the MFMA loop instead -- while group g
+  // multiplies, the patch of group g+1 is read (one element per ab step), its row pass runs column by column as the reads
+  // land, and its column pass runs row by row right before the four MFMA steps that need that row.
+  constexpr bool PIPE = (C::CIN_ >= 32);
+  auto read_elem = [&](f32x2_t (&v)[16][2], int kd, int ch, int e) {     // e = j*4 + i: column-major so a column completes every 4 reads
+    const int i = e & 3, j = e >> 2;
+    const float4 t = *reinterpret_cast<const float4*>(planes[kd] + ((ch * 4) * S + i * PW + j) * 4);
+    v[i * 4 + j][0] = (f32x2_t){t.x, t.y};
+    v[i * 4 + j][1] = (f32x2_t){t.z, t.w};
+  };
+  auto row_pass = [&](f32x2_t (&v)[16][2], int j) {                      // B^T d : over the patch rows, column j
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f32x2_t d0 = v[j][c], d1 = v[4 + j][c], d2 = v[8 + j][c], d3 = v[12 + j][c];
-        v[j][c] = d0 - d2; v[4 + j][c] = d1 + d2; v[8 + j][c] = d2 - d1; v[12 + j][c] = d1 - d3;
-      }
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const f32x2_t e0 = v[a * 4][c], e1 = v[a * 4 + 1][c], e2 = v[a * 4 + 2][c], e3 = v[a * 4 + 3][c];
-        v[a * 4][c] = e0 - e2; v[a * 4 + 1][c] = e1 + e2; v[a * 4 + 2][c] = e2 - e1; v[a * 4 + 3][c] = e1 - e3;
-      }
+      const f32x2_t d0 = v[j][c], d1 = v[4 + j][c], d2 = v[8 + j][c], d3 = v[12 + j][c];
+      v[j][c] = d0 - d2; v[4 + j][c] = d1 + d2; v[8 + j][c] = d2 - d1; v[12 + j][c] = d1 - d3;
     }
-    static_for<0, 16>([&](auto abc) {
-      constexpr int ab = decltype(abc)::value;
-      constexpr int i = g * 16 + ab;
-      if constexpr (i + AHEAD < NF) load_a(i + AHEAD, (i + AHEAD) % NA);
-      __builtin_amdgcn_sched_barrier(0);
+  };
+  auto col_pass = [&](f32x2_t (&v)[16][2], int a) {                      // (B^T d) B : over the columns, row a
 #pragma unroll
-      for (int sidx = 0; sidx < 4; ++sidx)
+    for (int c = 0; c < 2; ++c) {
+      const f32x2_t e0 = v[a * 4][c], e1 = v[a * 4 + 1][c], e2 = v[a * 4 + 2][c], e3 = v[a * 4 + 3][c];
+      v[a * 4][c] = e0 - e2; v[a * 4 + 1][c] = e1 + e2; v[a * 4 + 2][c] = e2 - e1; v[a * 4 + 3][c] = e1 - e3;
+    }
+  };
+  if constexpr (!PIPE) {
+    static_for<0, NG_>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      constexpr int kd = g / NCH, ch = g % NCH;
+      f32x2_t v[16][2];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[ab][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i % NA][nt][sidx], v[ab][sidx >> 1][sidx & 1], acc[ab][nt], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int e = 0; e < 16; ++e) read_elem(v, kd, ch, e);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) row_pass(v, j);
+#pragma unroll
+      for (int a4 = 0; a4 < 4; ++a4) col_pass(v, a4);
+      static_for<0, 16>([&](auto abc) {
+        constexpr int ab = decltype(abc)::value;
+        constexpr int i = g * 16 + ab;
+        if constexpr (i + AHEAD < NF) load_a(i + AHEAD, (i + AHEAD) % NA);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[ab][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i % NA][nt][sidx], v[ab][sidx >> 1][sidx & 1], acc[ab][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      });
     });
-  });
+  } else {
+    f32x2_t vbuf[2][16][2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) read_elem(vbuf[0], 0, 0, e);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) row_pass(vbuf[0], j);
+    static_for<0, NG_>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      constexpr int cur = g & 1, nxt = cur ^ 1;
+      constexpr bool more = (g + 1 < NG_);
+      constexpr int nkd = more ? (g + 1) / NCH : 0, nch = more ? (g + 1) % NCH : 0;
+      static_for<0, 16>([&](auto abc) {
+        constexpr int ab = decltype(abc)::value;
+        constexpr int i = g * 16 + ab;
+        if constexpr (i + AHEAD < NF) load_a(i + AHEAD, (i + AHEAD) % NA);
+        if constexpr (more) read_elem(vbuf[nxt], nkd, nch, ab);                       // next group's patch, one element per step
+        if constexpr (more && ab >= 5 && (ab & 3) == 1) row_pass(vbuf[nxt], (ab >> 2) - 1);   // column j complete since step 4j+3
+        if constexpr ((ab & 3) == 0) col_pass(vbuf[cur], ab >> 2);                    // row a of the current group, just in time
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[ab][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i % NA][nt][sidx], vbuf[cur][ab][sidx >> 1][sidx & 1], acc[ab][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if constexpr (more) row_pass(vbuf[nxt], 3);                                     // last column (its reads were issued at steps 12..15)
+    });
+  }
   // epilogue: Y = A^T M A per cout, A^T = [1 1 1 0; 0 1 -1 -1]; outputs (h + pr, w0 + 2*n16 + r)
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
