@@ -782,7 +782,7 @@ __global__ __launch_bounds__(256, ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 :
     auto slot_of = [](int dz) { return (KD == 1) ? 0 : ((dz % KD) + KD) % KD; };
 
     // prologue: planes d0-PD .. d0+PD
-    if constexpr (CIN <= 16) {
+    if constexpr (CIN <= 16 || (C::WINO && CIN >= 32)) {   // (the one-block-per-CU Winograd kernels have the registers for it)
       vec_t pro[KD][C::NFILL];   // all KD planes in flight at once: one memory latency instead of KD
 #pragma unroll
       for (int j = 0; j < KD; ++j)
@@ -890,7 +890,9 @@ int launch_lds(LdsConvParams& p, hipStream_t st) {
     // 1-plane tail chunk (D = 4 -> 3 + 1) costs a whole prologue for a third of the work: 93 -> 77 us on 16->16 @4x296x400.
     // (A makespan model "rounds x (chunk + prologue)" was tried and is wrong here: two resident blocks share one MFMA pipe,
     // so fewer, longer items do not finish sooner.)
-    long long want = (6LL * max_grid + tiles - 1) / tiles;
+    long long ipb = 6;
+    if (const char* e = getenv("MDF_CONV_ITEMS_PER_BLOCK")) { if (atoi(e) > 0) ipb = atoi(e); }   // dev A/B
+    long long want = (ipb * max_grid + tiles - 1) / tiles;
     if (want < 1) want = 1;
     if (want > p.D / 3) want = p.D / 3;
     if (want < 1) want = 1;
