@@ -304,7 +304,7 @@ __global__ void pack_weights_wino_kernel(const float* __restrict__ w, float* __r
     wp[i] = v;
   }
 }
-static bool wino_built(int Cin, int Cout) { return (Cout == 16 || Cout == 32) && (Cin == 16 || Cin == 32) && Cout <= Cin; }   // 3-D
+static bool wino_built(int Cin, int Cout) { return ((Cout == 16 || Cout == 32) && (Cin == 16 || Cin == 32) && Cout <= Cin) || (Cin == 16 && Cout == 8); }   // 3-D
 static bool wino2d_built(int Cin, int Cout) { return (Cin == 16 && Cout == 16) || (Cin == 32 && Cout == 32); }
 
 // ConvTranspose3d weights [Cin][Cout][3][3][3] -> wpack[tap' = (kd*3+kh)*2+ow][chunk][nt][q][n][s] with GEMM row
