@@ -153,7 +153,7 @@ struct Cfg {
 template <typename C, int KD, int KHW, int SHW, int COUT, int MTL>
 __device__ __forceinline__ void step(const float* const (&planes)[KD], __amdgpu_buffer_rsrc_t wres, int wvoff, const LdsConvParams& p,
                                      size_t row_vox, int w0, int q, int n16, const float (&wr)[C::WN][C::NT][C::KPL],
-                                     const float (&al)[C::NT][4], const float (&be)[C::NT][4]) {
+                                     const float (&al)[C::NT][4], const float (&be)[C::NT][4], const float (&wfirst)[2][C::NT][C::KPL]) {
   constexpr int KPL = C::KPL, NCH = C::NCH, NT = C::NT, S = C::S, PW = C::PW;
   typedef typename VecT<KPL>::type vec_t;
   f32x4 acc[MTL][NT];
@@ -183,8 +183,19 @@ __device__ __forceinline__ void step(const float* const (&planes)[KD], __amdgpu_
       vec_to<KPL>(*reinterpret_cast<const vec_t*>(planes[kd] + ((ch * 4) * S + kh * PW + kw + t * 16 * C::SW) * KPL), bf[buf][t]);
   };
   if constexpr (!C::WREG) {
+    // the first fragments of every call are the same: they stay in registers for the whole kernel (wfirst), so a step
+    // does not begin with an exposed L1/L2 round trip
 #pragma unroll
-    for (int i = 0; i < AHEAD_A; ++i) load_a(i, i % NA);
+    for (int i = 0; i < AHEAD_A; ++i) {
+      if (i < 2) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int k = 0; k < KPL; ++k) af[i % NA][nt][k] = wfirst[i][nt][k];
+      } else {
+        load_a(i, i % NA);
+      }
+    }
   }
   load_b(0, 0);
 #pragma unroll
@@ -320,7 +331,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 template <typename C, int COUT, int MTL>
 __device__ __forceinline__ void step_tr(const float* const (&planes)[2], __amdgpu_buffer_rsrc_t wres, int wvoff, const LdsConvParams& p,
-                                        int b, int d, int h, int w0, int q, int n16) {
+                                        int b, int d, int h, int w0, int q, int n16, const float (&wfirst)[2][C::NT][C::KPL]) {
   constexpr int KPL = C::KPL, NCH = C::NCH, NT = C::NT, S = C::S, PW = C::PW, NSTEP = C::NSTEP;
   typedef typename VecT<KPL>::type vec_t;
   f32x4 acc[8][MTL][NT];
@@ -343,7 +354,11 @@ __device__ __forceinline__ void step_tr(const float* const (&planes)[2], __amdgp
       vec_to<KPL>(*reinterpret_cast<const vec_t*>(planes[dd] + ((ch * 4) * S + dh * PW + dw + t * 16) * KPL), bf[buf][t]);
   };
 #pragma unroll
-  for (int i = 0; i < AHEAD_A; ++i) load_a(i, i % NA);
+  for (int i = 0; i < AHEAD_A; ++i)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int k = 0; k < KPL; ++k) af[i % NA][nt][k] = wfirst[i][nt][k];
   load_b(0, 0, 0);
   static_for<0, NSTEP>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
@@ -405,7 +420,7 @@ __device__ __forceinline__ void step_tr(const float* const (&planes)[2], __amdgp
 // Weight fragments (pack_weights_wino_kernel, conv3d.hip): [kd][chunk][ab = a*4+b][nt][lane][4], U = G g_kd G^T.
 template <typename C, int COUT, int NKD>
 __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __amdgpu_buffer_rsrc_t wres, int wvoff, const LdsConvParams& p,
-                                          int b, int d, int h, int w0, int q, int n16) {
+                                          int b, int d, int h, int w0, int q, int n16, const float (&wfirst)[2][C::NT][C::KPL]) {
   constexpr int NCH = C::NCH, NT = C::NT, S = C::S, PW = C::PW;
   f32x4 acc[16][NT];
 #pragma unroll
@@ -423,7 +438,16 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __a
     for (int nt = 0; nt < NT; ++nt) buf_load_to<4>(wres, wvoff, (i * NT + nt) * (64 * 4 * 4), af[buf][nt]);
   };
 #pragma unroll
-  for (int i = 0; i < AHEAD; ++i) load_a(i, i % NA);
+  for (int i = 0; i < AHEAD; ++i) {
+    if (i < 2) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) af[i % NA][nt][k] = wfirst[i][nt][k];
+    } else {
+      load_a(i, i % NA);
+    }
+  }
   constexpr int NG_ = NKD * NCH;
   // one block per CU (32+ channels: the LDS image allows no second one) means one wave per SIMD and nobody to hide this
   // wave's LDS latency and transform arithmetic: software-pipeline them into the MFMA loop instead -- while group g
@@ -587,6 +611,17 @@ __global__ __launch_bounds__(256, ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 :
       al[nt][k] = (C::EPI_REG && row < C::ROWS && p.alpha) ? p.alpha[c] : 1.f;
       be[nt][k] = (C::EPI_REG && row < C::ROWS && p.beta) ? p.beta[c] : 0.f;
     }
+  float wfirst[2][C::NT][KPL];   // fragments 0 and 1 of the packed weights: what every step call starts with
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int nt = 0; nt < C::NT; ++nt) {
+      if constexpr (!C::WREG) buf_load_to<KPL>(wres, wvoff, (i * C::NT + nt) * (64 * KPL * 4), wfirst[i][nt]);   // (past the end reads 0)
+      else {
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) wfirst[i][nt][k] = 0.f;
+      }
+    }
   float wr[C::WN][C::NT][KPL];
   if constexpr (C::WREG) {
 #pragma unroll
@@ -706,13 +741,13 @@ __global__ __launch_bounds__(256, ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 :
           const float* planes[1] = {lds + slot * C::PLANE + lane_lds};
           const size_t row_vox = ((size_t)cb * p.Ho + (ch0 + wave)) * p.Wo;
           if constexpr (C::WINO) {
-            step_wino<C, COUT, 1>(planes, wres, wvoff, p, cb, 0, ch0 + 2 * wave, cw0, q, n16);
+            step_wino<C, COUT, 1>(planes, wres, wvoff, p, cb, 0, ch0 + 2 * wave, cw0, q, n16, wfirst);
           } else {
             switch (mt_live2) {
-              case 1: step<C, KD, KHW, SHW, COUT, 1>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be); break;
-              case 2: if (MT >= 2) step<C, KD, KHW, SHW, COUT, (MT >= 2 ? 2 : 1)>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be); break;
-              case 3: if (MT >= 3) step<C, KD, KHW, SHW, COUT, (MT >= 3 ? 3 : 1)>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be); break;
-              default: step<C, KD, KHW, SHW, COUT, MT>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be); break;
+              case 1: step<C, KD, KHW, SHW, COUT, 1>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be, wfirst); break;
+              case 2: if (MT >= 2) step<C, KD, KHW, SHW, COUT, (MT >= 2 ? 2 : 1)>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be, wfirst); break;
+              case 3: if (MT >= 3) step<C, KD, KHW, SHW, COUT, (MT >= 3 ? 3 : 1)>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be, wfirst); break;
+              default: step<C, KD, KHW, SHW, COUT, MT>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be, wfirst); break;
             }
           }
         }
@@ -821,18 +856,18 @@ __global__ __launch_bounds__(256, ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 :
         for (int kd = 0; kd < KD; ++kd) planes[kd] = lds + slot_of(d + kd - C::PD) * C::PLANE + lane_lds;
         const size_t row_vox = (((size_t)b * p.D + d) * p.Ho + (h0 + wave)) * p.Wo;
         if constexpr (C::WINO) {
-          step_wino<C, COUT, 3>(planes, wres, wvoff, p, b, d, h0 + 2 * wave, w0, q, n16);
+          step_wino<C, COUT, 3>(planes, wres, wvoff, p, b, d, h0 + 2 * wave, w0, q, n16, wfirst);
         } else if constexpr (C::TR) {
           switch (mt_live) {
-            case 1: step_tr<C, COUT, 1>(planes, wres, wvoff, p, b, d, h0 + wave, w0, q, n16); break;
-            default: if (MT >= 2) step_tr<C, COUT, (MT >= 2 ? 2 : 1)>(planes, wres, wvoff, p, b, d, h0 + wave, w0, q, n16); break;
+            case 1: step_tr<C, COUT, 1>(planes, wres, wvoff, p, b, d, h0 + wave, w0, q, n16, wfirst); break;
+            default: if (MT >= 2) step_tr<C, COUT, (MT >= 2 ? 2 : 1)>(planes, wres, wvoff, p, b, d, h0 + wave, w0, q, n16, wfirst); break;
           }
         } else {
           switch (mt_live) {
-            case 1: step<C, KD, KHW, SHW, COUT, 1>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be); break;
-            case 2: if (MT >= 2) step<C, KD, KHW, SHW, COUT, (MT >= 2 ? 2 : 1)>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be); break;
-            case 3: if (MT >= 3) step<C, KD, KHW, SHW, COUT, (MT >= 3 ? 3 : 1)>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be); break;
-            default: step<C, KD, KHW, SHW, COUT, MT>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be); break;
+            case 1: step<C, KD, KHW, SHW, COUT, 1>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be, wfirst); break;
+            case 2: if (MT >= 2) step<C, KD, KHW, SHW, COUT, (MT >= 2 ? 2 : 1)>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be, wfirst); break;
+            case 3: if (MT >= 3) step<C, KD, KHW, SHW, COUT, (MT >= 3 ? 3 : 1)>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be, wfirst); break;
+            default: step<C, KD, KHW, SHW, COUT, MT>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be, wfirst); break;
           }
         }
       }
