@@ -87,6 +87,15 @@ class EvalTanks(EvalArgs):            # config.py:114-121
         self.show_args()
 
 
+def _scan_ids(spec):
+    """ "2 6-8 14" -> [2, 6, 7, 8, 14] """
+    out = []
+    for tok in spec.split():
+        lo, _, hi = tok.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
 class DatasetsArgs(Args):
     def __init__(self):
         self.root_dir = DATA_ROOT
@@ -97,11 +106,8 @@ class LoadDTU(DatasetsArgs):          # config.py:131-152
         super().__init__()
         self.train_root = os.path.join(self.root_dir, "dtu640x512")
         self.train_pair = os.path.join(self.train_root, "Cameras", "pair.txt")
-        self.train_label = [2, 6, 7, 8, 14, 16, 18, 19, 20, 22, 30, 31, 36, 39, 41, 42, 44, 45, 46, 47, 50, 51, 52, 53, 55,
-                            57, 58, 60, 61, 63, 64, 65, 68, 69, 70, 71, 72, 74, 76, 83, 84, 85, 87, 88, 89, 90, 91, 92, 93,
-                            94, 95, 96, 97, 98, 99, 100, 101, 102, 103, 104, 105, 107, 108, 109, 111, 112, 113, 115, 116,
-                            119, 120, 121, 122, 123, 124, 125, 126, 127, 128]
-        self.train_lighting_label = [0, 1, 2, 3, 4, 5, 6]
+        self.train_label = _scan_ids("2 6-8 14 16 18-20 22 30-31 36 39 41-42 44-47 50-53 55 57-58 60-61 63-65 68-72 74 76 83-85 87-105 107-109 111-113 115-116 119-128")   # the 79 DTU training scans
+        self.train_lighting_label = list(range(7))
         self.train_robust = True
         self.eval_root = os.path.join(self.root_dir, "dtu1600x1200")
         self.eval_pair = os.path.join(self.eval_root, "pair.txt")

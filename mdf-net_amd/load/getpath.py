@@ -1,33 +1,38 @@
-"""Dataset path templates (counterpart of load/getpath.py:4-32)."""
+"""Where the datasets keep their files (the layouts the reference's load/getpath.py:4-45 encodes), as one table.
+
+    kind   mode         relative path (fields: scan folder, view id, lighting)
+"""
 import os
+
+_LAYOUT = {
+    # DTU training set (640x512): lighting-specific rectified images, shared cameras, per-scan depth maps
+    ("img", "train"): lambda s, v, l: ("Rectified", s, "rect_%03d_%s_r5000.png" % (v + 1, l)),
+    ("cam", "train"): lambda s, v, l: ("Cameras", "%08d_cam.txt" % v),
+    ("depth", "train"): lambda s, v, l: ("Depths", s, "depth_map_%04d.pfm" % v),
+    # DTU evaluation set (1600x1200) and Tanks&Temples: per-scan images/ and cams/ (cams_1/ for T&T)
+    ("img", "eval"): lambda s, v, l: (s, "images", "%08d.jpg" % v),
+    ("cam", "eval"): lambda s, v, l: (s, "cams", "%08d_cam.txt" % v),
+    ("img", "tanks"): lambda s, v, l: (s, "images", "%08d.jpg" % v),
+    ("cam", "tanks"): lambda s, v, l: (s, "cams_1", "%08d_cam.txt" % v),
+    # BlendedMVS (768x576)
+    ("img", "blendedmvs"): lambda s, v, l: (s, "blended_images", "%08d.jpg" % v),
+    ("cam", "blendedmvs"): lambda s, v, l: (s, "cams", "%08d_cam.txt" % v),
+    ("depth", "blendedmvs"): lambda s, v, l: (s, "rendered_depth_maps", "%08d.pfm" % v),
+}
+
+
+def _path(kind, root, scan, view, lighting, mode):
+    entry = _LAYOUT.get((kind, mode))
+    return None if entry is None else os.path.join(root, *entry(scan, view, lighting))
 
 
 def get_img_path(dataset_path, scan_folder, view_id, lighting=None, mode=""):
-    if mode == "train":
-        return os.path.join(dataset_path, "Rectified", scan_folder, "rect_{:0>3}_{}_r5000.png".format(view_id + 1, lighting))
-    if mode in ("eval", "tanks"):
-        return os.path.join(dataset_path, scan_folder, "images", "{:0>8}.jpg".format(view_id))
-    if mode == "blendedmvs":
-        return os.path.join(dataset_path, "{}/blended_images/{:0>8}.jpg".format(scan_folder, view_id))
-    return None
+    return _path("img", dataset_path, scan_folder, view_id, lighting, mode)
 
 
 def get_cam_path(dataset_path, scan_folder, view_id, mode):
-    if mode == "train":
-        return os.path.join(dataset_path, "Cameras", "{:0>8}_cam.txt".format(view_id))
-    if mode == "eval":
-        return os.path.join(dataset_path, scan_folder, "cams", "{:0>8}_cam.txt".format(view_id))
-    if mode == "tanks":
-        return os.path.join(dataset_path, scan_folder, "cams_1", "{:0>8}_cam.txt".format(view_id))
-    if mode == "blendedmvs":
-        return os.path.join(dataset_path, "{}/cams/{:0>8}_cam.txt".format(scan_folder, view_id))
-    return None
+    return _path("cam", dataset_path, scan_folder, view_id, None, mode)
 
 
 def get_depth_path(dataset_path, scan_folder, view_id, mode):
-    """Ground-truth depth maps (load/getpath.py:34-45)."""
-    if mode == "train":
-        return os.path.join(dataset_path, "Depths", scan_folder, "depth_map_{:0>4}.pfm".format(view_id))
-    if mode == "blendedmvs":
-        return os.path.join(dataset_path, "{}/rendered_depth_maps/{:0>8}.pfm".format(scan_folder, view_id))
-    return None
+    return _path("depth", dataset_path, scan_folder, view_id, None, mode)
