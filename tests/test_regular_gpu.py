@@ -45,10 +45,11 @@ def test_conv3d_layer(cin, cout, mode, shape):
 
 
 @pytest.mark.parametrize("cin,cout", [(32, 16), (16, 16), (32, 32), (16, 8), (8, 8)])
-@pytest.mark.parametrize("shape", [(1, 6, 130, 201), (2, 5, 125, 131), (1, 3, 260, 197)])
+@pytest.mark.parametrize("shape", [(1, 6, 130, 201), (2, 5, 125, 131), (1, 3, 260, 197), (1, 90, 5, 401), (1, 2, 3, 25001), (1, 1, 400, 400)])
 def test_conv3d_layer_lds_kernels(cin, cout, shape):
     """Volumes of >= 150 000 voxels take the LDS-staged kernels (conv_lds.hip; Cout = 8 in the w-phase form): ragged tiles
-    in h and w (odd widths exercise the half-filled last w-phase pair), D not a multiple of the depth chunk, batch 2."""
+    in h and w (odd widths exercise the half-filled last w-phase pair / Winograd tile), D not a multiple of the depth chunk,
+    batch 2, fewer rows than one tile (5, 3), a single plane."""
     b, d, h, w = shape
     assert b * d * h * w >= 150000
     g = torch.Generator().manual_seed(cin * 100 + cout + w)
