@@ -145,7 +145,10 @@ struct Cfg {
   static constexpr int WN = WREG ? NSTEP : 1;
   // 2-D: issue the next tile's global loads before this tile's MFMAs when the staging registers are cheap
   static constexpr bool EARLY2 = (KD == 1) && !WINO && (NFILL * KPL <= EARLY2_MAX_REGS);
-  static constexpr size_t LDS_BYTES = (size_t)RING * PLANE * sizeof(float) + 16;  // + the broadcast slot of the item id
+  // + the broadcast slot of the item id (16 B) + the epilogue table: alpha[64], beta[64] (read per step from LDS instead of
+  // from global memory: the per-call L1/L2 round trip was ~1000 exposed cycles per depth step, in-kernel stamps)
+  static constexpr int EPI_OFF = RING * PLANE + 4;   // floats
+  static constexpr size_t LDS_BYTES = (size_t)RING * PLANE * sizeof(float) + 16 + 128 * sizeof(float);
 };
 
 // One output row-tile of one depth plane: MTL live m-tiles (16 voxels each) x all couts.  Fully unrolled over the
@@ -156,6 +159,8 @@ __device__ __forceinline__ void step(const float* const (&planes)[KD], __amdgpu_
                                      const float (&al)[C::NT][4], const float (&be)[C::NT][4], const float (&wfirst)[2][C::NT][C::KPL]) {
   constexpr int KPL = C::KPL, NCH = C::NCH, NT = C::NT, S = C::S, PW = C::PW;
   typedef typename VecT<KPL>::type vec_t;
+  extern __shared__ __attribute__((aligned(16))) float lds_base_[];
+  const float* epi_tab = lds_base_ + C::EPI_OFF;
   f32x4 acc[MTL][NT];
 #pragma unroll
   for (int t = 0; t < MTL; ++t)
@@ -230,8 +235,8 @@ __device__ __forceinline__ void step(const float* const (&planes)[KD], __amdgpu_
       if constexpr (C::EPI_REG) {
         al_l[k] = al[nt][k]; be_l[k] = be[nt][k];
       } else {
-        al_l[k] = (c0 + k < COUT && p.alpha) ? p.alpha[c0 + k] : 1.f;
-        be_l[k] = (c0 + k < COUT && p.beta) ? p.beta[c0 + k] : 0.f;
+        al_l[k] = epi_tab[c0 + k];
+        be_l[k] = epi_tab[64 + c0 + k];
       }
     }
 #pragma unroll
@@ -334,6 +339,8 @@ __device__ __forceinline__ void step_tr(const float* const (&planes)[2], __amdgp
                                         int b, int d, int h, int w0, int q, int n16, const float (&wfirst)[2][C::NT][C::KPL]) {
   constexpr int KPL = C::KPL, NCH = C::NCH, NT = C::NT, S = C::S, PW = C::PW, NSTEP = C::NSTEP;
   typedef typename VecT<KPL>::type vec_t;
+  extern __shared__ __attribute__((aligned(16))) float lds_base_[];
+  const float* epi_tab = lds_base_ + C::EPI_OFF;
   f32x4 acc[8][MTL][NT];
 #pragma unroll
   for (int c = 0; c < 8; ++c)
@@ -388,8 +395,8 @@ __device__ __forceinline__ void step_tr(const float* const (&planes)[2], __amdgp
     float al_l[4], be_l[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      al_l[k] = (c0 + k < COUT && p.alpha) ? p.alpha[c0 + k] : 1.f;
-      be_l[k] = (c0 + k < COUT && p.beta) ? p.beta[c0 + k] : 0.f;
+      al_l[k] = epi_tab[c0 + k];
+      be_l[k] = epi_tab[64 + c0 + k];
     }
 #pragma unroll
     for (int t = 0; t < MTL; ++t) {
@@ -422,6 +429,8 @@ template <typename C, int COUT, int NKD>
 __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __amdgpu_buffer_rsrc_t wres, int wvoff, const LdsConvParams& p,
                                           int b, int d, int h, int w0, int q, int n16, const float (&wfirst)[2][C::NT][C::KPL]) {
   constexpr int NCH = C::NCH, NT = C::NT, S = C::S, PW = C::PW;
+  extern __shared__ __attribute__((aligned(16))) float lds_base_[];
+  const float* epi_tab = lds_base_ + C::EPI_OFF;
   f32x4 acc[16][NT];
 #pragma unroll
   for (int ab = 0; ab < 16; ++ab)
@@ -551,8 +560,8 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __a
     float al_l[4], be_l[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      al_l[k] = (c0 + k < COUT && p.alpha) ? p.alpha[c0 + k] : 1.f;
-      be_l[k] = (c0 + k < COUT && p.beta) ? p.beta[c0 + k] : 0.f;
+      al_l[k] = epi_tab[c0 + k];
+      be_l[k] = epi_tab[64 + c0 + k];
     }
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
@@ -600,6 +609,11 @@ __global__ __launch_bounds__(256, ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 :
   const int lane_lds = (q * S + wave * (C::WINO ? 2 : SHW) * PW + n16 * C::SW) * KPL;
 
   int* item_slot = reinterpret_cast<int*>(lds + C::RING * C::PLANE);
+  if (tid < 128) {   // epilogue table (1 / 0 beyond COUT or without BN)
+    const int c = tid & 63;
+    lds[C::EPI_OFF + tid] = (tid < 64) ? ((c < COUT && p.alpha) ? p.alpha[c] : 1.f) : ((c < COUT && p.beta) ? p.beta[c] : 0.f);
+  }
+  __syncthreads();
   // per-lane constants for the whole kernel: epilogue scale/shift of the lane's 4 couts, and (small layers) all weights
   float al[C::NT][4], be[C::NT][4];
 #pragma unroll
