@@ -543,18 +543,21 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __a
     if (c0 >= COUT) continue;
     float y[2][2][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float srow[2][4];
+    for (int k2 = 0; k2 < 2; ++k2) {          // two couts per packed instruction
+      f32x2_t srow[2][4];
 #pragma unroll
       for (int bb = 0; bb < 4; ++bb) {
-        const float m0 = acc[bb][nt][k], m1 = acc[4 + bb][nt][k], m2 = acc[8 + bb][nt][k], m3 = acc[12 + bb][nt][k];
+        const f32x2_t m0 = {acc[bb][nt][2 * k2], acc[bb][nt][2 * k2 + 1]}, m1 = {acc[4 + bb][nt][2 * k2], acc[4 + bb][nt][2 * k2 + 1]};
+        const f32x2_t m2 = {acc[8 + bb][nt][2 * k2], acc[8 + bb][nt][2 * k2 + 1]}, m3 = {acc[12 + bb][nt][2 * k2], acc[12 + bb][nt][2 * k2 + 1]};
         srow[0][bb] = m0 + m1 + m2;
         srow[1][bb] = m1 - m2 - m3;
       }
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
-        y[pr][0][k] = srow[pr][0] + srow[pr][1] + srow[pr][2];
-        y[pr][1][k] = srow[pr][1] - srow[pr][2] - srow[pr][3];
+        const f32x2_t y0 = srow[pr][0] + srow[pr][1] + srow[pr][2];
+        const f32x2_t y1 = srow[pr][1] - srow[pr][2] - srow[pr][3];
+        y[pr][0][2 * k2] = y0[0]; y[pr][0][2 * k2 + 1] = y0[1];
+        y[pr][1][2 * k2] = y1[0]; y[pr][1][2 * k2 + 1] = y1[1];
       }
     }
     float al_l[4], be_l[4];
