@@ -133,6 +133,34 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // Epilogue operands (folded BN, residual) are fetched NOW so their L2 round trip overlaps the tap loop: a block lives for
+  // one wave tile (10-20 us), an exposed ~1 us at its end is 5-10 % of it.
+  // (the residual only for the transposed layers -- the ones that carry a skip connection in these networks; holding it for
+  // the others costs the big-tile kernels an occupancy step)
+  constexpr bool kPrefetchRes = (MODE == kTr);
+  float4 ep_al[NT], ep_be[NT], ep_res[kPrefetchRes ? MT : 1][NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int r0 = nt * 16 + 4 * q;
+    const int c0 = (MODE == kTr) ? r0 % COUT : r0;
+    ep_al[nt] = make_float4(1.f, 1.f, 1.f, 1.f);
+    ep_be[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 < ROWS && p.alpha) {
+      ep_al[nt] = *reinterpret_cast<const float4*>(p.alpha + c0);
+      ep_be[nt] = *reinterpret_cast<const float4*>(p.beta + c0);
+    }
+    if constexpr (kPrefetchRes) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        ep_res[t][nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 < ROWS && p.res && live[t]) {
+          const int pw_out = r0 / COUT;
+          ep_res[t][nt] = *reinterpret_cast<const float4*>(p.res + (size_t)(out_vox[t] + pw_out) * COUT + c0);
+        }
+      }
+    }
+  }
+
   const float* xq = p.x + KPL * q;                       // this lane's cin slot inside a chunk
   const float* wl = p.wpack + (size_t)lane * KPL;        // this lane's slot inside a packed 64-lane fragment
 
@@ -210,11 +238,7 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
     if (r0 >= ROWS) continue;
     const int pw_out = (MODE == kTr) ? r0 / COUT : 0;
     const int c0 = (MODE == kTr) ? r0 % COUT : r0;
-    float4 al = make_float4(1.f, 1.f, 1.f, 1.f), be = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.alpha) {
-      al = *reinterpret_cast<const float4*>(p.alpha + c0);
-      be = *reinterpret_cast<const float4*>(p.beta + c0);
-    }
+    const float4 al = ep_al[nt], be = ep_be[nt];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       if (!live[t]) continue;
@@ -227,7 +251,7 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
       if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
       const size_t oi = (size_t)(out_vox[t] + pw_out) * COUT + c0;
       if (p.res) {
-        const float4 rr = *reinterpret_cast<const float4*>(p.res + oi);
+        const float4 rr = kPrefetchRes ? ep_res[kPrefetchRes ? t : 0][nt] : *reinterpret_cast<const float4*>(p.res + oi);
         o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
       }
       *reinterpret_cast<float4*>(p.y + oi) = o;
