@@ -356,42 +356,6 @@ __global__ void pack_weights_tr_kernel(const float* __restrict__ w, float* __res
   }
 }
 
-// ConvTranspose3d weights for the LDS-staged transposed form (conv_lds.hip step_tr): fragments in the order that loop walks
-// them -- for delta in 0..7 (dd*4+dh*2+dw), for chunk, for class p >= delta (ascending), for nt.  Kernel tap per dim:
-// parity 0 -> k=1; parity 1 -> k=2 (delta 0) or k=0 (delta 1).
-__global__ void pack_weights_trlds_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout) {
-  const int KPL = (Cin >= 16) ? 4 : 2, CK = 4 * KPL, NCH = Cin / CK, NT = (Cout + 15) / 16;
-  const int total = 27 * NCH * NT * 64 * KPL;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    int r = i;
-    const int s = r % KPL; r /= KPL;
-    const int n = r % 16; r /= 16;
-    const int qq = r % 4; r /= 4;
-    const int nt = r % NT; r /= NT;
-    const int step = r;
-    int delta = 0, ch = 0, cls = 0, cnt = 0;
-    bool found = false;
-    for (int dl = 0; dl < 8 && !found; ++dl)
-      for (int c = 0; c < NCH && !found; ++c)
-        for (int pc = 0; pc < 8 && !found; ++pc) {
-          if ((pc & dl) != dl) continue;
-          if (cnt == step) { delta = dl; ch = c; cls = pc; found = true; }
-          ++cnt;
-        }
-    const int cout = nt * 16 + n, cin = ch * CK + KPL * qq + s;
-    float v = 0.f;
-    if (cout < Cout) {
-      int k[3];
-      for (int dim = 0; dim < 3; ++dim) {
-        const int pb = (cls >> dim) & 1, db = (delta >> dim) & 1;   // dim 0 = w, 1 = h, 2 = d
-        k[dim] = pb == 0 ? 1 : (db == 0 ? 2 : 0);
-      }
-      v = w[((size_t)cin * Cout + cout) * 27 + (k[2] * 3 + k[1]) * 3 + k[0]];
-    }
-    wp[i] = v;
-  }
-}
-
 template <int CIN, int COUT, int MODE, int MT, int SPLITK>
 int launch_conv(ConvParams& p, hipStream_t st) {
   const long long per_blk = (SPLITK > 1 ? 1LL : 4LL) * MT * 16;
@@ -424,8 +388,7 @@ extern "C" int64_t mdf_conv3d_packed_size(int Cin, int Cout) {
   int64_t plain = (int64_t)27 * Cin * (((Cout + 15) / 16) * 16);
   if (rw_of(Cout)) plain += (int64_t)9 * (3 + rw_of(Cout) - 1) * Cin * 16;   // + the w-phase packing behind the plain one
   if (wino_built(Cin, Cout)) plain += (int64_t)48 * Cin * (((Cout + 15) / 16) * 16);   // + the Winograd-domain weights
-  const int64_t transposed = (int64_t)18 * Cin * (((2 * Cout + 15) / 16) * 16)      // v1 form
-                             + (int64_t)27 * Cin * (((Cout + 15) / 16) * 16);      // + LDS-staged 8-class form behind it
+  const int64_t transposed = (int64_t)18 * Cin * (((2 * Cout + 15) / 16) * 16);
   return plain > transposed ? plain : transposed;   // one size serves both packings
 }
 
@@ -435,8 +398,6 @@ extern "C" int mdf_conv3d_pack_weights(const float* w, float* wpack, int Cin, in
   MDF_REQUIRE(Cout >= 1 && Cout <= 64, "Cout=%d out of range", Cout);
   if (transposed) {
     hipLaunchKernelGGL(pack_weights_tr_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, wpack, Cin, Cout);
-    hipLaunchKernelGGL(pack_weights_trlds_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w,
-                       wpack + (size_t)18 * Cin * (((2 * Cout + 15) / 16) * 16), Cin, Cout);
   } else {
     hipLaunchKernelGGL(pack_weights_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, wpack, Cin, Cin, Cout, 27, 0);
     if (rw_of(Cout))
@@ -519,15 +480,6 @@ extern "C" int mdf_conv3d_fwd(const float* x, const float* wpack, const float* a
     const char* e = getenv("MDF_CONV_LDS_MIN_VOXELS");
     return e ? atoll(e) : 150000LL;
   }();
-  static const long long tr_lds_min = [] {  // transposed layers: input voxels from which the LDS-staged form is used
-    const char* e = getenv("MDF_CONVT_LDS_MIN_VOXELS");
-    return e ? atoll(e) : 150000LL;
-  }();
-  if (m == kTr && p.m_total >= tr_lds_min) {
-    const int rc = mdf_conv_lds_dispatch(x, wpack + (size_t)18 * Cin * (((2 * Cout + 15) / 16) * 16), alpha, beta, res, 1.0f, nullptr, y, B, Di, Hi,
-                                         Wi, Cin, Cin, Cout, 2, 2, 1, relu, stream, 0, 0);
-    if (rc != MDF_EUNSUPPORTED) return rc;
-  }
   if (m == kS1 && p.m_total >= lds_min) {  // large stride-1 layers: LDS-staged planes (conv_lds.hip)
     const int rc = mdf_conv_lds_dispatch(x, wpack, alpha, beta, res, 1.0f, nullptr, y, B, Di, Hi, Wi, Cin, Cin, Cout, 3, 3, 1, relu, stream, 0, 0);
     if (rc != MDF_EUNSUPPORTED) return rc;

@@ -134,9 +134,7 @@ struct Cfg {
   static constexpr int PLANE = CIN * S;  // floats
   static constexpr int NFILL = (NG * PH * PW + 255) / 256;
   static constexpr int RING = (KD > 1) ? KD : 2;  // 3-D: rolling window of KD planes; 2-D: double-buffered tiles
-  // KD = KHW = 2 marks the transposed form (ConvTranspose3d k3 s2 p1 op1 as 2x2x2 input taps -> 8 output parities, step_tr)
-  static constexpr bool TR = (KD == 2 && KHW == 2);
-  static constexpr int NSTEP = WINO ? KD * 16 * NCH : (TR ? 27 * NCH : KD * KHW * KW * NCH);   // MFMA pipeline steps per output row-tile (tap x cin chunk)
+  static constexpr int NSTEP = WINO ? KD * 16 * NCH : KD * KHW * KW * NCH;   // MFMA pipeline steps per output row-tile (tap x cin chunk)
   // small layers keep ALL their weight fragments in registers for the whole kernel (<= 40 VGPRs; beyond that occupancy drops and it is a loss, measured) instead of re-fetching
   // them from L1 for every tile: with 8-16 MFMAs per step there is nothing to hide that round trip behind
   static constexpr bool WREG = (KD == 1) && !WINO && (NSTEP * NT * KPL <= 40);
@@ -295,131 +293,11 @@ __device__ __forceinline__ void step(const float* const (&planes)[KD], __amdgpu_
   }
 }
 
-// ---- transposed form --------------------------------------------------------------------------------------------
-// ConvTranspose3d(k3, s2, p1, op1): output o = 2i - 1 + k per dim, so output parity 0 takes (k=1, i=m) and parity 1 takes
-// (k=2, i=m) and (k=0, i=m+1).  Over the INPUT grid this is a 2x2x2-tap stencil (delta in {0,1}^3) feeding 8 output parity
-// classes p, tap delta contributing to the classes p >= delta (componentwise): 27 (delta, p) pairs = the 27 kernel taps,
-// no structural zeros.  One LDS tile of input voxels, eight accumulator sets, each B fragment read once per delta.
-// Weight fragments are packed in exactly the order this loop walks them (pack_weights_trlds_kernel, conv3d.hip).
-constexpr int tr_ncls(int delta) { return 1 << (3 - ((delta & 1) + ((delta >> 1) & 1) + ((delta >> 2) & 1))); }
-constexpr int tr_cls(int delta, int j) {   // j-th class p (ascending) with (p & delta) == delta
-  int n = 0;
-  for (int p = 0; p < 8; ++p)
-    if ((p & delta) == delta) { if (n == j) return p; ++n; }
-  return -1;
-}
-struct TrStep { int delta, ch, cls, first; };   // first: this step starts a new (delta, chunk) -> needs a new B fragment
-template <int NCH> constexpr TrStep tr_step(int i) {
-  int n = 0;
-  for (int delta = 0; delta < 8; ++delta)
-    for (int ch = 0; ch < NCH; ++ch)
-      for (int j = 0; j < tr_ncls(delta); ++j) { if (n == i) return TrStep{delta, ch, tr_cls(delta, j), j == 0}; ++n; }
-  return TrStep{0, 0, 0, 0};
-}
-template <int NCH> constexpr int tr_bindex(int i) {   // index of the (delta, chunk) group step i belongs to
-  int n = 0, g = -1;
-  for (int delta = 0; delta < 8; ++delta)
-    for (int ch = 0; ch < NCH; ++ch) {
-      ++g;
-      for (int j = 0; j < tr_ncls(delta); ++j) { if (n == i) return g; ++n; }
-    }
-  return g;
-}
-
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {
     f(std::integral_constant<int, I>{});
     static_for<I + 1, N>(f);
-  }
-}
-
-template <typename C, int COUT, int MTL>
-__device__ __forceinline__ void step_tr(const float* const (&planes)[2], __amdgpu_buffer_rsrc_t wres, int wvoff, const LdsConvParams& p,
-                                        int b, int d, int h, int w0, int q, int n16, const float (&wfirst)[2][C::NT][C::KPL]) {
-  constexpr int KPL = C::KPL, NCH = C::NCH, NT = C::NT, S = C::S, PW = C::PW, NSTEP = C::NSTEP;
-  typedef typename VecT<KPL>::type vec_t;
-  extern __shared__ __attribute__((aligned(16))) float lds_base_[];
-  const float* epi_tab = lds_base_ + C::EPI_OFF;
-  f32x4 acc[8][MTL][NT];
-#pragma unroll
-  for (int c = 0; c < 8; ++c)
-#pragma unroll
-    for (int t = 0; t < MTL; ++t)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[c][t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  constexpr int AHEAD_A = 2, NA = 3;
-  float af[NA][NT][KPL], bf[2][MTL][KPL];
-  auto load_a = [&](int i, int buf) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) buf_load_to<KPL>(wres, wvoff, (i * NT + nt) * (64 * KPL * 4), af[buf][nt]);
-  };
-  auto load_b = [&](int delta, int ch, int buf) {
-    const int dw = delta & 1, dh = (delta >> 1) & 1, dd = delta >> 2;
-#pragma unroll
-    for (int t = 0; t < MTL; ++t)
-      vec_to<KPL>(*reinterpret_cast<const vec_t*>(planes[dd] + ((ch * 4) * S + dh * PW + dw + t * 16) * KPL), bf[buf][t]);
-  };
-#pragma unroll
-  for (int i = 0; i < AHEAD_A; ++i)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int k = 0; k < KPL; ++k) af[i % NA][nt][k] = wfirst[i][nt][k];
-  load_b(0, 0, 0);
-  static_for<0, NSTEP>([&](auto ic) {
-    constexpr int i = decltype(ic)::value;
-    constexpr TrStep st = tr_step<NCH>(i);
-    if constexpr (i + AHEAD_A < NSTEP) load_a(i + AHEAD_A, (i + AHEAD_A) % NA);
-    if constexpr (i + 1 < NSTEP) {
-      constexpr TrStep nx = tr_step<NCH>(i + 1);
-      if constexpr (nx.first != 0) load_b(nx.delta, nx.ch, tr_bindex<NCH>(i + 1) & 1);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    constexpr int bb = tr_bindex<NCH>(i) & 1;
-#pragma unroll
-    for (int s = 0; s < KPL; ++s)
-#pragma unroll
-      for (int t = 0; t < MTL; ++t)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[st.cls][t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i % NA][nt][s], bf[bb][t][s], acc[st.cls][t][nt], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  });
-  // epilogue: class (pd,ph,pw) of input voxel (d,h,w) is output voxel (2d+pd, 2h+ph, 2w+pw)
-  const int Do = 2 * p.D, Ho = 2 * p.H, Wo = 2 * p.W;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int c0 = nt * 16 + 4 * q;
-    if (c0 >= COUT) continue;
-    float al_l[4], be_l[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      al_l[k] = epi_tab[c0 + k];
-      be_l[k] = epi_tab[64 + c0 + k];
-    }
-#pragma unroll
-    for (int t = 0; t < MTL; ++t) {
-      const int iw = w0 + t * 16 + n16;
-      if (iw >= p.W) continue;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const int pw = c & 1, ph = (c >> 1) & 1, pd = c >> 2;
-        const size_t oi = ((((size_t)b * Do + 2 * d + pd) * Ho + 2 * h + ph) * Wo + 2 * iw + pw) * COUT + c0;
-        float o[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          o[k] = acc[c][t][nt][k] * al_l[k] + be_l[k];
-          if (p.relu) o[k] = fmaxf(o[k], 0.f);
-        }
-        if (p.res) {
-          const float4 rr = *reinterpret_cast<const float4*>(p.res + oi);
-          o[0] = rr.x + o[0] * p.res_scale; o[1] = rr.y + o[1] * p.res_scale;
-          o[2] = rr.z + o[2] * p.res_scale; o[3] = rr.w + o[3] * p.res_scale;
-        }
-        *reinterpret_cast<float4*>(p.y + oi) = make_float4(o[0], o[1], o[2], o[3]);
-      }
-    }
   }
 }
 
@@ -874,11 +752,6 @@ __global__ __launch_bounds__(256, ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 :
         const size_t row_vox = (((size_t)b * p.D + d) * p.Ho + (h0 + wave)) * p.Wo;
         if constexpr (C::WINO) {
           step_wino<C, COUT, 3>(planes, wres, wvoff, p, b, d, h0 + 2 * wave, w0, q, n16, wfirst);
-        } else if constexpr (C::TR) {
-          switch (mt_live) {
-            case 1: step_tr<C, COUT, 1>(planes, wres, wvoff, p, b, d, h0 + wave, w0, q, n16, wfirst); break;
-            default: if (MT >= 2) step_tr<C, COUT, (MT >= 2 ? 2 : 1)>(planes, wres, wvoff, p, b, d, h0 + wave, w0, q, n16, wfirst); break;
-          }
         } else {
           switch (mt_live) {
             case 1: step<C, KD, KHW, SHW, COUT, 1>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be, wfirst); break;
@@ -1058,12 +931,6 @@ int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha
   const int pad = (KHW - 1) / 2;
   p.Ho = (H + 2 * pad - KHW) / stride + 1;
   p.Wo = (W + 2 * pad - KHW) / stride + 1;
-  if (KD == 2 && KHW == 2) {   // transposed form: tiles live on the input grid, y is [B,2D,2H,2W,Cout]
-    p.Ho = H; p.Wo = W;
-    // (16 -> 8 is HBM-bound -- 12 flop/B -- and its v1 form already pairs the two w-parities in one MFMA: no gain, measured)
-    LDS_CASE(32, 32, 16, 2, 2, 1, 2) LDS_CASE(64, 64, 32, 2, 2, 1, 1)
-    return MDF_EUNSUPPORTED;
-  }
   // 3-D stride-1 layers with 16 output channels: Winograd F(2x2,3x3) in (h,w)
   LDS_CASE_WG(16, 16) LDS_CASE_WG(32, 16) LDS_CASE_WG(32, 32) LDS_CASE_WG(16, 8)
   LDS_CASE_WG2(16, 16) LDS_CASE_WG2(32, 32)

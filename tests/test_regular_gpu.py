@@ -70,9 +70,9 @@ def test_conv3d_layer_lds_kernels(cin, cout, shape):
 
 @pytest.mark.parametrize("cin,cout", [(32, 16), (16, 8), (64, 32)])
 @pytest.mark.parametrize("shape", [(1, 6, 130, 201), (2, 4, 101, 187)])
-def test_conv_transpose3d_layer_lds_kernel(cin, cout, shape):
-    """ConvTranspose3d(k3,s2,p1,op1)+BN+ReLU+skip on >= 150 000 input voxels: the LDS-staged 8-parity-class form
-    (conv_lds.hip step_tr); ragged tiles, odd widths, D not a multiple of the depth chunk, batch 2."""
+def test_conv_transpose3d_layer_large_volumes(cin, cout, shape):
+    """ConvTranspose3d(k3,s2,p1,op1)+BN+ReLU+skip on >= 150 000 input voxels (big-tile launch of conv3d_kernel, prefetched
+    residual); ragged tiles, odd widths, batch 2."""
     b, d, h, w = shape
     assert b * d * h * w >= 150000
     g = torch.Generator().manual_seed(cin + cout + w)
