@@ -115,6 +115,7 @@ struct Cfg {
   static_assert(RW == 1 || WG == 1 || (SHW == 1 && COUT * RW <= 16 && COUT % 4 == 0), "w-phase form: stride 1, RW*Cout <= 16, Cout % 4 == 0");
   static_assert(WG == 0 || ((KD == 3 || KD == 1) && KHW == 3 && SHW == 1 && RW == 2 && MT == 1 && CIN % 16 == 0 && COUT % 4 == 0), "Winograd form: 3x3(x3) stride 1, RW = 2, MT = 1");
   static constexpr bool WINO = (WG == 1);
+  static constexpr int NTP = ((COUT + 15) / 16 > 2) ? 2 : (COUT + 15) / 16;   // Winograd: n-tiles per pass over K (16 accumulators each)
   static constexpr int CIN_ = CIN;
   static constexpr int RWF = RW;
   static constexpr int KW = KHW + RW - 1;       // taps along w
@@ -133,7 +134,9 @@ struct Cfg {
   static constexpr int S = round_s(PH * PW);
   static constexpr int PLANE = CIN * S;  // floats
   static constexpr int NFILL = (NG * PH * PW + 255) / 256;
-  static constexpr int RING = (KD > 1) ? KD : 2;  // 3-D: rolling window of KD planes; 2-D: double-buffered tiles
+  // 3-D: rolling window of KD planes; 2-D: double-buffered tiles -- except the 64-channel Winograd form, whose 10x34 tile
+  // (87 KB) fits once: single buffer, the next tile's loads wait in registers during the (long) compute
+  static constexpr int RING = (KD > 1) ? KD : ((WINO && CIN >= 64) ? 1 : 2);
   static constexpr int NSTEP = WINO ? KD * 16 * NCH : KD * KHW * KW * NCH;   // MFMA pipeline steps per output row-tile (tap x cin chunk)
   // small layers keep ALL their weight fragments in registers for the whole kernel (<= 40 VGPRs; beyond that occupancy drops and it is a loss, measured) instead of re-fetching
   // them from L1 for every tile: with 8-16 MFMAs per step there is nothing to hide that round trip behind
@@ -142,7 +145,7 @@ struct Cfg {
   static constexpr bool EPI_REG = (KD == 1) && (NT <= 2);
   static constexpr int WN = WREG ? NSTEP : 1;
   // 2-D: issue the next tile's global loads before this tile's MFMAs when the staging registers are cheap
-  static constexpr bool EARLY2 = (KD == 1) && !WINO && (NFILL * KPL <= EARLY2_MAX_REGS);
+  static constexpr bool EARLY2 = (KD == 1) && ((!WINO && (NFILL * KPL <= EARLY2_MAX_REGS)) || (WINO && CIN >= 64));
   // + the broadcast slot of the item id (16 B) + the epilogue table: alpha[64], beta[64] (read per step from LDS instead of
   // from global memory: the per-call L1/L2 round trip was ~1000 exposed cycles per depth step, in-kernel stamps)
   static constexpr int EPI_OFF = RING * PLANE + 4;   // floats
@@ -306,9 +309,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <typename C, int COUT, int NKD>
 __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __amdgpu_buffer_rsrc_t wres, int wvoff, const LdsConvParams& p,
                                           int b, int d, int h, int w0, int q, int n16, const float (&wfirst)[2][C::NT][C::KPL]) {
-  constexpr int NCH = C::NCH, NT = C::NT, S = C::S, PW = C::PW;
+  constexpr int NCH = C::NCH, NTALL = C::NT, NT = C::NTP, S = C::S, PW = C::PW;
   extern __shared__ __attribute__((aligned(16))) float lds_base_[];
   const float* epi_tab = lds_base_ + C::EPI_OFF;
+  // Cout > 32: two passes over K with 2 n-tiles each (16 accumulators x 4 n-tiles would be the whole register file); the
+  // patch is re-read and re-transformed per pass, which costs ~15 % of a pass
+#pragma unroll 1
+  for (int pass = 0; pass < NTALL / NT; ++pass) {
   f32x4 acc[16][NT];
 #pragma unroll
   for (int ab = 0; ab < 16; ++ab)
@@ -322,11 +329,11 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __a
   float af[NA][NT][4];
   auto load_a = [&](int i, int buf) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) buf_load_to<4>(wres, wvoff, (i * NT + nt) * (64 * 4 * 4), af[buf][nt]);
+    for (int nt = 0; nt < NT; ++nt) buf_load_to<4>(wres, wvoff, (i * NTALL + pass * NT + nt) * (64 * 4 * 4), af[buf][nt]);
   };
 #pragma unroll
   for (int i = 0; i < AHEAD; ++i) {
-    if (i < 2) {
+    if (i < 2 && pass == 0 && C::CIN_ < 64) {   // (pass 0 starts with the kernel-resident fragments; not kept for 64 channels: registers)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -340,7 +347,7 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __a
   // wave's LDS latency and transform arithmetic: software-pipeline them into the MFMA loop instead -- while group g
   // multiplies, the patch of group g+1 is read (one element per ab step), its row pass runs column by column as the reads
   // land, and its column pass runs row by row right before the four MFMA steps that need that row.
-  constexpr bool PIPE = (C::CIN_ >= 32);
+  constexpr bool PIPE = (C::CIN_ >= 32 && C::CIN_ < 64);   // (64 channels: two passes x 128 accumulator registers leave no room for the second patch buffer)
   auto read_elem = [&](f32x2_t (&v)[16][2], int kd, int ch, int e) {     // e = j*4 + i: column-major so a column completes every 4 reads
     const int i = e & 3, j = e >> 2;
     const float4 t = *reinterpret_cast<const float4*>(planes[kd] + ((ch * 4) * S + i * PW + j) * 4);
@@ -417,7 +424,7 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __a
   // epilogue: Y = A^T M A per cout, A^T = [1 1 1 0; 0 1 -1 -1]; outputs (h + pr, w0 + 2*n16 + r)
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int c0 = nt * 16 + 4 * q;
+    const int c0 = (pass * NT + nt) * 16 + 4 * q;
     if (c0 >= COUT) continue;
     float y[2][2][4];
 #pragma unroll
@@ -468,6 +475,7 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __a
       }
     }
   }
+  }  // pass
 }
 
 template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT, int RW = 1, int WG = 0>
@@ -511,7 +519,7 @@ __global__ __launch_bounds__(256, ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 :
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int nt = 0; nt < C::NT; ++nt) {
-      if constexpr (!C::WREG) buf_load_to<KPL>(wres, wvoff, (i * C::NT + nt) * (64 * KPL * 4), wfirst[i][nt]);   // (past the end reads 0)
+      if constexpr (!C::WREG && !(C::WINO && CIN >= 64)) buf_load_to<KPL>(wres, wvoff, (i * C::NT + nt) * (64 * KPL * 4), wfirst[i][nt]);   // (past the end reads 0)
       else {
 #pragma unroll
         for (int k = 0; k < KPL; ++k) wfirst[i][nt][k] = 0.f;
@@ -613,7 +621,7 @@ __global__ __launch_bounds__(256, ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 :
       t_pro += STAMP() - ts1;
 #endif
       for (int tl = t_begin; tl < t_end; ++tl) {
-        const int slot = (tl - t_begin) & 1;
+        const int slot = (C::RING == 1) ? 0 : ((tl - t_begin) & 1);
         const bool row_live2 = (th0 + wave * C::WROWS) < p.Ho;
         const int cols2 = (min(p.Wo - tw0, C::TWO) + RW - 1) / RW;   // live MFMA columns
         const int mt_live2 = row_live2 ? (cols2 + 15) / 16 : 0;
@@ -657,8 +665,9 @@ __global__ __launch_bounds__(256, ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 :
 #pragma unroll
             for (int k = 0; k < C::NFILL; ++k) pf[k] = load2(tid + k * 256, tb, th0, tw0);
           }
+          if constexpr (C::RING == 1) __syncthreads();   // single buffer: everybody is done reading this tile
 #pragma unroll
-          for (int k = 0; k < C::NFILL; ++k) store2(tid + k * 256, slot ^ 1, pf[k]);
+          for (int k = 0; k < C::NFILL; ++k) store2(tid + k * 256, (C::RING == 1) ? 0 : (slot ^ 1), pf[k]);
           __syncthreads();
         }
 #ifdef MDF_STAMPS
@@ -933,7 +942,7 @@ int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha
   p.Wo = (W + 2 * pad - KHW) / stride + 1;
   // 3-D stride-1 layers with 16 output channels: Winograd F(2x2,3x3) in (h,w)
   LDS_CASE_WG(16, 16) LDS_CASE_WG(32, 16) LDS_CASE_WG(32, 32) LDS_CASE_WG(16, 8)
-  LDS_CASE_WG2(16, 16) LDS_CASE_WG2(32, 32)
+  LDS_CASE_WG2(16, 16) LDS_CASE_WG2(32, 32) LDS_CASE_WG2(64, 64)
   // Cout < 16: w-phase form (RW output voxels per MFMA column)
   LDS_CASE_RW(16, 16, 8, 3, 3, 1, 2, 2) LDS_CASE_RW(8, 8, 8, 3, 3, 1, 2, 2)
   LDS_CASE_RW(16, 16, 4, 1, 3, 1, 1, 4) LDS_CASE_RW(8, 8, 4, 1, 3, 1, 1, 4)
