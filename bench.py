@@ -158,12 +158,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("MDF_BENCH_IN_FLIGHT", "3")),
+    from mdfnet_hip.pipeline import DEFAULT_IN_FLIGHT
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("MDF_BENCH_IN_FLIGHT", DEFAULT_IN_FLIGHT)),
                     help="items in flight on that many HIP streams (the eval driver's pipelining); 1 = strictly one at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, before this process touches the GPU (no HIP call
+        # has happened yet; the children are fresh subprocesses, nothing is exec'ed over an initialised process)
+        from mdfnet_hip import shard
+        raise SystemExit(shard.launch_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -43,6 +43,11 @@ extern "C" {
 
 int mdf_abi_version(void);
 const char* mdf_last_error(void);
+/* The conv kernels keep one device-side work-item counter pair per HIP stream that has launched them (128 slots per
+ * process; launches on one stream are ordered, launches on different streams may overlap).  A long-lived process that
+ * destroys streams hands their slots back with this call (before hipStreamDestroy, with no conv launch of this library
+ * still running on the stream).  Always returns MDF_OK; unknown streams are ignored.                               */
+int mdf_release_stream(void* stream);
 
 /* ---- a4  homo_warping (net/unit/base.py:85-126) ---------------------------------------------
  * Plane-sweep homography warp of ONE source feature map; bilinear, zero padding, the reference's

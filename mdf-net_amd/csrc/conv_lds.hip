@@ -850,8 +850,13 @@ int launch_lds(LdsConvParams& p, hipStream_t st) {
     p.n_items = (int)g;                          // = grid size (static partition)
     p.dch = 1; p.dchunks = 1;
   }
-  static bool attr_done = false;  // benign race: the call is idempotent
-  if (!attr_done) {
+  // the dynamic-LDS attribute is a per-DEVICE property of the function: one flag per device (several GPUs in one
+  // process, DataParallel-style).  Benign race: the call is idempotent.
+  static bool attr_done_dev[64] = {};
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  bool& attr_done = attr_done_dev[(dev_id >= 0 && dev_id < 64) ? dev_id : 0];
+  if (!attr_done || dev_id >= 64) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW, WG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
     if (e != hipSuccess) return mdf::fail(MDF_EHIP, "hipFuncSetAttribute(dynamic LDS %zu): %s", C::LDS_BYTES, hipGetErrorString(e));
@@ -892,16 +897,31 @@ extern "C" int mdf_debug_read_stamps(unsigned long long* out8, int reset) {
   if (Cin == ci && Cin_mem == cim && Cout == co && KD == kd && KHW == k && stride == s)          \
     return launch_lds<ci, cim, co, kd, k, s, mt>(p, (hipStream_t)stream);
 
-// stream -> scheduler slot (launches on one stream are ordered, so they can share a slot; different streams must not)
+// stream -> scheduler slot (launches on one stream are ordered, so they can share a slot; different streams must not).
+// A slot stays bound to its stream handle until mdf_release_stream(stream) gives it back (long-lived processes that
+// create and destroy streams); the table holds kSchedSlots live streams.
+namespace {
+std::mutex g_slot_mu;
+void* g_slot_stream[kSchedSlots];
+bool g_slot_used[kSchedSlots];
+}  // namespace
+
 static int sched_slot_of(void* stream) {
-  static std::mutex mu;
-  static void* known[kSchedSlots];
-  static int n_known = 0;
-  std::lock_guard<std::mutex> lock(mu);
-  for (int i = 0; i < n_known; ++i)
-    if (known[i] == stream) return i;
-  if (n_known < kSchedSlots) { known[n_known] = stream; return n_known++; }
-  return -1;
+  std::lock_guard<std::mutex> lock(g_slot_mu);
+  int free_slot = -1;
+  for (int i = 0; i < kSchedSlots; ++i) {
+    if (g_slot_used[i] && g_slot_stream[i] == stream) return i;
+    if (!g_slot_used[i] && free_slot < 0) free_slot = i;
+  }
+  if (free_slot >= 0) { g_slot_used[free_slot] = true; g_slot_stream[free_slot] = stream; }
+  return free_slot;
+}
+
+extern "C" int mdf_release_stream(void* stream) {
+  std::lock_guard<std::mutex> lock(g_slot_mu);
+  for (int i = 0; i < kSchedSlots; ++i)
+    if (g_slot_used[i] && g_slot_stream[i] == stream) { g_slot_used[i] = false; g_slot_stream[i] = nullptr; return MDF_OK; }
+  return MDF_OK;   // never used by a conv launch: nothing to release
 }
 
 // w-phase variants read the expanded packing that conv3d.hip appends after the plain one (mdf_conv_rw_of / pack functions)

@@ -1,7 +1,7 @@
 """Evaluation driver (counterpart of the reference's eval.py:10-89): same CLI (-p/-d/-s), same outputs
 (<out>/<scan>/depth_est/%08d.pfm|.png, <out>/<scan>/confidence/%08d.pfm), same per-item print line — plus:
-one process per GPU with the item list sharded over ranks (`torchrun --nproc-per-node N eval.py ...`), two items in flight
-on two HIP streams (the printed per-item time is the interval between completions), the cross-item feature cache, and no
+one process per GPU with the item list sharded over ranks (`torchrun --nproc-per-node N eval.py ...`), three items in flight
+on three HIP streams (pipeline.DEFAULT_IN_FLIGHT, the same constant bench.py uses) (the printed per-item time is the interval between completions), the cross-item feature cache, and no
 collective on the data path."""
 import argparse
 import logging
@@ -16,25 +16,42 @@ from tools.data_io import save_pfm, write_depth_img
 
 
 class FeatureCache(dict):
-    """Feature pyramids per (scan, view id), bounded (a 1600x1184 image's pyramid is 53 MB; 64 entries = 3.4 GB of 288)."""
+    """Feature pyramids per (scan, view id), bounded and least-recently-used (a 1600x1184 image's pyramid is 53 MB; 64
+    entries = 3.4 GB of 288).  `pin(keys)` names the views of the item being assembled: they are never evicted, so an item
+    with more views than `max_items` (Tanks&Temples, nviews=11, small caches) still finds all its pyramids."""
 
     def __init__(self, max_items=64):
         super().__init__()
         self.max_items = max_items
+        self.pinned = ()
+
+    def pin(self, keys):
+        self.pinned = tuple(keys)
+
+    def __getitem__(self, k):
+        v = super().pop(k)                      # move to the young end on a hit
+        super().__setitem__(k, v)
+        return v
 
     def __setitem__(self, k, v):
+        if k in self:
+            super().pop(k)
         while len(self) >= self.max_items:
-            del self[next(iter(self))]          # oldest first
+            victim = next((old for old in self if old not in self.pinned), None)
+            if victim is None:
+                break                           # everything left belongs to the current item: grow rather than fail
+            del self[victim]
         super().__setitem__(k, v)
 
 
-def run_eval(model, dataset, device, output_path, rank=0, world=1, nworks=1, log=print, cache_features=True, in_flight=2):
+def run_eval(model, dataset, device, output_path, rank=0, world=1, nworks=1, log=print, cache_features=True, in_flight=None):
     """Shard `dataset` over ranks, run `model` item by item, write PFM/PNG.  Returns (n_items_this_rank, seconds).
     With cache_features (and a model that accepts it) every image goes through the feature pyramid once per scan instead
     of once per item it appears in.  in_flight > 1 issues items round-robin on that many HIP streams
     (mdfnet_hip/pipeline.py): the next item fills the idle tails of the current one and the PFM writes overlap with GPU
     work.  Outputs are identical either way."""
-    from mdfnet_hip.pipeline import InFlight
+    from mdfnet_hip.pipeline import DEFAULT_IN_FLIGHT, InFlight
+    in_flight = DEFAULT_IN_FLIGHT if in_flight is None else in_flight
     idx = shard.shard_items(len(dataset), rank, world)
     loader = DataLoader(Subset(dataset, idx), batch_size=1, num_workers=nworks, shuffle=False,
                         pin_memory=(device.type == "cuda"), drop_last=False)

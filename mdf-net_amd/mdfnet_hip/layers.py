@@ -6,15 +6,35 @@ from . import ops
 
 
 class _Folded:
+    """One cached, derived device value (packed weights, folded BN, ...).  The value is built by kernels enqueued on the
+    stream current at build time; items in flight on OTHER streams (pipeline.InFlight) may consume it right away, so the
+    build records an event and every consumer stream waits for it once -- until the event has completed, after which the
+    check is a single `is None`."""
+
     def __init__(self):
-        self.key, self.val = None, None
+        self.key, self.val, self.ev, self.seen = None, None, None, ()
 
     def get(self, tensors, build):
         key = tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors if t is not None)
+        dev = next((t.device for t in tensors if t is not None and t.is_cuda), None)
         if key != self.key:
             with torch.no_grad():
                 self.val = build()
+            self.ev, self.seen = None, ()
+            if dev is not None:
+                cur = torch.cuda.current_stream(dev)
+                self.ev = torch.cuda.Event()
+                self.ev.record(cur)
+                self.seen = (cur.cuda_stream,)
             self.key = key
+        elif self.ev is not None:
+            if self.ev.query():
+                self.ev = None                      # build finished: nothing to order against any more
+            else:
+                cur = torch.cuda.current_stream(dev)
+                if cur.cuda_stream not in self.seen:
+                    cur.wait_event(self.ev)
+                    self.seen = self.seen + (cur.cuda_stream,)
         return self.val
 
 

@@ -4,6 +4,7 @@ PyTorch is plumbing here: it owns device memory and the stream; every operator b
 (or a few) hand-written HIP kernels.  No fallback: tensors must live on a HIP device.
 """
 import ctypes
+import threading
 
 import torch
 
@@ -75,10 +76,47 @@ def nhwc(t):
     return t.float().contiguous(memory_format=torch.channels_last)
 
 
+# --------------------------------------------------------------------------- recorded host values (parity tests)
+# The few host-side control-plane computations (4x4 inverse / matmul, the gauss-fit row, log of the threshold) go through
+# LAPACK/BLAS/libm, whose code paths differ per x86 host at cond ~1e14.  The e2e goldens therefore carry
+# the values the REAL reference computed on the build host (oracle/gen_golden.py:HostValueRecorder); inside
+# `recorded_host_values(...)` the host functions below hand those out instead of computing them, so the device path can be
+# compared with the golden depth at the metric's own 1e-3 bar on any host.  Never active in the product path.
+_recorded = threading.local()
+
+
+class recorded_host_values:
+    def __init__(self, projs=None, fit_row=None, log_thresh=None, cams=None):
+        """projs: list (per aggregate call) of [n_src,B,12]; cams: list (per scale call) of [B,V,3,4]; fit_row [B,D];
+        log_thresh: {mode: float}."""
+        self.v = {"projs": list(projs or []), "cams": list(cams or []), "fit_row": fit_row, "log_thresh": log_thresh or {}}
+
+    def __enter__(self):
+        _recorded.v = self.v
+        return self
+
+    def __exit__(self, *exc):
+        _recorded.v = None
+
+
+def recorded(kind, key=None):
+    v = getattr(_recorded, "v", None)
+    if v is None:
+        return None
+    if kind in ("projs", "cams"):
+        return torch.as_tensor(v[kind].pop(0)).float().contiguous() if v[kind] else None
+    if kind == "log_thresh":
+        return v["log_thresh"].get(key)
+    return None if v[kind] is None else torch.as_tensor(v[kind]).float().contiguous()
+
+
 def relative_projections(ref_proj, src_projs):
     """HOST side of homo_warping (base.py:98): (src_proj @ inverse(ref_proj))[:3,:4] for every source
     view, computed on the CPU with the reference's own torch calls so the kernel consumes the same
     12 floats as the oracle (GPU and CPU `torch.inverse` use different solvers).  -> [n_src,B,12] CPU."""
+    pinned = recorded("projs")
+    if pinned is not None:
+        return pinned
     ref = ref_proj.detach().to("cpu", torch.float32)
     with _single_thread():
         inv = torch.inverse(ref)
@@ -216,6 +254,9 @@ def gauss1_fit_row(depth_hypos):
     2x2-pixel replica: verified bit-identical to the per-pixel matrices of any larger image, for any batch size
     (a 1x1 replica is NOT: degenerate strides take another path).  Cached by value: the row only depends on the
     hypotheses, i.e. on (depth_min, depth_max, D), which is constant for a whole dataset.  -> [B,D] CPU float32."""
+    pinned = recorded("fit_row")
+    if pinned is not None:
+        return pinned
     hyp = depth_hypos.detach().to("cpu", torch.float32)
     b, d = hyp.shape[:2]
     key = (b, d, hyp.numpy().tobytes())

@@ -5,8 +5,12 @@ second item on another stream fills those gaps: +11 % (2 streams) / +15 % (3) vi
 (scripts/bench_streams.py).  Used by eval.py (whole-scan runs) and bench.py.  The conv kernels keep one scheduler slot per
 stream (csrc/conv_lds.hip), every other kernel is stateless."""
 import collections
+import os
 
 import torch
+
+# items in flight used by BOTH the eval driver (eval.py:run_eval) and bench.py, so the benchmark times what eval issues
+DEFAULT_IN_FLIGHT = int(os.environ.get("MDF_IN_FLIGHT", "3"))
 
 
 class InFlight:

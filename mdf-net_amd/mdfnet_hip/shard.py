@@ -1,5 +1,8 @@
 """One process per GPU: shard independent eval items over ranks (no data-path collective) and reduce timings."""
 import os
+import socket
+import subprocess
+import sys
 
 import torch
 import torch.distributed as dist
@@ -48,3 +51,43 @@ def sum_over_ranks(value, device="cpu"):
 def barrier():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def rank_environments(n, port=None, base=None):
+    """The environment of each of the n rank processes of one node (what torch.distributed.run would set)."""
+    port = port or _free_port()
+    envs = []
+    for r in range(n):
+        e = dict(os.environ if base is None else base)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                 MASTER_PORT=str(port))
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        e.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+        envs.append(e)
+    return envs
+
+
+def launch_ranks(n, argv, port=None, timeout=None):
+    """Self-launch: start n FRESH child processes (one per GPU) running `argv`, relay rank 0's stdout, return the worst
+    exit status.  Must be called before the calling process has touched the GPU: the parent never initialises HIP and
+    never execs -- the children are ordinary subprocesses (a process that has initialised the GPU must not be replaced)."""
+    procs = []
+    for r, env in enumerate(rank_environments(n, port)):
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=env,
+                                      stdout=(None if r == 0 else subprocess.DEVNULL)))
+    status = 0
+    try:
+        for p in procs:
+            rc = p.wait(timeout=timeout)
+            status = status or rc
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return status

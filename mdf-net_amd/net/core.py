@@ -25,6 +25,8 @@ class CoreNet(torch.nn.Module):
     def _pyramids(self, imgs, feature_cache, view_keys):
         nb, nv = imgs.shape[:2]
         if feature_cache is not None and view_keys is not None and nb == 1 and not self.training:
+            if hasattr(feature_cache, "pin"):
+                feature_cache.pin(view_keys)                             # a bounded cache must keep this item's views
             missing = [v for v in range(nv) if view_keys[v] not in feature_cache]
             if missing:
                 f = self.Backbone(imgs[0, missing])                      # only the images not seen yet, batched

@@ -46,5 +46,7 @@ class HyposByFit(nn.Module):
                 row = ops.gauss1_fit_row(hostmirror.get(depth_hypos)).to(depth.device, non_blocking=True)
             s = ops.hypos_fit(mode, prob_volume, depth, depth_hypos, row)
             rng = hostmirror.get(depth_range).float().contiguous().to(depth.device, non_blocking=True)
-            log_thr = float(torch.log(self.prob_thresh))
+            log_thr = ops.recorded("log_thresh", mode)
+            if log_thr is None:
+                log_thr = float(torch.log(self.prob_thresh))
             return ops.hypos_from_fit(mode, s, depth, rng, log_thr, self.ndepths, bool(upsample))

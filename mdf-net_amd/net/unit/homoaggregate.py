@@ -21,15 +21,10 @@ class VectorAggregate(nn.Module):
         super().__init__()
         self.ngroups = ngroups
         self.depth_weight = nn.Sequential(ConvBNReLU3D(ngroups, 1, 1, 1, 0), nn.Conv3d(1, 1, 1, 1, 0), nn.Sigmoid())
-        self._folded = None
 
     def _params(self):
         sd = {k: v for k, v in self.depth_weight.state_dict(keep_vars=True).items()}
-        key = tuple((v.data_ptr(), v._version) for v in sd.values())
-        if self._folded is None or self._folded[0] != key:
-            with torch.no_grad():
-                self._folded = (key, ops.fold_view_weight(sd, self.ngroups, prefix=""))
-        return self._folded[1]
+        return layers.cache_of(self).get(list(sd.values()), lambda: ops.fold_view_weight(sd, self.ngroups, prefix=""))
 
     def forward(self, features, ref_proj, src_projs, depth_hypos):
         if not layers.use_hip(self, *features, depth_hypos):

@@ -1,14 +1,16 @@
 """GPU parity, end to end: CoreNet.forward (product, HIP kernels) vs the reference.
 Metric = BASELINE.json's: mean |delta depth| <= 1e-3 (mm).
 
-Two comparisons, because the reference is not bit-stable across x86 hosts: its stage-1 gauss fit
-inverts a 3x3 fp32 matrix with cond ~1e14 through LAPACK/BLAS, whose code paths differ between the build
-container's Xeon (where the goldens were produced by the real reference) and the GPU box's EPYC.  Measured on the
-GPU box: the reference algorithm run on that host differs from its own goldens by 1.2-1.4e-3 mm mean
-(scripts/diag_host_variance.py).
-  (A) same host: product vs the oracle executed live on this machine          -> asserted <= 1e-3 (the bar)
-  (B) cross host: product vs goldens from the real reference on the build host -> asserted to be no farther than
-      the reference's own cross-host drift measured in the same test (and <= 2.5e-3 absolute)."""
+The reference is not bit-stable across x86 hosts: its stage-1 gauss fit inverts a 3x3 fp32 matrix with
+cond ~1e14 through LAPACK/BLAS, whose code paths differ between the build container's Xeon (where the goldens were
+produced by the real reference) and the GPU box's EPYC (the reference algorithm run there differs from its own goldens by
+1.2-1.4e-3 mm mean, scripts/diag_host_variance.py).  The host-side values the reference computed on the build host (the 4x4
+projection products, the camera products, the fit row, log of the thresholds: a few hundred floats) are stored with the
+goldens (oracle/gen_golden.py:HostValueRecorder), so both legs carry the metric's own bar:
+  (A) same host: product vs the oracle executed live on this machine                         -> mean <= 1e-3
+  (B) cross host: product, GIVEN the reference's own host values, vs the goldens of the real
+      reference (everything the GPU computes is compared with the reference's output)        -> mean <= 1e-3
+  (C) informational: product with this host's LAPACK values vs the goldens = the reference's own cross-host drift."""
 import numpy as np
 import pytest
 import torch
@@ -28,6 +30,13 @@ def model(seeded_sd):
     return m.eval().to(DEV)
 
 
+def _recorded(g):
+    from mdfnet_hip import ops
+    return ops.recorded_host_values(projs=[g[f"host_proj{st}"] for st in range(3)], cams=[g[f"host_cam{st}"] for st in range(3)],
+                                    fit_row=g["host_fit_row"],
+                                    log_thresh={1: float(g["host_log_thresh1"]), 2: float(g["host_log_thresh2"])})
+
+
 def _scene(g):
     w, h, v, b, rot, seed = g["cfg"]
     return synth.make_scene(int(w), int(h), int(v), batch=int(b), rot_deg=float(rot), seed=int(seed))
@@ -39,22 +48,26 @@ def test_forward_parity(golden, model, seeded_sd, name):
     imgs, extr, intr, dr = _scene(g)
     with torch.no_grad():
         out = model(imgs.to(DEV), extr.to(DEV), intr.to(DEV), dr.to(DEV))
+        with _recorded(g):
+            pinned = model(imgs.to(DEV), extr.clone().to(DEV), intr.clone().to(DEV), dr.clone().to(DEV))
     depth, conf = out["depth"].cpu().numpy(), out["confidence"].cpu().numpy()
     assert depth.shape == g["depth"].shape and conf.shape == g["confidence"].shape
+    e_pin = np.abs(pinned["depth"].cpu().numpy() - g["depth"])
+    c_pin = np.abs(pinned["confidence"].cpu().numpy() - g["confidence"])
     # live oracle on this host; warp through the explicit (host-independent, golden-pinned) arithmetic
     live = O.core_forward(seeded_sd, imgs, extr, intr, dr, warp=O.homo_warping_explicit)
     e_same = np.abs(depth - live["depth"].numpy())
     e_gold = np.abs(depth - g["depth"])
     e_ref_drift = np.abs(live["depth"].numpy() - g["depth"])
     c_same = np.abs(conf - live["confidence"].numpy())
-    print(f"\n{name}: mean|d depth| product-vs-oracle(same host) {e_same.mean():.3e} (max {e_same.max():.3e}) | "
-          f"product-vs-golden(build host) {e_gold.mean():.3e} | reference cross-host drift {e_ref_drift.mean():.3e} | "
-          f"confidence max|d| {c_same.max():.3e}")
+    print(f"\n{name}: mean|d depth| (A) product-vs-oracle(same host) {e_same.mean():.3e} (max {e_same.max():.3e}) | "
+          f"(B) product given the reference's host values vs golden {e_pin.mean():.3e} (max {e_pin.max():.3e}) | "
+          f"(C) product with this host's LAPACK vs golden {e_gold.mean():.3e}, reference cross-host drift {e_ref_drift.mean():.3e} | "
+          f"confidence max|d| same-host {c_same.max():.3e}, vs golden {c_pin.max():.3e}")
     assert e_same.mean() <= 1e-3, f"(A) same-host mean |delta depth| {e_same.mean()} > 1e-3"
-    assert e_gold.mean() <= max(1e-3, 1.25 * e_ref_drift.mean() + 1e-4) and e_gold.mean() <= 2.5e-3, \
-        f"(B) product is farther from the goldens ({e_gold.mean()}) than the reference's own drift ({e_ref_drift.mean()})"
+    assert e_pin.mean() <= 1e-3, f"(B) vs the real reference's output, given its host values: {e_pin.mean()} > 1e-3"
     # confidence = sum of 4 probabilities picked by an integer index; an index flip moves it by O(p)
-    assert np.mean(c_same > 1e-3) < 1e-3
+    assert np.mean(c_same > 1e-3) < 1e-3 and np.mean(c_pin > 1e-3) < 1e-3
 
 
 def test_stagewise_vs_reference_trace(golden, model, seeded_sd):

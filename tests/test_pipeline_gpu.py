@@ -103,3 +103,37 @@ def test_items_in_flight_on_several_streams_give_identical_results(seeded_sd):
     assert len(got) == 12
     for (rep, i), out in got.items():
         assert torch.equal(out["depth"], ref[i]["depth"]) and torch.equal(out["confidence"], ref[i]["confidence"]), (rep, i)
+
+
+def test_cold_model_first_forwards_on_two_streams_equal_serial(seeded_sd):
+    """The weight caches (packed conv weights, folded BN, composed FPN heads, view-weight head, prob pack) are built by
+    kernels on the stream of the FIRST forward; a second item issued at once on another stream must not read them before
+    those kernels ran (mdfnet_hip/layers.py:_Folded records an event, consumers wait for it).  Fresh model, nothing warmed:
+    both outputs equal the serial result bit for bit.  A busy kernel in front of stream 1 widens the window."""
+    from mdfnet_hip import synth
+    from mdfnet_hip.pipeline import InFlight
+    dev = torch.device("cuda", 0)
+    scenes = [tuple(t.to(dev) for t in synth.make_scene(320, 256, 5, rot_deg=2.0, seed=60 + i)) for i in range(2)]
+    warm = build_model()
+    warm.load_state_dict(seeded_sd)
+    warm.eval().to(dev)
+    with torch.no_grad():
+        ref = [warm(*s) for s in scenes]
+    torch.cuda.synchronize()
+    for trial in range(3):
+        m = build_model()                       # cold: no cache entry exists
+        m.load_state_dict(seeded_sd)
+        m.eval().to(dev)
+        big = torch.randn(8192, 8192, device=dev)
+        torch.cuda.synchronize()
+        got = {}
+        pipe = InFlight(dev, 2, done=lambda tag, out: got.__setitem__(tag, out))
+        with torch.no_grad():
+            with torch.cuda.stream(pipe.streams[0]):
+                for _ in range(4):
+                    big = big @ big * 1e-4          # delays item 0 (and its pack kernels) on stream 0
+            for i, s in enumerate(scenes):
+                pipe.submit(lambda s=s: m(s[0], s[1].clone(), s[2].clone(), s[3].clone()), tag=i)
+            pipe.drain()
+        for i in range(2):
+            assert torch.equal(got[i]["depth"], ref[i]["depth"]) and torch.equal(got[i]["confidence"], ref[i]["confidence"]), (trial, i)

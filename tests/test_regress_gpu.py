@@ -44,7 +44,14 @@ def test_hypos_gauss1_stage1(golden):
     live = O.gauss1_fit(T(g["reg0_prob"]), hyp0).numpy()
     np.testing.assert_allclose(sn, live, rtol=1e-4)
     print("gauss1 s: fraction of pixels not bit-identical to the same-host oracle:", float(np.mean(sn != live)))
-    np.testing.assert_allclose(sn, g["hyp1_s"], rtol=5e-3)  # cross-host (build container) golden: H3 drift
+    np.testing.assert_allclose(sn, g["hyp1_s"], rtol=5e-3)  # this host's row vs the build container's golden: H3 drift
+    # GIVEN the row the real reference computed on the build host (ops.npz:hyp1_fit_row), the kernel reproduces the
+    # reference's s: same sequential fp32 sum; the only ulp source left is logf (device libm vs the host's SLEEF), which
+    # the cancelling 48-term sum (terms ~1e3 x larger than the result) amplifies to <= ~1e-4 relative in single pixels
+    sg = ops.hypos_fit(1, p0, d0, hyp0.to(DEV), T(g["hyp1_fit_row"]).to(DEV)).cpu().numpy()
+    rel = np.abs(sg - g["hyp1_s"]) / np.abs(g["hyp1_s"])
+    print(f"gauss1 s given the reference's row: not bit-identical {float(np.mean(sg != g['hyp1_s'])):.3f}, rel max {rel.max():.2e} mean {rel.mean():.2e}")
+    assert rel.max() <= 2e-4 and rel.mean() <= 1e-5
     lt = float(torch.log(torch.tensor(0.95)))
     out = ops.hypos_from_fit(1, T(g["hyp1_s"]).to(DEV), d0, dr.float().to(DEV), lt, 24, True)
     # same upsample/range arithmetic as ATen (bit-exact in all but ~0.1 % of entries: sqrt of a 1-ulp-different product)
