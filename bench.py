@@ -31,6 +31,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 6
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 WIDTH, HEIGHT, VIEWS = 1600, 1184, 5
+if os.environ.get("MDF_BENCH_SIZE"):            # rehearsal knob of tests/test_bench_launch_gpu.py (never set by the driver)
+    WIDTH, HEIGHT, VIEWS = (int(v) for v in os.environ["MDF_BENCH_SIZE"].split("x"))
 
 
 def build(device):
