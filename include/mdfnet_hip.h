@@ -170,6 +170,64 @@ int mdf_consistency_fuse_fwd(const float* depth_ref, const float* conf, const fl
                              int n_src, int h, int w, float photo_threshold, int nconditions, float thre1, float thre2,
                              float* depth_avg, unsigned char* masks, unsigned short* view_masks, float* rep_out, void* stream);
 
+/* =====================================================================================================
+ * Training path (BASELINE config 3; train.py:36-45 -> loss.backward()).  The reference has no explicit backward:
+ * autograd differentiates the op chains cited above.  Each entry below is the hand-written forward-in-train-mode or
+ * backward of one such chain; gradients match torch autograd to fp32 summation-order tolerance.
+ * ===================================================================================================== */
+
+/* ---- BatchNorm3d in batch-statistics mode + ReLU (+ residual) around a conv layer (net/unit/base.py:61-68 with
+ *      nn.BatchNorm3d.training, the blocks of net/unit/regular.py:17-41,82-108).  Activations channels-last [N,C],
+ *      N = B*D*H*W voxels, C in {8,16,32,64}.
+ *   stats:    sums[0..C) += sum_n y[n][c], sums[C..2C) += sum_n y^2      (sums: fp64, zeroed by the caller)
+ *   finalize: aux[4C] = (a = gamma*invstd, b = beta - mean*a, mean, invstd) with the biased variance; when given,
+ *             running_mean/var are updated as nn.BatchNorm does (momentum, unbiased variance) and *nbt += 1
+ *   apply:    z = [res +] relu(y*a + b)
+ *   bwd_reduce: red[0..C) += sum dr, red[C..2C) += sum dr*xhat,  dr = dz*[y*a+b > 0], xhat = (y-mean)*invstd
+ *   bwd:      dy = gamma*invstd*(dr - red0/N - xhat*red1/N);  dgamma[c] = red1, dbeta[c] = red0                      */
+int mdf_bn_stats_fwd(const float* y, long long N, int C, double* sums, void* stream);
+int mdf_bn_finalize_fwd(const double* sums, const float* gamma, const float* beta, float eps, float momentum, long long N,
+                        int C, float* aux, float* running_mean, float* running_var, long long* num_batches_tracked,
+                        void* stream);
+int mdf_bn_relu_apply_fwd(const float* y, const float* aux, const float* res, float* z, long long N, int C, void* stream);
+int mdf_bn_relu_bwd_reduce(const float* dz, const float* y, const float* aux, long long N, int C, double* red, void* stream);
+int mdf_bn_relu_bwd(const float* dz, const float* y, const float* aux, const double* red, const float* gamma, long long N,
+                    int C, float* dy, float* dgamma, float* dbeta, void* stream);
+
+/* ---- weight gradient of nn.Conv3d(k3,p1,stride s) / nn.ConvTranspose3d(k3,s2,p1,op1) (net/unit/regular.py:17-43,
+ *      80-110) as ONE correlation on the fp32 matrix cores:
+ *          dw[a][b][tap] (+)= sum_o small[o][a] * big[stride*o + tap - 1][b]        (zero outside big)
+ *      Conv3d: small = dy [B,Ds,Hs,Ws,A=Cout], big = x [B,s*Ds,s*Hs,s*Ws,Bc=Cin]      -> dw = torch [Cout,Cin,3,3,3]
+ *      ConvTranspose3d: small = x [.., A=Cin], big = dy [.., Bc=Cout], stride 2         -> dw = torch [Cin,Cout,3,3,3]
+ *      (the `prob` conv: A = 1).  NDHWC operands; workspace: mdf_conv3d_wgrad_workspace(...) floats.            */
+int64_t mdf_conv3d_wgrad_workspace(int B, int Ds, int Hs, int Ws, int A, int Bc);
+int mdf_conv3d_wgrad(const float* small_, const float* big, float* dw, float* workspace, int B, int Ds, int Hs, int Ws,
+                     int A, int Bc, int stride, int accumulate, void* stream);
+/* (input gradients of these layers are mdf_conv3d_fwd with re-packed weights: a stride-1 conv with flipped taps and
+ *  swapped channels, the transposed conv for a stride-2 conv and vice versa.) */
+
+/* ---- backward of the `prob` head: softmax over D + soft-argmin (regular.py:69/133, regress.py:5-7), and the input
+ *      gradient of its Conv3d(C->1,k3,p1).   dlogit [B,D,h,w]; ddepth [B,h,w] and/or dprob [B,D,h,w] (either may be
+ *      NULL); w torch [1,C,3,3,3]; dx NDHWC [B,D,h,w,C], C in {8,16}.                                           */
+int mdf_prob_softmax_regress_bwd(const float* prob, const float* hypos, int hypos_per_pixel, const float* ddepth,
+                                 const float* dprob, float* dlogit, int B, int D, int h, int w, void* stream);
+int mdf_prob_conv_dgrad(const float* dlogit, const float* w, float* dx, int B, int D, int h, int wd, int C, void* stream);
+
+/* ---- training-mode VectorAggregate fused with the warp (homoaggregate.py:16-20,25-46 with the 1-channel
+ *      BatchNorm3d in batch-statistics mode -- a global reduction per source view between similarity and view weight;
+ *      base.py:97: no gradient through the sampling grid).  pass:
+ *        0 stats       red_out[2v], [2v+1] += sum t_v, sum t_v^2  (t_v = Conv3d(G->1)(sim_v); fp64, zeroed by caller)
+ *        1 forward     cost [B,D,h,w,G] and wsum [B,D,h,w] = sum_v w_v, with per-view (alpha_v, beta_v) from `par`
+ *        2 bwd-reduce  red_out[2v], [2v+1] += sum dz_v, sum dz_v*xhat_v; red_out[2n], [2n+1] += d w2, d b2
+ *        3 backward    dref [B,h,w,C] (stored), dsrc[v] [B,h,w,C] (+= by fp32 atomics; zeroed by caller), dcw[G] (+=)
+ *      par (float): [0,G) conv weight | G: w2 | G+1: b2 | G+2: gamma | G+3: 1/N | G+4+4v: alpha_v, beta_v, mean_v,
+ *      invstd_v.  Features NHWC, C in {16,32,64}, G = C/2.                                                        */
+int mdf_warp_aggregate_vec_train(int pass, const float* ref_fea, const float* const* src_feas, const float* proj,
+                                 const float* hypos, int hypos_per_pixel, const float* par, const double* red_in,
+                                 const float* dcost, float* cost, float* wsum, double* red_out, float* dref,
+                                 float* const* dsrc, float* dcw, int B, int C, int G, int D, int h, int w, int n_src,
+                                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,201 @@
+// Training-mode BatchNorm3d + ReLU (+ residual) around the regulariser's conv layers (net/unit/base.py:50-68 with
+// nn.BatchNorm3d in batch-statistics mode, net/unit/regular.py:17-41,82-108), channels-last activations [N, C]
+// (N = B*D*H*W voxels, C in {8,16,32,64}).  All kernels are HBM-bound streams:
+//
+//   bn_stats          sum, sum of squares per channel                                  reads y once
+//   bn_finalize       mean/var -> (a, b, mean, invstd), running-stat update            C threads
+//   bn_relu_apply     z = [res +] relu(y*a + b)                                        reads y (+res), writes z
+//   bn_relu_bwd_reduce  S1 = sum dr, S2 = sum dr*xhat, dr = dz*[y*a+b > 0]             reads dz, y
+//   bn_relu_bwd       dy = gamma*invstd*(dr - S1/N - xhat*S2/N); dgamma = S2, dbeta = S1   reads dz, y, writes dy
+//
+// A block strides over the tensor in steps that are multiples of C floats, so a thread owns the same 4 channels for
+// the whole kernel: per-thread fp32 partial sums (a few dozen elements each), combined in fp64 through LDS and one
+// fp64 atomic per channel per block.
+#include "common.h"
+
+namespace {
+
+constexpr int kT = 256;
+
+__device__ __forceinline__ void lds_add(double* p, double v) { atomicAdd(p, v); }
+
+template <bool BWD>
+__global__ __launch_bounds__(kT) void bn_reduce_kernel(const float* __restrict__ y, const float* __restrict__ dz,
+                                                       const float* __restrict__ aux, long long n4, int C,
+                                                       double* __restrict__ out) {
+  // FWD: out[c] += sum y, out[C+c] += sum y^2.   BWD: out[c] += sum dr, out[C+c] += sum dr*xhat.
+  __shared__ double sm[128];
+  const int tid = threadIdx.x;
+  if (tid < 2 * C) sm[tid] = 0.0;
+  __syncthreads();
+  const int c0 = (4 * tid) % C;
+  float a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0}, mu[4] = {0, 0, 0, 0}, is[4] = {0, 0, 0, 0};
+  if (BWD) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a[k] = aux[c0 + k]; b[k] = aux[C + c0 + k]; mu[k] = aux[2 * C + c0 + k]; is[k] = aux[3 * C + c0 + k]; }
+  }
+  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  const long long stride = (long long)gridDim.x * kT;
+  for (long long i = (long long)blockIdx.x * kT + tid; i < n4; i += stride) {
+    const float4 v = reinterpret_cast<const float4*>(y)[i];
+    const float yv[4] = {v.x, v.y, v.z, v.w};
+    if (!BWD) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { s1[k] += yv[k]; s2[k] = fmaf(yv[k], yv[k], s2[k]); }
+    } else {
+      const float4 g = reinterpret_cast<const float4*>(dz)[i];
+      const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float dr = (fmaf(yv[k], a[k], b[k]) > 0.0f) ? gv[k] : 0.0f;
+        s1[k] += dr;
+        s2[k] = fmaf(dr, (yv[k] - mu[k]) * is[k], s2[k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { lds_add(&sm[c0 + k], (double)s1[k]); lds_add(&sm[C + c0 + k], (double)s2[k]); }
+  __syncthreads();
+  if (tid < 2 * C) atomicAdd(&out[tid], sm[tid]);
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float eps, float momentum, double n, int C, float* __restrict__ aux,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt) {
+  const int c = threadIdx.x;
+  if (c < C) {
+    const double mean = sums[c] / n;
+    double var = sums[C + c] / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float a = gamma[c] * invstd;
+    aux[c] = a;
+    aux[C + c] = beta[c] - (float)mean * a;
+    aux[2 * C + c] = (float)mean;
+    aux[3 * C + c] = invstd;
+    if (running_mean) {   // nn.BatchNorm: running = (1-m)*running + m*batch, variance unbiased
+      const double unb = (n > 1.0) ? var * n / (n - 1.0) : var;
+      running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+      running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  }
+  if (c == 0 && nbt) *nbt += 1;
+}
+
+__global__ __launch_bounds__(kT) void bn_relu_apply_kernel(const float* __restrict__ y, const float* __restrict__ aux,
+                                                           const float* __restrict__ res, float* __restrict__ z, long long n4, int C) {
+  const int tid = threadIdx.x;
+  const int c0 = (4 * tid) % C;
+  float a[4], b[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { a[k] = aux[c0 + k]; b[k] = aux[C + c0 + k]; }
+  const long long stride = (long long)gridDim.x * kT;
+  for (long long i = (long long)blockIdx.x * kT + tid; i < n4; i += stride) {
+    const float4 v = reinterpret_cast<const float4*>(y)[i];
+    float4 o;
+    o.x = fmaxf(fmaf(v.x, a[0], b[0]), 0.0f);
+    o.y = fmaxf(fmaf(v.y, a[1], b[1]), 0.0f);
+    o.z = fmaxf(fmaf(v.z, a[2], b[2]), 0.0f);
+    o.w = fmaxf(fmaf(v.w, a[3], b[3]), 0.0f);
+    if (res) {
+      const float4 r = reinterpret_cast<const float4*>(res)[i];
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    reinterpret_cast<float4*>(z)[i] = o;
+  }
+}
+
+__global__ __launch_bounds__(kT) void bn_relu_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+                                                         const float* __restrict__ aux, const double* __restrict__ red,
+                                                         const float* __restrict__ gamma, double inv_n, float* __restrict__ dy,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, long long n4, int C) {
+  const int tid = threadIdx.x;
+  const int c0 = (4 * tid) % C;
+  float a[4], b[4], mu[4], is[4], m1[4], m2[4], gi[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    a[k] = aux[c0 + k]; b[k] = aux[C + c0 + k]; mu[k] = aux[2 * C + c0 + k]; is[k] = aux[3 * C + c0 + k];
+    m1[k] = (float)(red[c0 + k] * inv_n);
+    m2[k] = (float)(red[C + c0 + k] * inv_n);
+    gi[k] = gamma[c0 + k] * is[k];
+  }
+  if (blockIdx.x == 0 && tid < C) {
+    dbeta[tid] = (float)red[tid];
+    dgamma[tid] = (float)red[C + tid];
+  }
+  const long long stride = (long long)gridDim.x * kT;
+  for (long long i = (long long)blockIdx.x * kT + tid; i < n4; i += stride) {
+    const float4 v = reinterpret_cast<const float4*>(y)[i];
+    const float4 g = reinterpret_cast<const float4*>(dz)[i];
+    const float yv[4] = {v.x, v.y, v.z, v.w}, gv[4] = {g.x, g.y, g.z, g.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float dr = (fmaf(yv[k], a[k], b[k]) > 0.0f) ? gv[k] : 0.0f;
+      const float xh = (yv[k] - mu[k]) * is[k];
+      o[k] = gi[k] * (dr - m1[k] - xh * m2[k]);
+    }
+    reinterpret_cast<float4*>(dy)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+int grid_for(long long n4) {
+  long long g = (n4 + kT - 1) / kT;
+  if (g > 2048) g = 2048;      // 8 blocks per CU: enough bytes in flight for an HBM stream
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+int check_bn(const void* y, long long N, int C) {
+  MDF_REQUIRE(y, "null pointer argument");
+  MDF_REQUIRE(N > 0, "bad voxel count");
+  MDF_REQUIRE(C == 8 || C == 16 || C == 32 || C == 64, "C=%d not in {8,16,32,64}", C);
+  return MDF_OK;
+}
+
+}  // namespace
+
+extern "C" int mdf_bn_stats_fwd(const float* y, long long N, int C, double* sums, void* stream) {
+  if (int rc = check_bn(y, N, C)) return rc;
+  MDF_REQUIRE(sums, "null pointer argument");
+  const long long n4 = N * C / 4;
+  hipLaunchKernelGGL(bn_reduce_kernel<false>, dim3(grid_for(n4)), dim3(kT), 0, (hipStream_t)stream, y, nullptr, nullptr, n4, C, sums);
+  return mdf::check_launch("bn_stats_kernel");
+}
+
+extern "C" int mdf_bn_finalize_fwd(const double* sums, const float* gamma, const float* beta, float eps, float momentum,
+                                   long long N, int C, float* aux, float* running_mean, float* running_var,
+                                   long long* num_batches_tracked, void* stream) {
+  MDF_REQUIRE(sums && gamma && beta && aux, "null pointer argument");
+  MDF_REQUIRE(C >= 1 && C <= 64 && N > 0, "bad shape");
+  MDF_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running_mean and running_var go together");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, gamma, beta, eps, momentum, (double)N, C, aux,
+                     running_mean, running_var, num_batches_tracked);
+  return mdf::check_launch("bn_finalize_kernel");
+}
+
+extern "C" int mdf_bn_relu_apply_fwd(const float* y, const float* aux, const float* res, float* z, long long N, int C, void* stream) {
+  if (int rc = check_bn(y, N, C)) return rc;
+  MDF_REQUIRE(aux && z, "null pointer argument");
+  const long long n4 = N * C / 4;
+  hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(grid_for(n4)), dim3(kT), 0, (hipStream_t)stream, y, aux, res, z, n4, C);
+  return mdf::check_launch("bn_relu_apply_kernel");
+}
+
+extern "C" int mdf_bn_relu_bwd_reduce(const float* dz, const float* y, const float* aux, long long N, int C, double* red, void* stream) {
+  if (int rc = check_bn(y, N, C)) return rc;
+  MDF_REQUIRE(dz && aux && red, "null pointer argument");
+  const long long n4 = N * C / 4;
+  hipLaunchKernelGGL(bn_reduce_kernel<true>, dim3(grid_for(n4)), dim3(kT), 0, (hipStream_t)stream, y, dz, aux, n4, C, red);
+  return mdf::check_launch("bn_relu_bwd_reduce_kernel");
+}
+
+extern "C" int mdf_bn_relu_bwd(const float* dz, const float* y, const float* aux, const double* red, const float* gamma, long long N,
+                               int C, float* dy, float* dgamma, float* dbeta, void* stream) {
+  if (int rc = check_bn(y, N, C)) return rc;
+  MDF_REQUIRE(dz && aux && red && gamma && dy && dgamma && dbeta, "null pointer argument");
+  const long long n4 = N * C / 4;
+  hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(grid_for(n4)), dim3(kT), 0, (hipStream_t)stream, dz, y, aux, red, gamma, 1.0 / (double)N, dy,
+                     dgamma, dbeta, n4, C);
+  return mdf::check_launch("bn_relu_bwd_kernel");
+}

@@ -1,0 +1,316 @@
+// Training-mode VectorAggregate fused with the plane-sweep warp (net/unit/homoaggregate.py:16-20,25-46 with
+// depth_weight's BatchNorm3d(1) in batch-statistics mode, net/unit/base.py:85-126 whose sampling grid is built under
+// no_grad, base.py:97 -- gradient flows to the features only).
+//
+// The 1-channel BatchNorm sits between "similarity" and "view weight" and needs the statistics of the WHOLE volume of
+// one source view before any weight can be formed, so every direction is two passes over the (cheap to recompute)
+// warp + similarity instead of storing the n_src similarity volumes:
+//   kStats      t_v = conv(G->1)(sim_v):  sum t, sum t^2 per source view                      (fp64 atomics)
+//   kFwd        cost = sum_v w_v sim_v / sum_v w_v with per-view (alpha_v, beta_v); also writes wsum = sum_v w_v
+//   kBwdReduce  per view S1 = sum dz, S2 = sum dz*xhat (BatchNorm backward), plus d w2, d b2   (fp64 atomics)
+//   kBwd        dt -> dsim -> d ref (direct store: a block owns its pixels over all planes), d src (fp32 atomic
+//               scatter through the 4 bilinear taps -- the transpose of the gather), d conv weight
+// Same thread mapping as the eval kernel (warp_aggregate.hip): a lane owns 4 channels = 2 groups, the C/4 lanes of a
+// pixel reduce with DPP row operations, sample positions are computed once per (pixel, plane, view) into an LDS table.
+//
+// par (float):  [0,G) conv weight | G: w2, G+1: b2, G+2: gamma, G+3: 1/N | G+4+4v..: alpha_v, beta_v, mean_v, invstd_v
+#include "warp_common.h"
+
+namespace {
+
+enum Pass { kStats = 0, kFwd = 1, kBwdReduce = 2, kBwd = 3 };
+
+struct TrainParams {
+  const float* ref;
+  const float* src[MDF_MAX_SRC_VIEWS];
+  const float* proj;
+  const float* hypos;
+  const float* par;
+  const double* red_in;   // kBwd: [2*n_src] S1_v, S2_v
+  const float* dcost;     // [B,D,h,w,G]
+  float* cost;            // [B,D,h,w,G]  (written by kFwd, read by the backward passes)
+  float* wsum;            // [B,D,h,w]    (same)
+  double* red_out;        // kStats: [2*n_src]; kBwdReduce: [2*n_src + 2]
+  float* dref;            // [B,h,w,C]
+  float* dsrc[MDF_MAX_SRC_VIEWS];   // zero-initialised by the caller
+  float* dcw;             // [G], zero-initialised
+  Geom g;
+  int B, D, n_src, hypos_per_pixel, dchunk, nblk_x;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int C, int PASS>
+__global__ __launch_bounds__(kThreads) void warp_train_kernel(const TrainParams p) {
+  constexpr int LPP = C / 4;
+  constexpr int PPB = kThreads / LPP;
+  constexpr int G = C / 2;
+  constexpr int KMAX = 2 * MDF_MAX_SRC_VIEWS + 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  TapEntry* tab = reinterpret_cast<TapEntry*>(smem);
+  __shared__ float part[4][KMAX];     // per-wave partial sums of the current depth chunk
+  __shared__ float dcw_sm[kThreads][2];
+
+  const int hw = p.g.h * p.g.w;
+  const int b = blockIdx.y;
+  const int tile = (int)mdf::xcd_remap(blockIdx.x, p.nblk_x);
+  const int pix0 = tile * PPB;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int pl = tid / LPP, sub = tid % LPP;
+  const int pix = min(pix0 + pl, hw - 1);
+  const bool live = (pix0 + pl) < hw;
+  const bool owner = live && (sub == 0);   // one lane per pixel contributes pixel-level scalars to the reductions
+
+  // reference features: group softmax
+  float r[4];
+  {
+    const float4 rv = *reinterpret_cast<const float4*>(p.ref + ((size_t)b * hw + pix) * C + 4 * sub);
+    softmax2(rv.x, rv.y, r[0], r[1]);
+    softmax2(rv.z, rv.w, r[2], r[3]);
+    r[0] -= r[1];   // sim = r1 + q0*(r0 - r1)
+    r[2] -= r[3];
+  }
+  const float cw0 = p.par[2 * sub], cw1 = p.par[2 * sub + 1];
+  const float w2 = p.par[G], b2 = p.par[G + 1], gamma = p.par[G + 2], inv_n = p.par[G + 3];
+  const float* vpar = p.par + G + 4;
+  const size_t map_stride = (size_t)hw * C;
+  const int nred = (PASS == kStats) ? 2 * p.n_src : 2 * p.n_src + 2;
+  double total = 0.0;                 // thread k < nred: block total of reduction slot k
+  float gref0 = 0.f, gref1 = 0.f;     // kBwd: d sim/d p0 accumulated over planes and views
+  float dcw0 = 0.f, dcw1 = 0.f;       // kBwd: d conv weight of this lane's two groups
+
+  for (int d0 = 0; d0 < p.D; d0 += p.dchunk) {
+    const int nd = min(p.dchunk, p.D - d0);
+    const int nent = nd * p.n_src * PPB;
+    for (int e = tid; e < nent; e += kThreads) {
+      const int epl = e % PPB;
+      const int ev = (e / PPB) % p.n_src;
+      const int ed = e / (PPB * p.n_src);
+      const int epix = min(pix0 + epl, hw - 1);
+      const int yy = epix / p.g.w, xx = epix - yy * p.g.w;
+      const float* m = p.proj + ((size_t)ev * p.B + b) * 12;
+      const int d = d0 + ed;
+      const float dep = p.hypos_per_pixel ? p.hypos[((size_t)b * p.D + d) * hw + epix] : p.hypos[(size_t)b * p.D + d];
+      float ix, iy;
+      warp_position(m, (float)xx, (float)yy, dep, p.g, ix, iy);
+      TapEntry t;
+      make_taps(ix, iy, p.g, C, t);
+      tab[e] = t;
+    }
+    __syncthreads();
+
+    if (PASS == kStats || PASS == kBwdReduce) {
+      // views outermost: the sums of a view stay in registers over the chunk's planes, one wave reduction per view
+      float a3 = 0.f, a4 = 0.f;
+      for (int v = 0; v < p.n_src; ++v) {
+        float s1 = 0.f, s2 = 0.f;
+        const float* sp = p.src[v] + (size_t)b * map_stride + 4 * sub;
+        for (int dd = 0; dd < nd; ++dd) {
+          const TapEntry t = tab[(dd * p.n_src + v) * PPB + pl];
+          const float4 nw = *reinterpret_cast<const float4*>(sp + t.off[0]);
+          const float4 ne = *reinterpret_cast<const float4*>(sp + t.off[1]);
+          const float4 sw = *reinterpret_cast<const float4*>(sp + t.off[2]);
+          const float4 se = *reinterpret_cast<const float4*>(sp + t.off[3]);
+          const float v0 = __fmaf_rn(se.x, t.wt[3], __fmaf_rn(sw.x, t.wt[2], __fmaf_rn(ne.x, t.wt[1], __fmul_rn(nw.x, t.wt[0]))));
+          const float v1 = __fmaf_rn(se.y, t.wt[3], __fmaf_rn(sw.y, t.wt[2], __fmaf_rn(ne.y, t.wt[1], __fmul_rn(nw.y, t.wt[0]))));
+          const float v2 = __fmaf_rn(se.z, t.wt[3], __fmaf_rn(sw.z, t.wt[2], __fmaf_rn(ne.z, t.wt[1], __fmul_rn(nw.z, t.wt[0]))));
+          const float v3 = __fmaf_rn(se.w, t.wt[3], __fmaf_rn(sw.w, t.wt[2], __fmaf_rn(ne.w, t.wt[1], __fmul_rn(nw.w, t.wt[0]))));
+          const float sim0 = __fmaf_rn(softmax2_p0(v0, v1), r[0], r[1]);
+          const float sim1 = __fmaf_rn(softmax2_p0(v2, v3), r[2], r[3]);
+          const float tt = pixel_sum<LPP>(__fmaf_rn(cw0, sim0, cw1 * sim1));
+          if (PASS == kStats) {
+            if (owner) { s1 += tt; s2 = fmaf(tt, tt, s2); }
+          } else {
+            const size_t vox = ((size_t)b * p.D + d0 + dd) * hw + pix;
+            const float2 dc = *reinterpret_cast<const float2*>(p.dcost + vox * G + 2 * sub);
+            const float2 co = *reinterpret_cast<const float2*>(p.cost + vox * G + 2 * sub);
+            const float dn = p.wsum[vox];
+            const float dDn = -pixel_sum<LPP>(__fmaf_rn(dc.x, co.x, dc.y * co.y)) / dn;
+            const float z = __fmaf_rn(tt, vpar[4 * v], vpar[4 * v + 1]);
+            const float rl = fmaxf(z, 0.0f);
+            const float u = __fmaf_rn(rl, w2, b2);
+            const float wv = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-u * kLog2e));
+            const float dwv = pixel_sum<LPP>(__fmaf_rn(dc.x / dn, sim0, (dc.y / dn) * sim1)) + dDn;
+            const float du = dwv * wv * (1.0f - wv);
+            const float dz = (z > 0.0f) ? du * w2 : 0.0f;
+            const float xh = (tt - vpar[4 * v + 2]) * vpar[4 * v + 3];
+            if (owner) { s1 += dz; s2 = fmaf(dz, xh, s2); a3 = fmaf(du, rl, a3); a4 += du; }
+          }
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0) { part[wave][2 * v] = s1; part[wave][2 * v + 1] = s2; }
+      }
+      if (PASS == kBwdReduce) {
+        a3 = wave_sum(a3);
+        a4 = wave_sum(a4);
+        if (lane == 0) { part[wave][2 * p.n_src] = a3; part[wave][2 * p.n_src + 1] = a4; }
+      }
+    } else {
+      for (int dd = 0; dd < nd; ++dd) {
+        const int d = d0 + dd;
+        const size_t vox = ((size_t)b * p.D + d) * hw + pix;
+        float acc0 = 0.f, acc1 = 0.f, wsum = 0.f;
+        float dN0 = 0.f, dN1 = 0.f, dDn = 0.f;
+        if (PASS == kBwd) {
+          const float2 dc = *reinterpret_cast<const float2*>(p.dcost + vox * G + 2 * sub);
+          const float2 co = *reinterpret_cast<const float2*>(p.cost + vox * G + 2 * sub);
+          const float dn = p.wsum[vox];
+          dN0 = dc.x / dn;
+          dN1 = dc.y / dn;
+          dDn = -pixel_sum<LPP>(__fmaf_rn(dc.x, co.x, dc.y * co.y)) / dn;
+        }
+        for (int v = 0; v < p.n_src; ++v) {
+          const TapEntry t = tab[(dd * p.n_src + v) * PPB + pl];
+          const float* sp = p.src[v] + (size_t)b * map_stride + 4 * sub;
+          const float4 nw = *reinterpret_cast<const float4*>(sp + t.off[0]);
+          const float4 ne = *reinterpret_cast<const float4*>(sp + t.off[1]);
+          const float4 sw = *reinterpret_cast<const float4*>(sp + t.off[2]);
+          const float4 se = *reinterpret_cast<const float4*>(sp + t.off[3]);
+          const float v0 = __fmaf_rn(se.x, t.wt[3], __fmaf_rn(sw.x, t.wt[2], __fmaf_rn(ne.x, t.wt[1], __fmul_rn(nw.x, t.wt[0]))));
+          const float v1 = __fmaf_rn(se.y, t.wt[3], __fmaf_rn(sw.y, t.wt[2], __fmaf_rn(ne.y, t.wt[1], __fmul_rn(nw.y, t.wt[0]))));
+          const float v2 = __fmaf_rn(se.z, t.wt[3], __fmaf_rn(sw.z, t.wt[2], __fmaf_rn(ne.z, t.wt[1], __fmul_rn(nw.z, t.wt[0]))));
+          const float v3 = __fmaf_rn(se.w, t.wt[3], __fmaf_rn(sw.w, t.wt[2], __fmaf_rn(ne.w, t.wt[1], __fmul_rn(nw.w, t.wt[0]))));
+          const float q0 = softmax2_p0(v0, v1), q1 = softmax2_p0(v2, v3);
+          const float sim0 = __fmaf_rn(q0, r[0], r[1]);
+          const float sim1 = __fmaf_rn(q1, r[2], r[3]);
+          const float tt = pixel_sum<LPP>(__fmaf_rn(cw0, sim0, cw1 * sim1));          // Conv3d(G->1, 1x1x1)
+          const float z = __fmaf_rn(tt, vpar[4 * v], vpar[4 * v + 1]);                 // BatchNorm3d(1), batch statistics
+          const float rl = fmaxf(z, 0.0f);
+          const float u = __fmaf_rn(rl, w2, b2);
+          const float wv = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-u * kLog2e));
+          if (PASS == kFwd) {
+            wsum += wv;
+            acc0 += wv * sim0;
+            acc1 += wv * sim1;
+          } else {
+            const float dwv = pixel_sum<LPP>(__fmaf_rn(dN0, sim0, dN1 * sim1)) + dDn;
+            const float du = dwv * wv * (1.0f - wv);
+            const float dz = (z > 0.0f) ? du * w2 : 0.0f;
+            const float xh = (tt - vpar[4 * v + 2]) * vpar[4 * v + 3];
+            {
+              const float s1 = (float)p.red_in[2 * v], s2 = (float)p.red_in[2 * v + 1];
+              const float dt = gamma * vpar[4 * v + 3] * (dz - s1 * inv_n - xh * (s2 * inv_n));
+              const float ds0 = __fmaf_rn(dN0, wv, dt * cw0);
+              const float ds1 = __fmaf_rn(dN1, wv, dt * cw1);
+              if (live) {
+                dcw0 = fmaf(dt, sim0, dcw0);
+                dcw1 = fmaf(dt, sim1, dcw1);
+                gref0 = fmaf(ds0, 2.0f * q0 - 1.0f, gref0);       // d sim / d p0 = 2 q0 - 1
+                gref1 = fmaf(ds1, 2.0f * q1 - 1.0f, gref1);
+                const float g0 = ds0 * r[0] * q0 * (1.0f - q0);   // d sim / d q0 = r0 = 2 p0 - 1; softmax pair: dv0 = -dv1
+                const float g1 = ds1 * r[2] * q1 * (1.0f - q1);
+                float* gp = p.dsrc[v] + (size_t)b * map_stride + 4 * sub;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  const float wk = t.wt[k];
+                  if (wk != 0.0f) {
+                    float* o = gp + t.off[k];
+                    unsafeAtomicAdd(o, wk * g0);
+                    unsafeAtomicAdd(o + 1, -(wk * g0));
+                    unsafeAtomicAdd(o + 2, wk * g1);
+                    unsafeAtomicAdd(o + 3, -(wk * g1));
+                  }
+                }
+              }
+            }
+          }
+        }
+        if (PASS == kFwd && live) {
+          *reinterpret_cast<float2*>(p.cost + vox * G + 2 * sub) = make_float2(acc0 / wsum, acc1 / wsum);
+          if (sub == 0) p.wsum[vox] = wsum;
+        }
+      }
+    }
+    __syncthreads();
+    if ((PASS == kStats || PASS == kBwdReduce) && tid < nred)   // (the next chunk's writes come after its phase-A barrier)
+      total += (double)part[0][tid] + (double)part[1][tid] + (double)part[2][tid] + (double)part[3][tid];
+  }
+
+  if ((PASS == kStats || PASS == kBwdReduce) && tid < nred) atomicAdd(&p.red_out[tid], total);
+  if (PASS == kBwd) {
+    // d ref: sim = p1 + q0*(p0 - p1) with (p0,p1) = softmax(a0,a1): d a0 = gref * p0*p1, d a1 = -d a0
+    if (live) {
+      const float p1a = r[1], p0a = 1.0f - r[1], p1b = r[3], p0b = 1.0f - r[3];
+      const float ga = gref0 * p0a * p1a, gb = gref1 * p0b * p1b;
+      *reinterpret_cast<float4*>(p.dref + ((size_t)b * hw + pix) * C + 4 * sub) = make_float4(ga, -ga, gb, -gb);
+    }
+    dcw_sm[tid][0] = dcw0;
+    dcw_sm[tid][1] = dcw1;
+    __syncthreads();
+    if (tid < G) {   // group tid lives in lane sub = tid/2 of every pixel, slot tid&1
+      float s = 0.f;
+      for (int q = 0; q < PPB; ++q) s += dcw_sm[q * LPP + (tid >> 1)][tid & 1];
+      unsafeAtomicAdd(&p.dcw[tid], s);
+    }
+  }
+}
+
+template <int PASS>
+int launch_train(TrainParams& p, int C, hipStream_t st) {
+  const int lpp = C / 4, ppb = kThreads / lpp;
+  const int hw = p.g.h * p.g.w;
+  p.nblk_x = (hw + ppb - 1) / ppb;
+  int dch = 512 / (p.n_src * ppb);
+  if (dch < 1) dch = 1;
+  if (dch > p.D) dch = p.D;
+  p.dchunk = dch;
+  const size_t lds = (size_t)dch * p.n_src * ppb * sizeof(TapEntry);
+  dim3 grid(p.nblk_x, p.B), block(kThreads);
+  switch (C) {
+    case 64: hipLaunchKernelGGL((warp_train_kernel<64, PASS>), grid, block, lds, st, p); break;
+    case 32: hipLaunchKernelGGL((warp_train_kernel<32, PASS>), grid, block, lds, st, p); break;
+    case 16: hipLaunchKernelGGL((warp_train_kernel<16, PASS>), grid, block, lds, st, p); break;
+    default: return mdf::fail(MDF_EUNSUPPORTED, "warp kernels are built for C in {16,32,64}, got %d", C);
+  }
+  return mdf::check_launch("warp_train_kernel");
+}
+
+}  // namespace
+
+extern "C" int mdf_warp_aggregate_vec_train(int pass, const float* ref_fea, const float* const* src_feas, const float* proj,
+                                            const float* hypos, int hypos_per_pixel, const float* par, const double* red_in,
+                                            const float* dcost, float* cost, float* wsum, double* red_out, float* dref,
+                                            float* const* dsrc, float* dcw, int B, int C, int G, int D, int h, int w, int n_src,
+                                            void* stream) {
+  MDF_REQUIRE(ref_fea && src_feas && proj && hypos && par, "null pointer argument");
+  MDF_REQUIRE(pass >= 0 && pass <= 3, "pass=%d not in 0..3", pass);
+  MDF_REQUIRE(B > 0 && D > 0 && h > 1 && w > 1, "bad shape B=%d D=%d h=%d w=%d", B, D, h, w);
+  MDF_REQUIRE((long long)h * w * C < (1ll << 31), "feature map too large for 32-bit tap offsets");
+  MDF_REQUIRE(n_src >= 1 && n_src <= MDF_MAX_SRC_VIEWS, "n_src=%d out of range [1,%d]", n_src, MDF_MAX_SRC_VIEWS);
+  if (G * 2 != C) return mdf::fail(MDF_EUNSUPPORTED, "only C/G == 2 is built (C=%d, G=%d)", C, G);
+  TrainParams p{};
+  p.ref = ref_fea;
+  for (int v = 0; v < n_src; ++v) {
+    MDF_REQUIRE(src_feas[v], "src_feas[%d] is null", v);
+    p.src[v] = src_feas[v];
+  }
+  p.proj = proj; p.hypos = hypos; p.par = par; p.red_in = red_in; p.dcost = dcost; p.cost = cost; p.wsum = wsum;
+  p.red_out = red_out; p.dref = dref; p.dcw = dcw;
+  p.g = make_geom(h, w);
+  p.B = B; p.D = D; p.n_src = n_src; p.hypos_per_pixel = hypos_per_pixel;
+  hipStream_t st = (hipStream_t)stream;
+  switch (pass) {
+    case kStats:
+      MDF_REQUIRE(red_out, "stats pass needs red_out");
+      return launch_train<kStats>(p, C, st);
+    case kFwd:
+      MDF_REQUIRE(cost && wsum, "forward pass needs cost and wsum");
+      return launch_train<kFwd>(p, C, st);
+    case kBwdReduce:
+      MDF_REQUIRE(dcost && cost && wsum && red_out, "backward-reduce pass needs dcost, cost, wsum, red_out");
+      return launch_train<kBwdReduce>(p, C, st);
+    default:
+      MDF_REQUIRE(dcost && cost && wsum && red_in && dref && dsrc && dcw, "backward pass needs dcost, cost, wsum, red_in, dref, dsrc, dcw");
+      for (int v = 0; v < n_src; ++v) {
+        MDF_REQUIRE(dsrc[v], "dsrc[%d] is null", v);
+        p.dsrc[v] = dsrc[v];
+      }
+      return launch_train<kBwd>(p, C, st);
+  }
+}

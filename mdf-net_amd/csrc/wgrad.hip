@@ -1,0 +1,177 @@
+// Weight gradient of the regulariser's 3x3x3 conv layers (net/unit/regular.py:17-43,82-110; backward of nn.Conv3d /
+// nn.ConvTranspose3d) on the fp32 matrix cores of gfx950.
+//
+// One generic correlation covers every layer kind:
+//     G[a][b][tap] = sum over voxels o of  small[o][a] * big[s*o + tap - 1][b]        (zero outside `big`)
+//   Conv3d  (stride s):      small = dy [.., Cout], big = x  [.., Cin]  -> dW[Cout][Cin][27]   (torch layout)
+//   ConvTranspose3d (k3,s2,p1,op1): small = x [.., Cin], big = dy [.., Cout] (twice the size), s = 2
+//                                                                          -> dW[Cin][Cout][27]   (torch layout)
+// Activations are NDHWC, so the 16 channels of an MFMA row/column are 64 contiguous bytes.
+//
+// GEMM view: M = a (16 per tile), N = b (16 per tile), K = voxels -- a long K, so the kernel is a split-K GEMM: a
+// wave keeps the 27 tap tiles of ONE (a-tile, b-tile) pair in registers (108 accumulator VGPRs) while it walks its
+// share of the voxels in chunks of 16 along w (4 MFMA k-steps of v_mfma_f32_16x16x4_f32; exact fp32 fma chain); per
+// chunk the `small` fragment is loaded once and reused by the 27 taps.  Blocks write their partial tiles to a slab,
+// a second kernel sums the slab (deterministic, no float atomics on the 27*A*B hot addresses).
+//   A operand: lane l holds small[voxel 4j + (l>>4)][a = l&15]      C/D: lane l holds rows 4*(l>>4)..+3, column l&15
+//   B operand: lane l holds big  [voxel 4j + (l>>4)][b = l&15]
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct WgradParams {
+  const float* small_;   // [B,Ds,Hs,Ws,A]
+  const float* big;      // [B,Db,Hb,Wb,Bc]
+  float* slab;           // [gridDim.x][A][Bc][27]
+  int B, Ds, Hs, Ws, Db, Hb, Wb, A, Bc, stride;
+  int chunks_per_row;    // ceil(Ws/16)
+  long long n_items;     // B*Ds*Hs*chunks_per_row
+  int NB;                // b-tiles
+  int split;             // waves of a block that share one pair and split the chunks (1, 2 or 4)
+};
+
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, c16 = lane & 15;
+  // which (a-tile, b-tile) pair this wave owns, and which slice of the block's chunk stream
+  const int pairs_per_block = 4 / p.split;
+  const int pair = blockIdx.y * pairs_per_block + wave / p.split;
+  const int part = wave % p.split;
+  const int na = pair / p.NB, nb = pair % p.NB;
+  const int a = na * 16 + c16, bcol = nb * 16 + c16;
+  const bool a_ok = a < p.A, b_ok = bcol < p.Bc;
+
+  f32x4 acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int s = p.stride;
+  for (long long item = (long long)blockIdx.x * p.split + part; item < p.n_items; item += (long long)gridDim.x * p.split) {
+    const int ch = (int)(item % p.chunks_per_row);
+    long long r = item / p.chunks_per_row;
+    const int oh = (int)(r % p.Hs); r /= p.Hs;
+    const int od = (int)(r % p.Ds);
+    const int n = (int)(r / p.Ds);
+    const int ow0 = ch * 16;
+    float af[4];
+    const float* srow = p.small_ + (((long long)n * p.Ds + od) * p.Hs + oh) * (long long)p.Ws * p.A;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ow = ow0 + 4 * j + q;
+      af[j] = (a_ok && ow < p.Ws) ? srow[(long long)ow * p.A + a] : 0.0f;
+    }
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+      const int id = od * s + kd - 1;
+      if (id < 0 || id >= p.Db) continue;          // wave-uniform
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int ih = oh * s + kh - 1;
+        if (ih < 0 || ih >= p.Hb) continue;        // wave-uniform
+        const float* brow = p.big + (((long long)n * p.Db + id) * p.Hb + ih) * (long long)p.Wb * p.Bc;
+        float bf[3][4];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int iw = (ow0 + 4 * j + q) * s + kw - 1;
+            bf[kw][j] = (b_ok && iw >= 0 && iw < p.Wb) ? brow[(long long)iw * p.Bc + bcol] : 0.0f;
+          }
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[(kd * 3 + kh) * 3 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[kw][j], acc[(kd * 3 + kh) * 3 + kw], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // partial tiles of the `split` waves that share a pair: summed through LDS (one 27-KB buffer per pair, the sharing
+  // waves take turns), then one slab write per pair.  Every wave runs the same barrier sequence.
+  __shared__ float red[2][27 * 4 * 64];
+  float* mine = red[(wave / p.split) & 1];
+  for (int turn = 1; turn < p.split; ++turn) {
+    if (part == turn) {
+#pragma unroll
+      for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mine[(t * 4 + i) * 64 + lane] = acc[t][i];
+    }
+    __syncthreads();
+    if (part == 0) {
+#pragma unroll
+      for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] += mine[(t * 4 + i) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  if (part == 0 && b_ok) {
+    float* out = p.slab + (long long)blockIdx.x * p.A * p.Bc * 27;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = na * 16 + 4 * q + i;
+      if (row < p.A) {
+        float* o = out + ((long long)row * p.Bc + bcol) * 27;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) o[t] = acc[t][i];
+      }
+    }
+  }
+}
+
+__global__ void slab_sum_kernel(const float* __restrict__ slab, int nslab, int n, float* __restrict__ out, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 3 < nslab; k += 4) {
+    s0 += slab[(long long)k * n + i];
+    s1 += slab[(long long)(k + 1) * n + i];
+    s2 += slab[(long long)(k + 2) * n + i];
+    s3 += slab[(long long)(k + 3) * n + i];
+  }
+  for (; k < nslab; ++k) s0 += slab[(long long)k * n + i];
+  const float v = (s0 + s1) + (s2 + s3);
+  out[i] = accumulate ? out[i] + v : v;
+}
+
+}  // namespace
+
+extern "C" int64_t mdf_conv3d_wgrad_workspace(int B, int Ds, int Hs, int Ws, int A, int Bc) {
+  if (B < 1 || Ds < 1 || Hs < 1 || Ws < 1 || A < 1 || Bc < 1) return 0;
+  const long long items = (long long)B * Ds * Hs * ((Ws + 15) / 16);
+  long long g = items / 8;
+  if (g < 1) g = 1;
+  if (g > 512) g = 512;
+  return g * A * Bc * 27;   // floats
+}
+
+extern "C" int mdf_conv3d_wgrad(const float* small_, const float* big, float* dw, float* workspace, int B, int Ds, int Hs, int Ws,
+                                int A, int Bc, int stride, int accumulate, void* stream) {
+  MDF_REQUIRE(small_ && big && dw && workspace, "null pointer argument");
+  MDF_REQUIRE(B > 0 && Ds > 0 && Hs > 0 && Ws > 0, "bad shape");
+  MDF_REQUIRE(stride == 1 || stride == 2, "stride must be 1 or 2");
+  MDF_REQUIRE(A >= 1 && A <= 64 && Bc >= 1 && Bc <= 64, "channel counts out of range (A=%d, B=%d)", A, Bc);
+  MDF_REQUIRE((long long)B * Ds * Hs * Ws * stride * stride * stride * (A > Bc ? A : Bc) < (1ll << 40), "volume too large");
+  WgradParams p{};
+  p.small_ = small_; p.big = big; p.slab = workspace;
+  p.B = B; p.Ds = Ds; p.Hs = Hs; p.Ws = Ws; p.Db = Ds * stride; p.Hb = Hs * stride; p.Wb = Ws * stride; p.A = A; p.Bc = Bc; p.stride = stride;
+  p.chunks_per_row = (Ws + 15) / 16;
+  p.n_items = (long long)B * Ds * Hs * p.chunks_per_row;
+  const int NA = (A + 15) / 16;
+  p.NB = (Bc + 15) / 16;
+  const int pairs = NA * p.NB;
+  p.split = pairs >= 4 ? 1 : (pairs == 2 ? 2 : 4);
+  const int gy = (pairs * p.split + 3) / 4;
+  const int gx = (int)(mdf_conv3d_wgrad_workspace(B, Ds, Hs, Ws, A, Bc) / ((long long)A * Bc * 27));
+  hipLaunchKernelGGL(wgrad_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, p);
+  if (int rc = mdf::check_launch("wgrad_kernel")) return rc;
+  const int n = A * Bc * 27;
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace, gx, n, dw, accumulate);
+  return mdf::check_launch("slab_sum_kernel");
+}

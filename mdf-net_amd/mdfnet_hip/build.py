@@ -14,7 +14,8 @@ LIB = os.path.join(PKG, "libmdfnet_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 # -ffp-contract=off: every fma in the kernels is explicit (bit-exact warp arithmetic)
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}", "-I", INCLUDE, "-I", CSRC,
+# -munsafe-fp-atomics: fp32/fp64 atomic adds of the training kernels compile to hardware atomics, not CAS loops
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics", f"--offload-arch={ARCH}", "-I", INCLUDE, "-I", CSRC,
          "-Wall", "-Wno-unused-function"]
 
 

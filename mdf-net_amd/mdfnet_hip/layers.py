@@ -45,6 +45,26 @@ def cache_of(mod):
     return c
 
 
+def cache_of_key(mod, name):
+    """Several derived values per module (forward pack, input-gradient pack, ...)."""
+    d = mod.__dict__.get("_mdf_caches")
+    if d is None:
+        d = mod.__dict__["_mdf_caches"] = {}
+    c = d.get(name)
+    if c is None:
+        c = d[name] = _Folded()
+    return c
+
+
+def hip_train(mod, *tensors):
+    """True when the slot runs its TRAINING mode on the hand-written kernels: module in training mode (or an enclosing
+    CoreNet in training mode) with its tensors on a GPU.  CPU tensors in training mode take the stock-op route
+    (mdfnet_hip/stockops.py), which exists for the reference-pinned CPU tests and the gloo rehearsals only."""
+    ts = [t for t in tensors if isinstance(t, torch.Tensor)]
+    training = mod.training if mod is not None else bool(getattr(_mode, "training", False))
+    return training and len(ts) > 0 and all(t.is_cuda for t in ts)
+
+
 def hip_eval(mod, x):
     """True when the fused HIP path applies: eval mode on a GPU tensor."""
     return (not mod.training) and x.is_cuda

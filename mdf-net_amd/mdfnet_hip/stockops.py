@@ -16,9 +16,9 @@ def homo_warping(src_fea, src_proj, ref_proj, depth_hypos):
     d = depth_hypos.shape[1]
     with torch.no_grad():
         m = torch.matmul(src_proj, torch.inverse(ref_proj))
-        ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32, device=src_fea.device),
-                                torch.arange(w, dtype=torch.float32, device=src_fea.device), indexing="ij")
-        pix = torch.stack((xs.reshape(-1), ys.reshape(-1), torch.ones(h * w, device=src_fea.device)))
+        ys, xs = torch.meshgrid(torch.arange(h, dtype=src_fea.dtype, device=src_fea.device),
+                                torch.arange(w, dtype=src_fea.dtype, device=src_fea.device), indexing="ij")
+        pix = torch.stack((xs.reshape(-1), ys.reshape(-1), torch.ones(h * w, dtype=src_fea.dtype, device=src_fea.device)))
         ray = torch.matmul(m[:, :3, :3], pix.unsqueeze(0).expand(b, 3, h * w))
         pts = ray.unsqueeze(2) * depth_hypos.reshape(b, 1, d, -1) + m[:, :3, 3].reshape(b, 3, 1, 1)
         uv = pts[:, :2] / pts[:, 2:3]

@@ -67,7 +67,7 @@ class CoreNet(torch.nn.Module):
             ref_proj, src_projs = self.scale(intrinsics, extrinsics, stage)
             hypos = make_hypos(depth, depth_range, prob, hypos, upsample=True)
             cost = aggregate(feats, ref_proj, src_projs, hypos)
-            if (not self.training and getattr(regular, "fused_regress", False)
+            if ((not self.training or cost.is_cuda) and getattr(regular, "fused_regress", False)
                     and getattr(self.Depth_regress, "mdf_builtin", False)):
                 # both slots are the built-in ones: the soft-argmin (core.py:64) rides in the regulariser's softmax kernel
                 # (same arithmetic as the standalone slot, asserted equal in tests/test_regular_gpu.py)

@@ -30,7 +30,8 @@ class HyposByFit(nn.Module):
     def forward(self, depth, depth_range, prob_volume, depth_hypos, upsample=False):
         if depth is None:
             return self._uniform(depth_range)
-        if not layers.use_hip(self, depth.detach(), prob_volume.detach()):
+        on_gpu = depth.is_cuda and prob_volume.is_cuda      # no gradient flows here (depthhypos.py:40): same kernels in training
+        if not on_gpu and not layers.use_hip(self, depth.detach(), prob_volume.detach()):
             if self.curve_calss not in _MODES:
                 raise NotImplementedError(f"HyposByFit curve '{self.curve_calss}' is not built (gauss1, laplace are)")
             return stockops.hypos_by_fit(self.curve_calss, self.prob_thresh, self.ndepths, depth.detach(), depth_range,

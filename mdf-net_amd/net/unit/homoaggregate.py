@@ -27,6 +27,11 @@ class VectorAggregate(nn.Module):
         return layers.cache_of(self).get(list(sd.values()), lambda: ops.fold_view_weight(sd, self.ngroups, prefix=""))
 
     def forward(self, features, ref_proj, src_projs, depth_hypos):
+        if layers.hip_train(self, *features, depth_hypos):
+            # training on the GPU: two-pass batch-statistics BatchNorm3d(1), backward as an atomic scatter (train_ops.py)
+            from mdfnet_hip import train_ops
+            proj = _projections(ref_proj, src_projs, features[0].device)
+            return train_ops.aggregate_train(self, list(features), proj, depth_hypos)
         if not layers.use_hip(self, *features, depth_hypos):
             # training path (autograd, batch-stat BN in depth_weight): stock PyTorch ops, see mdfnet_hip/stockops.py
             return stockops.vector_aggregate(self.depth_weight, self.ngroups, features, ref_proj, src_projs, depth_hypos)

@@ -14,14 +14,18 @@ from mdfnet_hip.layers import cache_of as _cache
 from .base import ConvBNReLU3D
 
 
-def run_layer(block, x, res=None):
-    """block: ConvBNReLU3D, or (conv|convT, bn) pair.  x/res/return: [B,D,H,W,C] NDHWC."""
+def run_layer(block, x, res=None, tape=None):
+    """block: ConvBNReLU3D, or (conv|convT, bn) pair.  x/res/return: [B,D,H,W,C] NDHWC.  With a `tape` (training mode,
+    mdfnet_hip/train_ops.py:Tape) the layer runs conv -> BatchNorm3d(batch statistics) -> ReLU (+ res) on the training
+    kernels and is recorded for the backward pass; without, it is one fused eval launch (BN folded)."""
     conv, bn = (block.conv, block.bn) if isinstance(block, ConvBNReLU3D) else block
     tr = isinstance(conv, nn.ConvTranspose3d)
-    if conv.training or bn.training:
-        raise NotImplementedError("regulariser: the HIP path is eval/forward-only (train-mode BN/backward not built)")
     if tuple(conv.kernel_size) != (3, 3, 3):
         raise NotImplementedError("conv3d kernel is built for 3x3x3 only")
+    if tape is not None:
+        return tape.layer(conv, bn, x, res)
+    if conv.training or bn.training:
+        raise RuntimeError("regulariser layer in training mode without a tape (use the module's forward)")
     tensors = [conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var]
     wpack, alpha, beta = _cache(conv).get(tensors, lambda: (ops.pack_conv3d_weight(conv.weight, tr),)
                                           + ops.fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps))
@@ -46,15 +50,18 @@ class RegularNet_3Scales(nn.Module):
         self.conv10 = nn.Sequential(*_up(b, a))
         self.prob = nn.Conv3d(a, 1, 3, stride=1, padding=1, bias=False)
 
-    def features(self, x):
+    def features(self, x, tape=None):
         """cost [B,D,H,W,C] -> last feature volume before `prob` (NDHWC)."""
         assert x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0, f"cost volume H,W must be divisible by 4: {tuple(x.shape)}"
-        x = run_layer(self.conv01[1], run_layer(self.conv01[0], x))
-        x1 = run_layer(self.conv12[0], x)
-        x1 = run_layer(self.conv12[2], run_layer(self.conv12[1], x1))
-        y = run_layer(self.conv232[2], run_layer(self.conv232[1], run_layer(self.conv232[0], x1)))
-        x1 = run_layer((self.conv232[3], self.conv232[4]), y, res=x1)     # x1 + relu(bn(convT(y)))
-        return run_layer((self.conv10[0], self.conv10[1]), x1, res=x)     # x + relu(bn(convT(x1)))
+
+        def L(block, t, res=None):
+            return run_layer(block, t, res, tape)
+        x = L(self.conv01[1], L(self.conv01[0], x))
+        x1 = L(self.conv12[0], x)
+        x1 = L(self.conv12[2], L(self.conv12[1], x1))
+        y = L(self.conv232[2], L(self.conv232[1], L(self.conv232[0], x1)))
+        x1 = L((self.conv232[3], self.conv232[4]), y, res=x1)     # x1 + relu(bn(convT(y)))
+        return L((self.conv10[0], self.conv10[1]), x1, res=x)     # x + relu(bn(convT(x1)))
 
     def _stock_forward(self, x):
         """Training path (autograd, batch-stat BN): the same layer program with the stock modules."""
@@ -68,6 +75,10 @@ class RegularNet_3Scales(nn.Module):
 
     def forward(self, x: torch.Tensor, depth_hypos=None):
         """cost [B,C,D,H,W] -> prob [B,D,H,W]; with depth_hypos also returns the soft-argmin depth."""
+        if layers.hip_train(self, x):
+            # training on the GPU: every layer forward + backward on the hand-written kernels (mdfnet_hip/train_ops.py)
+            from mdfnet_hip import train_ops
+            return train_ops.regulariser_train(self, x, depth_hypos)
         if not layers.use_hip(self, x):
             prob = self._stock_forward(x)
             return prob if depth_hypos is None else (prob, torch.sum(prob * depth_hypos, 1))
@@ -93,15 +104,18 @@ class RegularNet_4Scales(nn.Module):
         self.trconv21 = nn.Sequential(*_up(b, a, sample_padding, sample_stride))
         self.prob = nn.Conv3d(a, 1, 3, stride=1, padding=1, bias=False)
 
-    def features(self, x):
+    def features(self, x, tape=None):
         assert x.shape[2] % 8 == 0 and x.shape[3] % 8 == 0, f"cost volume H,W must be divisible by 8: {tuple(x.shape)}"
-        x1 = run_layer(self.conv01, x)
-        x2 = run_layer(self.conv12[1], run_layer(self.conv12[0], x1))
-        x3 = run_layer(self.conv23[1], run_layer(self.conv23[0], x2))
-        y = run_layer(self.conv343[1], run_layer(self.conv343[0], x3))
-        x3 = run_layer((self.conv343[2], self.conv343[3]), y, res=x3)
-        x2 = run_layer((self.trconv32[0], self.trconv32[1]), x3, res=x2)
-        return run_layer((self.trconv21[0], self.trconv21[1]), x2, res=x1)
+
+        def L(block, t, res=None):
+            return run_layer(block, t, res, tape)
+        x1 = L(self.conv01, x)
+        x2 = L(self.conv12[1], L(self.conv12[0], x1))
+        x3 = L(self.conv23[1], L(self.conv23[0], x2))
+        y = L(self.conv343[1], L(self.conv343[0], x3))
+        x3 = L((self.conv343[2], self.conv343[3]), y, res=x3)
+        x2 = L((self.trconv32[0], self.trconv32[1]), x3, res=x2)
+        return L((self.trconv21[0], self.trconv21[1]), x2, res=x1)
 
     def _stock_forward(self, x):
         x1 = self.conv01(x)
@@ -115,6 +129,10 @@ class RegularNet_4Scales(nn.Module):
     fused_regress = True   # forward(cost, hypos) also returns the soft-argmin depth
 
     def forward(self, x: torch.Tensor, depth_hypos=None):
+        if layers.hip_train(self, x):
+            # training on the GPU: every layer forward + backward on the hand-written kernels (mdfnet_hip/train_ops.py)
+            from mdfnet_hip import train_ops
+            return train_ops.regulariser_train(self, x, depth_hypos)
         if not layers.use_hip(self, x):
             prob = self._stock_forward(x)
             return prob if depth_hypos is None else (prob, torch.sum(prob * depth_hypos, 1))

@@ -1,9 +1,15 @@
-"""GPU: one training step on the MI355X (stock-op training path = PyTorch-ROCm autograd) vs the reference's golden."""
+"""GPU: the TRAINING path on the hand-written kernels (mdfnet_hip/train_ops.py; BASELINE config 3, train.py:36-45).
+
+Checker: torch autograd over the stock-op restatement of the slots run on the CPU (mdfnet_hip/stockops.py + the stock
+nn modules), which tests/test_train_cpu.py pins to the reference's own training golden (loss and gradients, rtol 1e-4); plus
+that golden directly.  Tolerances are summation-order level: fp32 sums over 1e5..1e7 voxels in a different order."""
 import numpy as np
 import pytest
 import torch
+import torch.nn as nn
+import torch.nn.functional as F
 
-from mdfnet_hip import ddp, synth
+from mdfnet_hip import ddp, ops, synth, train_ops
 from modelutil import build_model
 
 pytestmark = pytest.mark.gpu
@@ -11,29 +17,307 @@ T = torch.from_numpy
 DEV = "cuda:0"
 
 
-def test_training_step_on_gpu_vs_reference_golden(golden, seeded_sd):
+def _rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+def _l2(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).norm() / b.norm().clamp(min=1e-30))
+
+
+# ----------------------------------------------------------------------------------------------- kernels one by one
+@pytest.mark.parametrize("c", [8, 16, 32, 64])
+def test_bn_relu_train_forward_backward(c):
+    torch.manual_seed(c)
+    shape = (2, 6, 10, 12, c)
+    n = 2 * 6 * 10 * 12
+    y = torch.randn(shape) * 2 + 0.3
+    res = torch.randn(shape)
+    bn = nn.BatchNorm3d(c)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.3, 0.3)
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.5, 2.0)
+    ref_bn = nn.BatchNorm3d(c)
+    ref_bn.load_state_dict(bn.state_dict())
+    ref_bn.train()
+    yr = y.permute(0, 4, 1, 2, 3).clone().requires_grad_(True)
+    zr = res.permute(0, 4, 1, 2, 3) + F.relu(ref_bn(yr))
+    dz = torch.randn(shape)
+    zr.backward(dz.permute(0, 4, 1, 2, 3))
+    bn = bn.to(DEV)
+    yd = y.to(DEV)
+    aux = train_ops.bn_finalize(train_ops.bn_stats(yd, n, c), bn, n, c)
+    z = train_ops.bn_relu_apply(yd, aux, res.to(DEV), n, c)
+    assert _rel(z, zr.permute(0, 2, 3, 4, 1)) < 1e-5
+    assert _rel(bn.running_mean, ref_bn.running_mean) < 1e-5 and _rel(bn.running_var, ref_bn.running_var) < 1e-5
+    assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked) == 1
+    dy, dgamma, dbeta = train_ops.bn_relu_backward(dz.to(DEV), yd, aux, bn.weight, n, c)
+    assert _rel(dy, yr.grad.permute(0, 2, 3, 4, 1)) < 2e-5
+    assert _rel(dgamma, ref_bn.weight.grad) < 2e-5 and _rel(dbeta, ref_bn.bias.grad) < 2e-5
+
+
+@pytest.mark.parametrize("cin,cout,stride,tr", [
+    (32, 16, 1, False), (16, 16, 1, False), (32, 32, 1, False), (64, 64, 1, False), (16, 8, 1, False), (8, 8, 1, False),
+    (16, 32, 2, False), (32, 64, 2, False), (8, 16, 2, False), (64, 32, 2, True), (32, 16, 2, True), (16, 8, 2, True)])
+def test_conv3d_input_and_weight_gradients(cin, cout, stride, tr):
+    """dgrad (the forward kernel family on re-packed weights) and wgrad (csrc/wgrad.hip) of every layer kind of the two
+    regularisers vs torch autograd on the CPU; odd w (masked chunk tails) and a non-multiple-of-16 row length."""
+    torch.manual_seed(cin * 100 + cout + stride)
+    d, h, w = (4, 6, 22) if not tr else (2, 3, 11)
+    if stride == 2 and not tr:
+        d, h, w = 4, 6, 20
+    conv = (nn.ConvTranspose3d(cin, cout, 3, stride=2, padding=1, output_padding=1, bias=False) if tr
+            else nn.Conv3d(cin, cout, 3, stride=stride, padding=1, bias=False))
+    x = torch.randn(2, cin, d, h, w, requires_grad=True)
+    y = conv(x)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    convd = conv.to(DEV)
+    xd = ops.to_ndhwc(x.detach().to(DEV))
+    dyd = ops.to_ndhwc(dy.to(DEV))
+    dx = train_ops.conv3d_dgrad(convd, tr, dyd)
+    assert _rel(ops.from_ndhwc(dx), x.grad) < 2e-5
+    extra = torch.randn_like(dx)
+    dx2 = train_ops.conv3d_dgrad(convd, tr, dyd, add_to=extra)          # fused accumulation into a skip gradient
+    assert _rel(dx2, dx + extra) < 1e-5
+    dw = train_ops.conv3d_wgrad(xd, dyd, 2, tuple(conv.weight.shape)) if tr else train_ops.conv3d_wgrad(dyd, xd, stride, tuple(conv.weight.shape))
+    assert _rel(dw, conv.weight.grad.cpu()) < 3e-5
+
+
+@pytest.mark.parametrize("c,d", [(8, 8), (16, 24)])
+def test_prob_head_backward(c, d):
+    torch.manual_seed(c)
+    b, h, w = 2, 12, 20
+    conv = nn.Conv3d(c, 1, 3, padding=1, bias=False)
+    x = torch.randn(b, c, d, h, w, requires_grad=True)
+    hyp = 425 + 500 * torch.rand(b, d, h, w)
+    prob = F.softmax(conv(x).squeeze(1), dim=1)
+    depth = torch.sum(prob * hyp, 1)
+    dd, dp = torch.randn_like(depth), 0.1 * torch.randn_like(prob)
+    (depth * dd).sum().backward(retain_graph=True)
+    gx1, gw1 = x.grad.clone(), conv.weight.grad.clone()
+    x.grad = None; conv.weight.grad = None
+    ((depth * dd).sum() + (prob * dp).sum()).backward()
+    xd = ops.to_ndhwc(x.detach().to(DEV))
+    w_dev = conv.weight.detach().to(DEV)
+    probd, depthd = ops.prob_head(xd, w_dev, hyp.to(DEV))
+    assert _rel(probd, prob) < 1e-4 and _rel(depthd, depth) < 1e-5
+    dx, dw = train_ops.prob_head_backward(probd, hyp.to(DEV), dd.to(DEV), None, xd, w_dev)
+    assert _rel(ops.from_ndhwc(dx), gx1) < 1e-4 and _rel(dw, gw1) < 1e-4
+    dx, dw = train_ops.prob_head_backward(probd, hyp.to(DEV), dd.to(DEV), dp.to(DEV), xd, w_dev)
+    assert _rel(ops.from_ndhwc(dx), x.grad) < 1e-4 and _rel(dw, conv.weight.grad) < 1e-4
+
+
+@pytest.mark.parametrize("stage,b,h,w,nviews,per_pixel", [(0, 2, 12, 20, 3, False), (1, 1, 24, 36, 4, True), (2, 1, 32, 48, 5, True)])
+def test_vector_aggregate_training_forward_backward(stage, b, h, w, nviews, per_pixel):
+    """Homoaggre[s] in training mode (batch-statistics BatchNorm3d(1) per source-view call, running stats, gradient to
+    reference and source features and to the five head parameters) vs autograd over the stock ops on the CPU."""
+    from net.unit.homoaggregate import VectorAggregate
+    from net.unit.scale import scale_cam
+    c, g, d = ((64, 32, 48), (32, 16, 24), (16, 8, 8))[stage]
+    torch.manual_seed(stage)
+    mod = VectorAggregate(g)
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.add_(0.3 * torch.randn_like(p))
+    ref = VectorAggregate(g)
+    ref.load_state_dict(mod.state_dict())
+    intr, extr, dr = synth.make_cameras(w * 2 ** (3 - stage), h * 2 ** (3 - stage), nviews, batch=b, rot_deg=2.0, seed=stage + 7)
+    rp, sps = scale_cam(intr, extr, stage)
+    feats = [torch.randn(b, c, h, w, requires_grad=True) for _ in range(nviews)]
+    if per_pixel:
+        hyp = (425 + 510 * torch.rand(b, 1, h, w)) + torch.linspace(-20, 20, d).reshape(1, d, 1, 1)
+    else:
+        hyp = torch.linspace(425, 935, d).reshape(1, d, 1, 1).repeat(b, 1, 1, 1)
+    import copy
+    ref.train()
+    ref64 = copy.deepcopy(ref).double()
+    cost_ref = ref(feats, rp, sps, hyp)                       # CPU tensors in training mode: stock ops + autograd
+    dcost = torch.randn_like(cost_ref)
+    cost_ref.backward(dcost)
+    f64 = [f.detach().double().requires_grad_(True) for f in feats]
+    cost64 = ref64(f64, rp.double(), tuple(s_.double() for s_ in sps), hyp.double())     # float64 yardstick (same sample positions
+    cost64.backward(dcost.double())                                                       #  up to fp64-vs-fp32 rounding of the grid)
+    mod.train().to(DEV)
+    fd = [f.detach().to(DEV).requires_grad_(True) for f in feats]
+    cost = mod(fd, rp.to(DEV), tuple(s.to(DEV) for s in sps), hyp.to(DEV))
+    assert cost.shape == cost_ref.shape and _rel(cost, cost_ref) < 2e-5
+    cost.backward(dcost.to(DEV))
+    bn, rbn = mod.depth_weight[0].bn, ref.depth_weight[0].bn
+    assert _rel(bn.running_mean, rbn.running_mean) < 1e-5 and _rel(bn.running_var, rbn.running_var) < 1e-4
+    assert int(bn.num_batches_tracked) == int(rbn.num_batches_tracked) == nviews - 1
+    print(f"\nstage {stage}: cost L2 error vs float64: HIP {_l2(cost, cost64):.1e} | fp32 CPU autograd {_l2(cost_ref, cost64):.1e}; "
+          f"d ref-feature: HIP {_l2(fd[0].grad, f64[0].grad):.1e} | CPU {_l2(feats[0].grad, f64[0].grad):.1e}; "
+          f"d src-feature: HIP {_l2(fd[1].grad, f64[1].grad):.1e} | CPU {_l2(feats[1].grad, f64[1].grad):.1e}")
+    for i, (a, r_) in enumerate(zip(fd, feats)):
+        assert _rel(a.grad, r_.grad) < 2e-4, f"feature {i}"
+    for (k, pa), (_, pr) in zip(mod.named_parameters(), ref.named_parameters()):
+        # the scalar head parameters are sums of ~1e5 signed terms that cancel to ~1e-5 of sum|terms|: fp32 noise of EITHER
+        # side (the CPU autograd reference included) is ~1e-3 of the result
+        assert _rel(pa.grad, pr.grad) < (5e-4 if pa.numel() > 1 else 1e-2), k
+
+
+@pytest.mark.parametrize("weights", ["default_init", "seeded_peaked"])
+@pytest.mark.parametrize("stage", [0, 1, 2])
+def test_regulariser_training_forward_backward(stage, weights, seeded_sd):
+    """Regular[s] + soft-argmin in training mode: outputs, input gradient, every parameter gradient and the BatchNorm
+    running statistics vs autograd over the stock nn modules on the CPU (fp32) and in float64.
+    default_init: torch's default initialisation -- a well-conditioned chain, errors are plain fp32 rounding.
+    seeded_peaked: the golden recipe (prob conv scaled up so that volumes are peaked) -- the softmax amplifies
+    rounding anywhere in the 11-layer chain ~1e3x; the fp32 CPU autograd result is itself ~1e-3 from float64, and the
+    sequential fp32 fma chain of the MFMA (27*Cin terms) rounds a few times more than oneDNN's blocked sums."""
+    torch.manual_seed(11 + stage)
+    m = build_model()
+    if weights == "seeded_peaked":
+        m.load_state_dict(seeded_sd)
+    factor = 3.0 if weights == "default_init" else 10.0
+    import copy
+    reg_ref = m.Regular[stage].train()
+    reg64 = copy.deepcopy(reg_ref).double().train()
+    reg = copy.deepcopy(reg_ref).to(DEV)
+    g, d, h, w = ((32, 48, 12, 20), (16, 24, 24, 40), (8, 8, 48, 56))[stage]
+    torch.manual_seed(stage + 3)
+    cost = torch.rand(2, g, d, h, w, requires_grad=True)
+    hyp = (425 + 510 * torch.rand(2, 1, h, w)) + torch.linspace(-20, 20, d).reshape(1, d, 1, 1)
+    prob_ref, depth_ref = reg_ref(cost, hyp)
+    dd = torch.randn_like(depth_ref)
+    depth_ref.backward(dd)
+    # the same in float64: the yardstick.  The HIP path must be as close to float64 as the fp32 CPU reference is (x factor).
+    cost64 = cost.detach().double().requires_grad_(True)
+    prob64, depth64 = reg64(cost64, hyp.double())
+    depth64.backward(dd.double())
+    cd = cost.detach().to(DEV).requires_grad_(True)
+    prob, depth = reg(cd, hyp.to(DEV))
+    depth.backward(dd.to(DEV))
+
+    def closer(name, hip, cpu32, f64):
+        e_hip, e_cpu = _l2(hip, f64), _l2(cpu32, f64)
+        assert e_hip <= max(factor * e_cpu, 2e-5), (name, e_hip, e_cpu)
+        return e_hip, e_cpu
+    e = closer("prob", prob, prob_ref, prob64)
+    e2 = closer("depth", depth, depth_ref, depth64)
+    e3 = closer("dcost", cd.grad, cost.grad, cost64.grad)
+    print(f"\nstage {stage} {weights}: L2 error vs float64 (HIP | fp32 CPU autograd): prob {e[0]:.1e} | {e[1]:.1e}, depth {e2[0]:.1e} | {e2[1]:.1e}, "
+          f"d cost {e3[0]:.1e} | {e3[1]:.1e}")
+    assert _l2(cd.grad, cost.grad) < 1e-2
+    worst = 0.0
+    for (k, pa), (_, pr), (_, p64) in zip(reg.named_parameters(), reg_ref.named_parameters(), reg64.named_parameters()):
+        assert pa.grad is not None, k
+        eh, _ = closer(k, pa.grad, pr.grad, p64.grad)
+        worst = max(worst, eh)
+        assert _l2(pa.grad, pr.grad) < 2e-2, (k, _l2(pa.grad, pr.grad))
+    for (k, ba), (_, br) in zip(reg.named_buffers(), reg_ref.named_buffers()):
+        assert _rel(ba.float(), br.float()) < 1e-4, k
+    print(f"stage {stage}: worst parameter-gradient L2 error vs float64 {worst:.2e}")
+
+
+# ----------------------------------------------------------------------------------------------- whole model
+def _step(m, dev, g):
     from net.loss import Loss
+    imgs, extr, intr, dr = synth.make_scene(96, 64, 3, batch=2, rot_deg=3.0, seed=31)
+    out = m(imgs.to(dev), extr.to(dev), intr.to(dev), dr.to(dev))
+    gt = {k: T(g["gt" + k]).to(dev) for k in ("3", "2", "1", "0")}
+    loss = Loss()(out, gt, dr.to(dev))
+    return out, loss
+
+
+def test_training_step_on_gpu_vs_reference_golden(golden, seeded_sd):
+    """One training step (forward, loss, backward, flat-bucket gradient, Adam) with Homoaggre / Regular / Depth_regress /
+    Depth_hypos on the hand-written training kernels, against the REFERENCE's golden loss, depths and gradients."""
     g = golden("train_tiny.npz")
     m = build_model()
     m.load_state_dict(seeded_sd)
     m.train().to(DEV)
     bucket = ddp.FlatBucket(m)                      # single rank: gradients still live in ONE flat buffer
     assert bucket.flat.numel() == 1206380 and bucket.flat.is_cuda
-    imgs, extr, intr, dr = synth.make_scene(96, 64, 3, batch=2, rot_deg=3.0, seed=31)
-    out = m(imgs.to(DEV), extr.to(DEV), intr.to(DEV), dr.to(DEV))
-    gt = {k: T(g["gt" + k]).to(DEV) for k in ("3", "2", "1", "0")}
-    loss = Loss()(out, gt, dr.to(DEV))
-    bucket.zero_grad()
-    loss.backward()
+    used = []
+    orig = train_ops._abi
+    train_ops._abi = lambda name, *a, **k: (used.append(name), orig(name, *a, **k))[1]
+    try:
+        out, loss = _step(m, DEV, g)
+        bucket.zero_grad()
+        loss.backward()
+    finally:
+        train_ops._abi = orig
+    assert {"mdf_warp_aggregate_vec_train", "mdf_conv3d_wgrad", "mdf_bn_relu_bwd", "mdf_prob_conv_dgrad"} <= set(used)
     bucket.allreduce_gradients()
-    # MIOpen/rocBLAS vs oneDNN rounding, amplified by the stage-1 curve fit (H3): loss within 1e-4 relative
-    np.testing.assert_allclose(float(loss.detach()), float(g["loss"]), rtol=1e-4)
+    for i, d in enumerate(out["depth"]):
+        err = np.abs(d.detach().cpu().numpy() - g[f"depth{i}"])
+        print(f"\ndepth{i}: max |d| vs reference {err.max():.3e} mean {err.mean():.3e}")
+        # cross-host leg (goldens from the build host, SURVEY H2/H3: the fit row / projections of THIS host's LAPACK differ,
+        # 1.2-1.4e-3 mm in eval mode) on top of train-mode BatchNorm over tiny volumes; the same-host comparison with the
+        # tight bound is test_all_parameter_gradients_vs_cpu_autograd below
+        assert err.mean() < (5e-3 if i < 3 else 2e-2) and err.max() < 0.5
+    np.testing.assert_allclose(float(loss.detach()), float(g["loss"]), rtol=2e-5)
     params = dict(m.named_parameters())
+    assert all(p.grad is not None for p in params.values())
     for k in g:
         if k.startswith("grad:"):
             ref = g[k]
             got = params[k[5:]].grad.cpu().numpy()
-            assert np.abs(got - ref).max() <= 5e-2 * np.abs(ref).max(), k
+            rel = np.abs(got - ref).max() / np.abs(ref).max()
+            print(f"{k}: max rel err {rel:.2e}")
+            # scalar parameters: cancelling sums over ~1e5 voxels whose hypotheses carry the cross-host drift (stage 2)
+            assert rel <= (5e-2 if ref.size == 1 else 5e-3), (k, rel)
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)
     opt.step()                                      # the optimizer consumes the bucket's views
     assert torch.isfinite(torch.cat([p.detach().reshape(-1) for p in m.parameters()])).all()
+
+
+def test_all_parameter_gradients_vs_cpu_autograd(golden, seeded_sd):
+    """Every one of the 158 parameter tensors: HIP training path vs the CPU stock-op path (pinned to the reference)."""
+    g = golden("train_tiny.npz")
+    ref = build_model()
+    ref.load_state_dict(seeded_sd)
+    ref.train()
+    out_ref, loss_ref = _step(ref, "cpu", g)
+    loss_ref.backward()
+    m = build_model()
+    m.load_state_dict(seeded_sd)
+    m.train().to(DEV)
+    out, loss = _step(m, DEV, g)
+    loss.backward()
+    for i, (a, b) in enumerate(zip(out["depth"], out_ref["depth"])):
+        err = (a.detach().cpu() - b.detach()).abs()
+        print(f"\ndepth{i}: HIP training path vs CPU stock path (same host): mean |d| {float(err.mean()):.3e} max {float(err.max()):.3e}")
+    assert abs(float(loss) - float(loss_ref)) <= 2e-5 * abs(float(loss_ref))
+    rows = []
+    for (k, pa), (_, pr) in zip(m.named_parameters(), ref.named_parameters()):
+        rows.append((_l2(pa.grad, pr.grad), k))
+    rows.sort(reverse=True)
+    print("\nworst parameter gradients (L2 rel err):", [(f"{e:.1e}", k) for e, k in rows[:5]], "median", np.median([e for e, _ in rows]))
+    # two fp32 implementations of a 3-stage cascade whose peaked softmaxes and small-volume BatchNorms amplify rounding
+    # (the per-operator tests above bound each piece against float64); whole-model bound: a few per cent worst case
+    assert rows[0][0] < 5e-2, rows[:5]
+    assert np.median([e for e, _ in rows]) < 5e-3
+    for (k, ba), (_, br) in zip(m.named_buffers(), ref.named_buffers()):
+        assert _rel(ba.float(), br.float()) < 2e-3, k
+
+
+def test_full_size_cfg3_training_step():
+    """BASELINE config 3 at its full size: 768x576, 5 views, one sample per GPU, forward + loss + backward + Adam."""
+    from net.loss import Loss
+    m = build_model()
+    m.load_state_dict(synth.seeded_state_dict(m.state_dict(), seed=1))
+    m.train().to(DEV)
+    bucket = ddp.FlatBucket(m)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    imgs, extr, intr, dr = synth.make_scene(768, 576, 5, batch=1, rot_deg=3.0, seed=77)
+    rng = np.random.RandomState(5)
+    gt = {k: T((425 + 510 * rng.rand(1, 576 // s, 768 // s)).astype(np.float32)).to(DEV) for k, s in (("3", 8), ("2", 4), ("1", 2), ("0", 1))}
+    losses = []
+    for it in range(2):
+        out = m(imgs.to(DEV), extr.to(DEV), intr.to(DEV), dr.to(DEV))
+        loss = Loss()(out, gt, dr.to(DEV))
+        bucket.zero_grad()
+        loss.backward()
+        bucket.allreduce_gradients()
+        opt.step()
+        losses.append(float(loss))
+    assert out["depth"][3].shape == (1, 576, 768) and all(np.isfinite(losses))
+    assert torch.isfinite(bucket.flat).all() and float(bucket.flat.abs().max()) > 0
+    print("\ncfg3 full-size losses:", losses, "peak memory GiB:", torch.cuda.max_memory_allocated() / 2 ** 30)
