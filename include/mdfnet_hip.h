@@ -219,7 +219,8 @@ int mdf_prob_conv_dgrad(const float* dlogit, const float* w, float* dx, int B, i
  *        0 stats       red_out[2v], [2v+1] += sum t_v, sum t_v^2  (t_v = Conv3d(G->1)(sim_v); fp64, zeroed by caller)
  *        1 forward     cost [B,D,h,w,G] and wsum [B,D,h,w] = sum_v w_v, with per-view (alpha_v, beta_v) from `par`
  *        2 bwd-reduce  red_out[2v], [2v+1] += sum dz_v, sum dz_v*xhat_v; red_out[2n], [2n+1] += d w2, d b2
- *        3 backward    dref [B,h,w,C] (stored), dsrc[v] [B,h,w,C] (+= by fp32 atomics; zeroed by caller), dcw[G] (+=)
+ *        3 backward    dref [B,h,w,C] (stored), dsrc[v] [B,h,w,G] (+= by fp32 atomics; zeroed by caller; the gradient of
+ *                      channel 2g of every softmax pair -- channel 2g+1 gets its negative), dcw[G] (+=)
  *      par (float): [0,G) conv weight | G: w2 | G+1: b2 | G+2: gamma | G+3: 1/N | G+4+4v: alpha_v, beta_v, mean_v,
  *      invstd_v.  Features NHWC, C in {16,32,64}, G = C/2.                                                        */
 int mdf_warp_aggregate_vec_train(int pass, const float* ref_fea, const float* const* src_feas, const float* proj,

@@ -8,8 +8,8 @@
 //   kStats      t_v = conv(G->1)(sim_v):  sum t, sum t^2 per source view                      (fp64 atomics)
 //   kFwd        cost = sum_v w_v sim_v / sum_v w_v with per-view (alpha_v, beta_v); also writes wsum = sum_v w_v
 //   kBwdReduce  per view S1 = sum dz, S2 = sum dz*xhat (BatchNorm backward), plus d w2, d b2   (fp64 atomics)
-//   kBwd        dt -> dsim -> d ref (direct store: a block owns its pixels over all planes), d src (fp32 atomic
-//               scatter through the 4 bilinear taps -- the transpose of the gather), d conv weight
+//   kBwd        dt -> dsim -> d ref (direct store: a block owns its pixels over all planes), d src (scatter through the
+//               4 bilinear taps -- the transpose of the gather -- staged in an LDS window, see warp_bwd_kernel), d conv weight
 // Same thread mapping as the eval kernel (warp_aggregate.hip): a lane owns 4 channels = 2 groups, the C/4 lanes of a
 // pixel reduce with DPP row operations, sample positions are computed once per (pixel, plane, view) into an LDS table.
 //
@@ -32,7 +32,7 @@ struct TrainParams {
   float* wsum;            // [B,D,h,w]    (same)
   double* red_out;        // kStats: [2*n_src]; kBwdReduce: [2*n_src + 2]
   float* dref;            // [B,h,w,C]
-  float* dsrc[MDF_MAX_SRC_VIEWS];   // zero-initialised by the caller
+  float* dsrc[MDF_MAX_SRC_VIEWS];   // [B,h,w,G]: gradient of the EVEN channel of every group (odd = -even); zero-initialised by the caller
   float* dcw;             // [G], zero-initialised
   Geom g;
   int B, D, n_src, hypos_per_pixel, dchunk, nblk_x;
@@ -53,7 +53,6 @@ __global__ __launch_bounds__(kThreads) void warp_train_kernel(const TrainParams 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   TapEntry* tab = reinterpret_cast<TapEntry*>(smem);
   __shared__ float part[4][KMAX];     // per-wave partial sums of the current depth chunk
-  __shared__ float dcw_sm[kThreads][2];
 
   const int hw = p.g.h * p.g.w;
   const int b = blockIdx.y;
@@ -76,13 +75,11 @@ __global__ __launch_bounds__(kThreads) void warp_train_kernel(const TrainParams 
     r[2] -= r[3];
   }
   const float cw0 = p.par[2 * sub], cw1 = p.par[2 * sub + 1];
-  const float w2 = p.par[G], b2 = p.par[G + 1], gamma = p.par[G + 2], inv_n = p.par[G + 3];
+  const float w2 = p.par[G], b2 = p.par[G + 1];
   const float* vpar = p.par + G + 4;
   const size_t map_stride = (size_t)hw * C;
   const int nred = (PASS == kStats) ? 2 * p.n_src : 2 * p.n_src + 2;
   double total = 0.0;                 // thread k < nred: block total of reduction slot k
-  float gref0 = 0.f, gref1 = 0.f;     // kBwd: d sim/d p0 accumulated over planes and views
-  float dcw0 = 0.f, dcw1 = 0.f;       // kBwd: d conv weight of this lane's two groups
 
   for (int d0 = 0; d0 < p.D; d0 += p.dchunk) {
     const int nd = min(p.dchunk, p.D - d0);
@@ -156,15 +153,6 @@ __global__ __launch_bounds__(kThreads) void warp_train_kernel(const TrainParams 
         const int d = d0 + dd;
         const size_t vox = ((size_t)b * p.D + d) * hw + pix;
         float acc0 = 0.f, acc1 = 0.f, wsum = 0.f;
-        float dN0 = 0.f, dN1 = 0.f, dDn = 0.f;
-        if (PASS == kBwd) {
-          const float2 dc = *reinterpret_cast<const float2*>(p.dcost + vox * G + 2 * sub);
-          const float2 co = *reinterpret_cast<const float2*>(p.cost + vox * G + 2 * sub);
-          const float dn = p.wsum[vox];
-          dN0 = dc.x / dn;
-          dN1 = dc.y / dn;
-          dDn = -pixel_sum<LPP>(__fmaf_rn(dc.x, co.x, dc.y * co.y)) / dn;
-        }
         for (int v = 0; v < p.n_src; ++v) {
           const TapEntry t = tab[(dd * p.n_src + v) * PPB + pl];
           const float* sp = p.src[v] + (size_t)b * map_stride + 4 * sub;
@@ -188,37 +176,6 @@ __global__ __launch_bounds__(kThreads) void warp_train_kernel(const TrainParams 
             wsum += wv;
             acc0 += wv * sim0;
             acc1 += wv * sim1;
-          } else {
-            const float dwv = pixel_sum<LPP>(__fmaf_rn(dN0, sim0, dN1 * sim1)) + dDn;
-            const float du = dwv * wv * (1.0f - wv);
-            const float dz = (z > 0.0f) ? du * w2 : 0.0f;
-            const float xh = (tt - vpar[4 * v + 2]) * vpar[4 * v + 3];
-            {
-              const float s1 = (float)p.red_in[2 * v], s2 = (float)p.red_in[2 * v + 1];
-              const float dt = gamma * vpar[4 * v + 3] * (dz - s1 * inv_n - xh * (s2 * inv_n));
-              const float ds0 = __fmaf_rn(dN0, wv, dt * cw0);
-              const float ds1 = __fmaf_rn(dN1, wv, dt * cw1);
-              if (live) {
-                dcw0 = fmaf(dt, sim0, dcw0);
-                dcw1 = fmaf(dt, sim1, dcw1);
-                gref0 = fmaf(ds0, 2.0f * q0 - 1.0f, gref0);       // d sim / d p0 = 2 q0 - 1
-                gref1 = fmaf(ds1, 2.0f * q1 - 1.0f, gref1);
-                const float g0 = ds0 * r[0] * q0 * (1.0f - q0);   // d sim / d q0 = r0 = 2 p0 - 1; softmax pair: dv0 = -dv1
-                const float g1 = ds1 * r[2] * q1 * (1.0f - q1);
-                float* gp = p.dsrc[v] + (size_t)b * map_stride + 4 * sub;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                  const float wk = t.wt[k];
-                  if (wk != 0.0f) {
-                    float* o = gp + t.off[k];
-                    unsafeAtomicAdd(o, wk * g0);
-                    unsafeAtomicAdd(o + 1, -(wk * g0));
-                    unsafeAtomicAdd(o + 2, wk * g1);
-                    unsafeAtomicAdd(o + 3, -(wk * g1));
-                  }
-                }
-              }
-            }
           }
         }
         if (PASS == kFwd && live) {
@@ -233,22 +190,207 @@ __global__ __launch_bounds__(kThreads) void warp_train_kernel(const TrainParams 
   }
 
   if ((PASS == kStats || PASS == kBwdReduce) && tid < nred) atomicAdd(&p.red_out[tid], total);
-  if (PASS == kBwd) {
-    // d ref: sim = p1 + q0*(p0 - p1) with (p0,p1) = softmax(a0,a1): d a0 = gref * p0*p1, d a1 = -d a0
-    if (live) {
-      const float p1a = r[1], p0a = 1.0f - r[1], p1b = r[3], p0b = 1.0f - r[3];
-      const float ga = gref0 * p0a * p1a, gb = gref1 * p0b * p1b;
-      *reinterpret_cast<float4*>(p.dref + ((size_t)b * hw + pix) * C + 4 * sub) = make_float4(ga, -ga, gb, -gb);
-    }
-    dcw_sm[tid][0] = dcw0;
-    dcw_sm[tid][1] = dcw1;
-    __syncthreads();
-    if (tid < G) {   // group tid lives in lane sub = tid/2 of every pixel, slot tid&1
-      float s = 0.f;
-      for (int q = 0; q < PPB; ++q) s += dcw_sm[q * LPP + (tid >> 1)][tid & 1];
-      unsafeAtomicAdd(&p.dcw[tid], s);
-    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// kBwd: the scatter.  The source-feature gradient of a softmax PAIR is antisymmetric (d v1 = -d v0), so only the even
+// channel of every group is accumulated ([B,h,w,G] buffers; the caller expands to (g, -g)).  Per (depth chunk, view)
+// the block finds the bounding box of its live taps in the source map; when it fits the LDS window the taps are
+// accumulated there with LDS atomics and the window is flushed once with DENSE global atomics (whole rows of the
+// window are contiguous in the NHWC gradient map) -- each texel is sent to memory once per chunk instead of once per
+// tap; a block whose footprint does not fit (strong rotation, very wide depth range) scatters to memory directly.
+constexpr int kWinFloats = 8192;   // 32 KiB
+
+template <int C>
+__global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p) {
+  constexpr int LPP = C / 4;
+  constexpr int PPB = kThreads / LPP;
+  constexpr int G = C / 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  TapXY* tab = reinterpret_cast<TapXY*>(smem);
+  float* win = reinterpret_cast<float*>(smem + (size_t)p.dchunk * p.n_src * PPB * sizeof(TapXY));
+  __shared__ int bb[MDF_MAX_SRC_VIEWS][4];   // xmin, xmax, ymin, ymax of the live taps of one view in this chunk
+  __shared__ float dcw_sm[kThreads][2];
+
+  const int hw = p.g.h * p.g.w;
+  const int W = p.g.w;
+  const int b = blockIdx.y;
+  const int tile = (int)mdf::xcd_remap(blockIdx.x, p.nblk_x);
+  const int pix0 = tile * PPB;
+  const int tid = threadIdx.x;
+  const int pl = tid / LPP, sub = tid % LPP;
+  const int pix = min(pix0 + pl, hw - 1);
+  const bool live = (pix0 + pl) < hw;
+
+  float r[4];
+  {
+    const float4 rv = *reinterpret_cast<const float4*>(p.ref + ((size_t)b * hw + pix) * C + 4 * sub);
+    softmax2(rv.x, rv.y, r[0], r[1]);
+    softmax2(rv.z, rv.w, r[2], r[3]);
+    r[0] -= r[1];
+    r[2] -= r[3];
   }
+  const float cw0 = p.par[2 * sub], cw1 = p.par[2 * sub + 1];
+  const float w2 = p.par[G], b2 = p.par[G + 1], gamma = p.par[G + 2], inv_n = p.par[G + 3];
+  const float* vpar = p.par + G + 4;
+  const size_t map_stride = (size_t)hw * C;
+  const size_t gmap_stride = (size_t)hw * G;
+  float gref0 = 0.f, gref1 = 0.f;     // d sim/d p0 accumulated over planes and views
+  float dcw0 = 0.f, dcw1 = 0.f;       // d conv weight of this lane's two groups
+
+  for (int d0 = 0; d0 < p.D; d0 += p.dchunk) {
+    const int nd = min(p.dchunk, p.D - d0);
+    if (tid < 4 * p.n_src) bb[tid >> 2][tid & 3] = (tid & 1) ? INT32_MIN : INT32_MAX;
+    __syncthreads();
+    const int nent = nd * p.n_src * PPB;
+    for (int e = tid; e < nent; e += kThreads) {
+      const int epl = e % PPB;
+      const int ev = (e / PPB) % p.n_src;
+      const int ed = e / (PPB * p.n_src);
+      const int epix = min(pix0 + epl, hw - 1);
+      const int yy = epix / W, xx = epix - yy * W;
+      const float* m = p.proj + ((size_t)ev * p.B + b) * 12;
+      const int d = d0 + ed;
+      const float dep = p.hypos_per_pixel ? p.hypos[((size_t)b * p.D + d) * hw + epix] : p.hypos[(size_t)b * p.D + d];
+      float ix, iy;
+      warp_position(m, (float)xx, (float)yy, dep, p.g, ix, iy);
+      TapXY t;
+      tap_weights_corners(ix, iy, p.g, t.wt, t.xa, t.xb, t.ya, t.yb);
+      tab[e] = t;
+      if ((pix0 + epl) < hw) {
+        const bool a = (t.wt[0] != 0.0f) || (t.wt[2] != 0.0f), bq = (t.wt[1] != 0.0f) || (t.wt[3] != 0.0f);   // column xa / xb live
+        const bool cq = (t.wt[0] != 0.0f) || (t.wt[1] != 0.0f), dq = (t.wt[2] != 0.0f) || (t.wt[3] != 0.0f);  // row ya / yb live
+        if (a || bq) {
+          atomicMin(&bb[ev][0], a ? t.xa : t.xb);
+          atomicMax(&bb[ev][1], bq ? t.xb : t.xa);
+          atomicMin(&bb[ev][2], cq ? t.ya : t.yb);
+          atomicMax(&bb[ev][3], dq ? t.yb : t.ya);
+        }
+      }
+    }
+    __syncthreads();
+
+    for (int v = 0; v < p.n_src; ++v) {
+      const int xmin = bb[v][0], xmax = bb[v][1], ymin = bb[v][2], ymax = bb[v][3];
+      const int ww = xmax - xmin + 1, wh = ymax - ymin + 1;
+      const bool any = (xmax >= xmin) && (ymax >= ymin);
+      const bool use_win = any && ((long long)ww * wh * G <= kWinFloats);      // block-uniform
+      if (use_win) {
+        for (int i = tid; i < ww * wh * G; i += kThreads) win[i] = 0.0f;
+        __syncthreads();
+      }
+      const float* sp = p.src[v] + (size_t)b * map_stride + 4 * sub;
+      float* gp = p.dsrc[v] + (size_t)b * gmap_stride + 2 * sub;
+      const float s1 = (float)p.red_in[2 * v], s2 = (float)p.red_in[2 * v + 1];
+      const float al = vpar[4 * v], be = vpar[4 * v + 1], mu = vpar[4 * v + 2], is = vpar[4 * v + 3];
+      for (int dd = 0; dd < nd; ++dd) {
+        const TapXY t = tab[(dd * p.n_src + v) * PPB + pl];
+        const int o0 = (t.ya * W + t.xa), o1 = (t.ya * W + t.xb), o2 = (t.yb * W + t.xa), o3 = (t.yb * W + t.xb);
+        const float4 nw = *reinterpret_cast<const float4*>(sp + (size_t)o0 * C);
+        const float4 ne = *reinterpret_cast<const float4*>(sp + (size_t)o1 * C);
+        const float4 sw = *reinterpret_cast<const float4*>(sp + (size_t)o2 * C);
+        const float4 se = *reinterpret_cast<const float4*>(sp + (size_t)o3 * C);
+        const float v0 = __fmaf_rn(se.x, t.wt[3], __fmaf_rn(sw.x, t.wt[2], __fmaf_rn(ne.x, t.wt[1], __fmul_rn(nw.x, t.wt[0]))));
+        const float v1 = __fmaf_rn(se.y, t.wt[3], __fmaf_rn(sw.y, t.wt[2], __fmaf_rn(ne.y, t.wt[1], __fmul_rn(nw.y, t.wt[0]))));
+        const float v2 = __fmaf_rn(se.z, t.wt[3], __fmaf_rn(sw.z, t.wt[2], __fmaf_rn(ne.z, t.wt[1], __fmul_rn(nw.z, t.wt[0]))));
+        const float v3 = __fmaf_rn(se.w, t.wt[3], __fmaf_rn(sw.w, t.wt[2], __fmaf_rn(ne.w, t.wt[1], __fmul_rn(nw.w, t.wt[0]))));
+        const float q0 = softmax2_p0(v0, v1), q1 = softmax2_p0(v2, v3);
+        const float sim0 = __fmaf_rn(q0, r[0], r[1]);
+        const float sim1 = __fmaf_rn(q1, r[2], r[3]);
+        const float tt = pixel_sum<LPP>(__fmaf_rn(cw0, sim0, cw1 * sim1));
+        const float z = __fmaf_rn(tt, al, be);
+        const float rl = fmaxf(z, 0.0f);
+        const float u = __fmaf_rn(rl, w2, b2);
+        const float wv = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-u * kLog2e));
+        const size_t vox = ((size_t)b * p.D + d0 + dd) * hw + pix;
+        const float2 dc = *reinterpret_cast<const float2*>(p.dcost + vox * G + 2 * sub);
+        const float2 co = *reinterpret_cast<const float2*>(p.cost + vox * G + 2 * sub);
+        const float dn = p.wsum[vox];
+        const float dN0 = dc.x / dn, dN1 = dc.y / dn;
+        const float dDn = -pixel_sum<LPP>(__fmaf_rn(dc.x, co.x, dc.y * co.y)) / dn;
+        const float dwv = pixel_sum<LPP>(__fmaf_rn(dN0, sim0, dN1 * sim1)) + dDn;
+        const float du = dwv * wv * (1.0f - wv);
+        const float dz = (z > 0.0f) ? du * w2 : 0.0f;
+        const float xh = (tt - mu) * is;
+        const float dt = gamma * is * (dz - s1 * inv_n - xh * (s2 * inv_n));
+        const float ds0 = __fmaf_rn(dN0, wv, dt * cw0);
+        const float ds1 = __fmaf_rn(dN1, wv, dt * cw1);
+        if (live) {
+          dcw0 = fmaf(dt, sim0, dcw0);
+          dcw1 = fmaf(dt, sim1, dcw1);
+          gref0 = fmaf(ds0, 2.0f * q0 - 1.0f, gref0);       // d sim / d p0 = 2 q0 - 1
+          gref1 = fmaf(ds1, 2.0f * q1 - 1.0f, gref1);
+          const float g0 = ds0 * r[0] * q0 * (1.0f - q0);   // d sim / d q0 = p0 - p1; softmax pair: d v1 = -d v0
+          const float g1 = ds1 * r[2] * q1 * (1.0f - q1);
+          const int oo[4] = {o0, o1, o2, o3};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float wk = t.wt[k];
+            if (wk != 0.0f) {
+              if (use_win) {
+                const int tx = ((k & 1) ? t.xb : t.xa) - xmin, ty = ((k & 2) ? t.yb : t.ya) - ymin;
+                float* o = win + (ty * ww + tx) * G + 2 * sub;
+                atomicAdd(o, wk * g0);
+                atomicAdd(o + 1, wk * g1);
+              } else {
+                float* o = gp + (size_t)oo[k] * G;
+                unsafeAtomicAdd(o, wk * g0);
+                unsafeAtomicAdd(o + 1, wk * g1);
+              }
+            }
+          }
+        }
+      }
+      if (use_win) {
+        __syncthreads();
+        float* gv = p.dsrc[v] + (size_t)b * gmap_stride;
+        for (int wy = 0; wy < wh; ++wy) {
+          float* grow = gv + ((size_t)(ymin + wy) * W + xmin) * G;     // ww*G contiguous floats
+          const float* wrow = win + wy * ww * G;
+          for (int j = tid; j < ww * G; j += kThreads) {
+            const float val = wrow[j];
+            if (val != 0.0f) unsafeAtomicAdd(grow + j, val);
+          }
+        }
+        __syncthreads();
+      }
+    }
+    __syncthreads();   // the next chunk overwrites tab and bb
+  }
+
+  // d ref: sim = p1 + q0*(p0 - p1) with (p0,p1) = softmax(a0,a1): d a0 = gref * p0*p1, d a1 = -d a0
+  if (live) {
+    const float p1a = r[1], p0a = 1.0f - r[1], p1b = r[3], p0b = 1.0f - r[3];
+    const float ga = gref0 * p0a * p1a, gb = gref1 * p0b * p1b;
+    *reinterpret_cast<float4*>(p.dref + ((size_t)b * hw + pix) * C + 4 * sub) = make_float4(ga, -ga, gb, -gb);
+  }
+  dcw_sm[tid][0] = dcw0;
+  dcw_sm[tid][1] = dcw1;
+  __syncthreads();
+  if (tid < G) {   // group tid lives in lane sub = tid/2 of every pixel, slot tid&1
+    float sacc = 0.f;
+    for (int qd = 0; qd < PPB; ++qd) sacc += dcw_sm[qd * LPP + (tid >> 1)][tid & 1];
+    unsafeAtomicAdd(&p.dcw[tid], sacc);
+  }
+}
+
+int launch_bwd(TrainParams& p, int C, hipStream_t st) {
+  const int lpp = C / 4, ppb = kThreads / lpp;
+  const int hw = p.g.h * p.g.w;
+  p.nblk_x = (hw + ppb - 1) / ppb;
+  int dch = 512 / (p.n_src * ppb);
+  if (dch < 1) dch = 1;
+  if (dch > p.D) dch = p.D;
+  p.dchunk = dch;
+  const size_t lds = (size_t)dch * p.n_src * ppb * sizeof(TapXY) + (size_t)kWinFloats * sizeof(float);
+  dim3 grid(p.nblk_x, p.B), block(kThreads);
+  switch (C) {
+    case 64: hipLaunchKernelGGL((warp_bwd_kernel<64>), grid, block, lds, st, p); break;
+    case 32: hipLaunchKernelGGL((warp_bwd_kernel<32>), grid, block, lds, st, p); break;
+    case 16: hipLaunchKernelGGL((warp_bwd_kernel<16>), grid, block, lds, st, p); break;
+    default: return mdf::fail(MDF_EUNSUPPORTED, "warp kernels are built for C in {16,32,64}, got %d", C);
+  }
+  return mdf::check_launch("warp_bwd_kernel");
 }
 
 template <int PASS>
@@ -311,6 +453,6 @@ extern "C" int mdf_warp_aggregate_vec_train(int pass, const float* ref_fea, cons
         MDF_REQUIRE(dsrc[v], "dsrc[%d] is null", v);
         p.dsrc[v] = dsrc[v];
       }
-      return launch_train<kBwd>(p, C, st);
+      return launch_bwd(p, C, st);
   }
 }

@@ -41,7 +41,8 @@ struct __attribute__((aligned(16))) TapEntry {
   float wt[4];  // bilinear weights; 0 for out-of-bounds taps, NaN for non-finite positions
 };
 
-__device__ __forceinline__ void make_taps(float ix, float iy, const Geom& g, int C, TapEntry& t) {
+// Weights (bit-exact w.r.t. ATen's grid_sampler) and clamped integer corners of one bilinear sample.
+__device__ __forceinline__ void tap_weights_corners(float ix, float iy, const Geom& g, float* wt, int& xa, int& xb, int& ya, int& yb) {
   const float x0f = floorf(ix), y0f = floorf(iy);
   const float fw = __fsub_rn(ix, x0f), fe = __fsub_rn(1.0f, fw);
   const float fn = __fsub_rn(iy, y0f), fs = __fsub_rn(1.0f, fn);
@@ -51,19 +52,30 @@ __device__ __forceinline__ void make_taps(float ix, float iy, const Geom& g, int
   const bool bx0 = (x0f >= 0.0f) && (x0f <= mw), bx1 = (x1f >= 0.0f) && (x1f <= mw);
   const bool by0 = (y0f >= 0.0f) && (y0f <= mh), by1 = (y1f >= 0.0f) && (y1f <= mh);
   // out-of-bounds taps read 0 in the reference; w*0 keeps NaN/inf weights NaN (z == 0 planes -> NaN).
-  t.wt[0] = (bx0 && by0) ? wnw : __fmul_rn(wnw, 0.0f);
-  t.wt[1] = (bx1 && by0) ? wne : __fmul_rn(wne, 0.0f);
-  t.wt[2] = (bx0 && by1) ? wsw : __fmul_rn(wsw, 0.0f);
-  t.wt[3] = (bx1 && by1) ? wse : __fmul_rn(wse, 0.0f);
+  wt[0] = (bx0 && by0) ? wnw : __fmul_rn(wnw, 0.0f);
+  wt[1] = (bx1 && by0) ? wne : __fmul_rn(wne, 0.0f);
+  wt[2] = (bx0 && by1) ? wsw : __fmul_rn(wsw, 0.0f);
+  wt[3] = (bx1 && by1) ? wse : __fmul_rn(wse, 0.0f);
   const int xi = (int)fminf(fmaxf(x0f, -2.0f), (float)g.w);  // NaN -> -2
   const int yi = (int)fminf(fmaxf(y0f, -2.0f), (float)g.h);
-  const int xa = min(max(xi, 0), g.w - 1), xb = min(max(xi + 1, 0), g.w - 1);
-  const int ya = min(max(yi, 0), g.h - 1), yb = min(max(yi + 1, 0), g.h - 1);
+  xa = min(max(xi, 0), g.w - 1); xb = min(max(xi + 1, 0), g.w - 1);
+  ya = min(max(yi, 0), g.h - 1); yb = min(max(yi + 1, 0), g.h - 1);
+}
+
+__device__ __forceinline__ void make_taps(float ix, float iy, const Geom& g, int C, TapEntry& t) {
+  int xa, xb, ya, yb;
+  tap_weights_corners(ix, iy, g, t.wt, xa, xb, ya, yb);
   t.off[0] = (ya * g.w + xa) * C;
   t.off[1] = (ya * g.w + xb) * C;
   t.off[2] = (yb * g.w + xa) * C;
   t.off[3] = (yb * g.w + xb) * C;
 }
+
+// The same sample with its corners kept as coordinates (kernels that address an LDS window of the source map).
+struct __attribute__((aligned(16))) TapXY {
+  int xa, xb, ya, yb;   // clamped in range
+  float wt[4];
+};
 
 // Reductions over the LPP (4/8/16) lanes of one pixel with DPP row operations (full-rate VALU, no LDS-pipe
 // permutes): xor-1 and xor-2 inside the quad, then row_half_mirror / row_mirror -- valid because after the quad steps

@@ -9,7 +9,7 @@
 // Activations are NDHWC, so the 16 channels of an MFMA row/column are 64 contiguous bytes.
 //
 // GEMM view: M = a (16 per tile), N = b (16 per tile), K = voxels -- a long K, so the kernel is a split-K GEMM: a
-// wave keeps the 27 tap tiles of ONE (a-tile, b-tile) pair in registers (108 accumulator VGPRs) while it walks its
+// wave keeps the 9 (kh,kw) tap tiles of ONE (a-tile, b-tile, kd) triple in registers (36 accumulator VGPRs) while it walks its
 // share of the voxels in chunks of 16 along w (4 MFMA k-steps of v_mfma_f32_16x16x4_f32; exact fp32 fma chain); per
 // chunk the `small` fragment is loaded once and reused by the 27 taps.  Blocks write their partial tiles to a slab,
 // a second kernel sums the slab (deterministic, no float atomics on the 27*A*B hot addresses).
@@ -43,9 +43,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   const int a = na * 16 + c16, bcol = nb * 16 + c16;
   const bool a_ok = a < p.A, b_ok = bcol < p.Bc;
 
-  f32x4 acc[27];
+  const int kd = blockIdx.z;          // one depth tap per block: 9 accumulator tiles per wave, 3x the independent work
+  f32x4 acc[9];
 #pragma unroll
-  for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int s = p.stride;
   for (long long item = (long long)blockIdx.x * p.split + part; item < p.n_items; item += (long long)gridDim.x * p.split) {
@@ -62,8 +63,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
       const int ow = ow0 + 4 * j + q;
       af[j] = (a_ok && ow < p.Ws) ? srow[(long long)ow * p.A + a] : 0.0f;
     }
-#pragma unroll
-    for (int kd = 0; kd < 3; ++kd) {
+    {
       const int id = od * s + kd - 1;
       if (id < 0 || id >= p.Db) continue;          // wave-uniform
 #pragma unroll
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         for (int kw = 0; kw < 3; ++kw) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            acc[(kd * 3 + kh) * 3 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[kw][j], acc[(kd * 3 + kh) * 3 + kw], 0, 0, 0);
+            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[kw][j], acc[kh * 3 + kw], 0, 0, 0);
         }
       }
     }
@@ -92,19 +92,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 
   // partial tiles of the `split` waves that share a pair: summed through LDS (one 27-KB buffer per pair, the sharing
   // waves take turns), then one slab write per pair.  Every wave runs the same barrier sequence.
-  __shared__ float red[2][27 * 4 * 64];
+  __shared__ float red[2][9 * 4 * 64];
   float* mine = red[(wave / p.split) & 1];
   for (int turn = 1; turn < p.split; ++turn) {
     if (part == turn) {
 #pragma unroll
-      for (int t = 0; t < 27; ++t)
+      for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) mine[(t * 4 + i) * 64 + lane] = acc[t][i];
     }
     __syncthreads();
     if (part == 0) {
 #pragma unroll
-      for (int t = 0; t < 27; ++t)
+      for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[t][i] += mine[(t * 4 + i) * 64 + lane];
     }
@@ -116,9 +116,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     for (int i = 0; i < 4; ++i) {
       const int row = na * 16 + 4 * q + i;
       if (row < p.A) {
-        float* o = out + ((long long)row * p.Bc + bcol) * 27;
+        float* o = out + ((long long)row * p.Bc + bcol) * 27 + kd * 9;
 #pragma unroll
-        for (int t = 0; t < 27; ++t) o[t] = acc[t][i];
+        for (int t = 0; t < 9; ++t) o[t] = acc[t][i];
       }
     }
   }
@@ -145,9 +145,13 @@ __global__ void slab_sum_kernel(const float* __restrict__ slab, int nslab, int n
 extern "C" int64_t mdf_conv3d_wgrad_workspace(int B, int Ds, int Hs, int Ws, int A, int Bc) {
   if (B < 1 || Ds < 1 || Hs < 1 || Ws < 1 || A < 1 || Bc < 1) return 0;
   const long long items = (long long)B * Ds * Hs * ((Ws + 15) / 16);
-  long long g = items / 8;
+  const int pairs = ((A + 15) / 16) * ((Bc + 15) / 16);
+  const int split = pairs >= 4 ? 1 : (pairs == 2 ? 2 : 4);
+  const int gy = (pairs * split + 3) / 4;
+  // enough blocks to fill the chip several times over (3 depth taps x gy pair groups x g), at least `split` chunks each
+  long long g = 2048 / (3 * gy);
+  if (g > items / split) g = items / split;
   if (g < 1) g = 1;
-  if (g > 512) g = 512;
   return g * A * Bc * 27;   // floats
 }
 
@@ -169,7 +173,7 @@ extern "C" int mdf_conv3d_wgrad(const float* small_, const float* big, float* dw
   p.split = pairs >= 4 ? 1 : (pairs == 2 ? 2 : 4);
   const int gy = (pairs * p.split + 3) / 4;
   const int gx = (int)(mdf_conv3d_wgrad_workspace(B, Ds, Hs, Ws, A, Bc) / ((long long)A * Bc * 27));
-  hipLaunchKernelGGL(wgrad_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(wgrad_kernel, dim3(gx, gy, 3), dim3(256), 0, (hipStream_t)stream, p);
   if (int rc = mdf::check_launch("wgrad_kernel")) return rc;
   const int n = A * Bc * 27;
   hipLaunchKernelGGL(slab_sum_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace, gx, n, dw, accumulate);

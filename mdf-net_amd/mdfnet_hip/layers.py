@@ -62,6 +62,8 @@ def hip_train(mod, *tensors):
     (mdfnet_hip/stockops.py), which exists for the reference-pinned CPU tests and the gloo rehearsals only."""
     ts = [t for t in tensors if isinstance(t, torch.Tensor)]
     training = mod.training if mod is not None else bool(getattr(_mode, "training", False))
+    if _TRAIN_STOCK:        # dev A/B switch (scripts/bench_train.py): PyTorch-ROCm autograd instead of the HIP training kernels
+        return False
     return training and len(ts) > 0 and all(t.is_cuda for t in ts)
 
 
@@ -71,7 +73,10 @@ def hip_eval(mod, x):
 
 
 import contextlib
+import os
 import threading
+
+_TRAIN_STOCK = bool(int(os.environ.get("MDF_TRAIN_STOCK", "0")))
 
 _mode = threading.local()
 

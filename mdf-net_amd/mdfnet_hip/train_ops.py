@@ -272,10 +272,11 @@ class AggregateTrainFn(torch.autograd.Function):
         _agg_call(_PASS_BWD_REDUCE, feas[0], feas[1:], ctx.proj, ctx.hyp, ctx.pp, ctx.par, None, dc, ctx.cost, ctx.wsum, red, None, None,
                   None, b, c, g, d, h, w)
         dref = torch.empty_like(feas[0])
-        dsrcs = [torch.zeros_like(f) for f in feas[1:]]
+        dhalf = [torch.zeros((b, h, w, g), device=dev, dtype=torch.float32) for _ in feas[1:]]   # even channel of every pair
         dcw = torch.zeros(g, device=dev, dtype=torch.float32)
-        _agg_call(_PASS_BWD, feas[0], feas[1:], ctx.proj, ctx.hyp, ctx.pp, ctx.par, red, dc, ctx.cost, ctx.wsum, None, dref, dsrcs, dcw,
+        _agg_call(_PASS_BWD, feas[0], feas[1:], ctx.proj, ctx.hyp, ctx.pp, ctx.par, red, dc, ctx.cost, ctx.wsum, None, dref, dhalf, dcw,
                   b, c, g, d, h, w)
+        dsrcs = [torch.stack((t, -t), dim=-1).reshape(b, h, w, c) for t in dhalf]      # softmax pair: d v1 = -d v0
         s_cw, s_gamma, s_beta, s_w2, s_b2 = ctx.wshapes
         dgamma = red[1:2 * nsrc:2].sum().float().reshape(s_gamma)
         dbeta = red[0:2 * nsrc:2].sum().float().reshape(s_beta)

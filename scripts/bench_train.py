@@ -1,11 +1,12 @@
-"""cfg3-shaped training step on one GPU (stock-op training path): 768x576, 5 views, batch 1, forward + loss + backward +
-flat-bucket all-reduce (1 rank) + Adam.  Informational (the headline metric is inference).  dev tool"""
-import os, sys, time
+"""cfg3-shaped training step on one GPU: 768x576, 5 views, batch 1, forward + loss + backward + flat-bucket all-reduce
+(1 rank) + Adam, on the HIP training path (MDF_TRAIN_STOCK=1: the PyTorch-ROCm autograd path, for comparison).
+Prints samples/s and the per-kernel-family time of one step (HIP events on the launch stream).  dev tool"""
+import collections, os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [R, R + '/mdf-net_amd']
 import torch
 import bench
-from mdfnet_hip import synth, ddp
+from mdfnet_hip import synth, ddp, ops
 from net import loss as loss_mod
 dev = torch.device('cuda', 0)
 W, H, V = (int(x) for x in os.environ.get("MDF_TRAIN_SHAPE", "768,576,5").split(","))
@@ -19,10 +20,28 @@ def step():
     out = model(imgs, extr, intr, dr)
     loss = crit(out, gt, dr)
     bucket.zero_grad(); loss.backward(); bucket.allreduce_gradients(); opt.step()
-    return float(loss.detach())
-for _ in range(2): l = step()
+    return loss.detach()
+for _ in range(3): l = step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
-n = 5
+n = int(os.environ.get("MDF_TRAIN_STEPS", "10"))
 for _ in range(n): l = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-print(f"train step {W}x{H}x{V} B=1: {dt*1e3:.1f} ms  ({1/dt:.2f} samples/s), loss {l:.3f}, peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
+mode = "stock PyTorch-ROCm autograd" if os.environ.get("MDF_TRAIN_STOCK") == "1" else "HIP training kernels"
+print(f"train step {W}x{H}x{V} B=1 [{mode}]: {dt*1e3:.1f} ms  ({1/dt:.2f} samples/s), loss {float(l):.3f}, peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
+if os.environ.get("MDF_TRAIN_STOCK") != "1":
+    ops.profile_begin()
+    step()
+    fam = collections.OrderedDict()
+    for name, tag, ms, work in ops.profile_end():
+        key = name.replace("mdf_", "") + ((" " + tag.split()[0] + " " + tag.split()[1]) if name == "mdf_warp_aggregate_vec_train" else "")
+        f = fam.setdefault(key, [0.0, 0, 0.0, 0.0])
+        f[0] += ms; f[1] += 1; f[2] += work.get("flops", 0.0); f[3] += work.get("bytes", 0.0)
+    tot = sum(f[0] for f in fam.values())
+    print(f"hand-written kernels in one step: {tot:.2f} ms over {sum(f[1] for f in fam.values())} launches")
+    for k, (ms, cnt, fl, by) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
+        extra = f"{fl / ms / 1e9:7.1f} TFLOP/s" if fl else (f"{by / ms / 1e6:7.0f} GB/s" if by else "")
+        print(f"  {k:42s} {ms:8.3f} ms {cnt:4d} launches {extra}")
+    if os.environ.get("MDF_TRAIN_VERBOSE"):
+        ops.profile_begin(); step()
+        for name, tag, ms, work in ops.profile_end():
+            print(f"    {name:34s} {tag:40s} {ms*1e3:9.1f} us")
