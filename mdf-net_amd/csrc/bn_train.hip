@@ -139,6 +139,14 @@ __global__ __launch_bounds__(kT) void bn_relu_bwd_kernel(const float* __restrict
   }
 }
 
+// reductions: every block ends with 2C fp64 atomics on the same 2C addresses -- few, fat blocks
+int grid_for_reduce(long long n4) {
+  long long g = (n4 + 4 * kT - 1) / (4 * kT);
+  if (g > 512) g = 512;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
 int grid_for(long long n4) {
   long long g = (n4 + kT - 1) / kT;
   if (g > 2048) g = 2048;      // 8 blocks per CU: enough bytes in flight for an HBM stream
@@ -159,7 +167,7 @@ extern "C" int mdf_bn_stats_fwd(const float* y, long long N, int C, double* sums
   if (int rc = check_bn(y, N, C)) return rc;
   MDF_REQUIRE(sums, "null pointer argument");
   const long long n4 = N * C / 4;
-  hipLaunchKernelGGL(bn_reduce_kernel<false>, dim3(grid_for(n4)), dim3(kT), 0, (hipStream_t)stream, y, nullptr, nullptr, n4, C, sums);
+  hipLaunchKernelGGL(bn_reduce_kernel<false>, dim3(grid_for_reduce(n4)), dim3(kT), 0, (hipStream_t)stream, y, nullptr, nullptr, n4, C, sums);
   return mdf::check_launch("bn_stats_kernel");
 }
 
@@ -186,7 +194,7 @@ extern "C" int mdf_bn_relu_bwd_reduce(const float* dz, const float* y, const flo
   if (int rc = check_bn(y, N, C)) return rc;
   MDF_REQUIRE(dz && aux && red, "null pointer argument");
   const long long n4 = N * C / 4;
-  hipLaunchKernelGGL(bn_reduce_kernel<true>, dim3(grid_for(n4)), dim3(kT), 0, (hipStream_t)stream, y, dz, aux, n4, C, red);
+  hipLaunchKernelGGL(bn_reduce_kernel<true>, dim3(grid_for_reduce(n4)), dim3(kT), 0, (hipStream_t)stream, y, dz, aux, n4, C, red);
   return mdf::check_launch("bn_relu_bwd_reduce_kernel");
 }
 

@@ -20,6 +20,7 @@
 //            across the pixel's lanes with wavefront shuffles, and accumulate over views.
 //
 // Compile with -ffp-contract=off: every fused multiply-add below is explicit.
+#include <cstdlib>
 #include "warp_common.h"
 
 namespace {
@@ -185,6 +186,180 @@ __global__ __launch_bounds__(kThreads) void warp_kernel(const Params p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// kVec with LDS-staged source-feature tiles.  Per depth chunk the block finds, for every source view, the bounding box
+// of its taps in that view's feature map (min/max over the tap table), loads the boxes ONCE with coalesced row loads
+// (ww*C contiguous floats per window row in NHWC) into a pool of LDS windows, and takes the 4 bilinear taps of every
+// sample from LDS: a texel crosses the L1/TA path once per chunk instead of once per tap that touches it (4 taps x
+// planes x neighbouring pixels).  The loop order, the accumulation order over views and all arithmetic are those of
+// warp_kernel<C,kVec>, so the cost volume is bit-identical.  A view whose box does not fit what is left of the pool
+// (strong rotation, wide depth range) gathers from memory as before -- a block-uniform, per-view decision.
+struct WinDesc {
+  int off;          // float offset of the window in the pool, -1: gather from memory
+  int xmin, ymin, ww;
+};
+
+template <int C>
+__global__ __launch_bounds__(kThreads) void warp_vec_win_kernel(const Params p, int pool_floats) {
+  constexpr int LPP = C / 4;
+  constexpr int PPB = kThreads / LPP;
+  constexpr int G = C / 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  TapXY* tab = reinterpret_cast<TapXY*>(smem);
+  float* pool = reinterpret_cast<float*>(smem + (size_t)p.dchunk * p.n_src * PPB * sizeof(TapXY));
+  __shared__ int bb[MDF_MAX_SRC_VIEWS][4];
+  __shared__ WinDesc wd[MDF_MAX_SRC_VIEWS];
+
+  const int hw = p.g.h * p.g.w;
+  const int W = p.g.w;
+  const int b = blockIdx.y;
+  const int tile = (int)mdf::xcd_remap(blockIdx.x, p.nblk_x);
+  const int pix0 = tile * PPB;
+  const int tid = threadIdx.x;
+  const int pl = tid / LPP, sub = tid % LPP;
+  const int pix = min(pix0 + pl, hw - 1);
+  const bool live = (pix0 + pl) < hw;
+
+  float r[4];
+  {
+    const float4 rv = *reinterpret_cast<const float4*>(p.ref + ((size_t)b * hw + pix) * C + 4 * sub);
+    softmax2(rv.x, rv.y, r[0], r[1]);
+    softmax2(rv.z, rv.w, r[2], r[3]);
+    r[0] -= r[1];
+    r[2] -= r[3];
+  }
+  const float cw0 = p.wpar[2 * sub], cw1 = p.wpar[2 * sub + 1];
+  const float alpha = p.wpar[G], beta = p.wpar[G + 1], w2 = p.wpar[G + 2], b2 = p.wpar[G + 3];
+  const size_t map_stride = (size_t)hw * C;
+
+  for (int d0 = 0; d0 < p.D; d0 += p.dchunk) {
+    const int nd = min(p.dchunk, p.D - d0);
+    if (tid < 4 * p.n_src) bb[tid >> 2][tid & 3] = (tid & 1) ? INT32_MIN : INT32_MAX;
+    __syncthreads();
+    const int nent = nd * p.n_src * PPB;
+    for (int e = tid; e < nent; e += kThreads) {
+      const int epl = e % PPB;
+      const int ev = (e / PPB) % p.n_src;
+      const int ed = e / (PPB * p.n_src);
+      const int epix = min(pix0 + epl, hw - 1);
+      const int yy = epix / W, xx = epix - yy * W;
+      const float* m = p.proj + ((size_t)ev * p.B + b) * 12;
+      const int d = d0 + ed;
+      const float dep = p.hypos_per_pixel ? p.hypos[((size_t)b * p.D + d) * hw + epix] : p.hypos[(size_t)b * p.D + d];
+      float ix, iy;
+      warp_position(m, (float)xx, (float)yy, dep, p.g, ix, iy);
+      TapXY t;
+      tap_weights_corners(ix, iy, p.g, t.wt, t.xa, t.xb, t.ya, t.yb);
+      tab[e] = t;
+      // every tap is READ (a zero weight still multiplies a finite value), so the box covers all four clamped corners
+      atomicMin(&bb[ev][0], t.xa);
+      atomicMax(&bb[ev][1], t.xb);
+      atomicMin(&bb[ev][2], t.ya);
+      atomicMax(&bb[ev][3], t.yb);
+    }
+    __syncthreads();
+    if (tid == 0) {   // hand out pool space view by view
+      int used = 0;
+      for (int v = 0; v < p.n_src; ++v) {
+        const int ww = bb[v][1] - bb[v][0] + 1, wh = bb[v][3] - bb[v][2] + 1;
+        const long long need = (long long)ww * wh * C;
+        WinDesc w_;
+        w_.xmin = bb[v][0]; w_.ymin = bb[v][2]; w_.ww = ww;
+        if (need <= pool_floats - used) { w_.off = used; used += (int)need; } else { w_.off = -1; }
+        wd[v] = w_;
+      }
+    }
+    __syncthreads();
+    for (int v = 0; v < p.n_src; ++v) {
+      const WinDesc w_ = wd[v];
+      if (w_.off < 0) continue;
+      const int wh = bb[v][3] - bb[v][2] + 1;
+      const int row4 = w_.ww * (C / 4);                 // float4s per window row, contiguous in memory
+      const float* sv = p.src[v] + (size_t)b * map_stride;
+      for (int wy = 0; wy < wh; ++wy) {
+        const float4* grow = reinterpret_cast<const float4*>(sv + ((size_t)(w_.ymin + wy) * W + w_.xmin) * C);
+        float4* lrow = reinterpret_cast<float4*>(pool + w_.off) + wy * row4;
+        for (int j = tid; j < row4; j += kThreads) lrow[j] = grow[j];
+      }
+    }
+    __syncthreads();
+
+    for (int dd = 0; dd < nd; ++dd) {
+      float acc0 = 0.f, acc1 = 0.f, wsum = 0.f;
+      for (int v = 0; v < p.n_src; ++v) {
+        const TapXY t = tab[(dd * p.n_src + v) * PPB + pl];
+        const WinDesc w_ = wd[v];
+        float4 nw, ne, sw, se;
+        if (w_.off >= 0) {
+          const float* lp = pool + w_.off + 4 * sub;
+          const int ra = (t.ya - w_.ymin) * w_.ww, rb = (t.yb - w_.ymin) * w_.ww, ca = t.xa - w_.xmin, cb = t.xb - w_.xmin;
+          nw = *reinterpret_cast<const float4*>(lp + (ra + ca) * C);
+          ne = *reinterpret_cast<const float4*>(lp + (ra + cb) * C);
+          sw = *reinterpret_cast<const float4*>(lp + (rb + ca) * C);
+          se = *reinterpret_cast<const float4*>(lp + (rb + cb) * C);
+        } else {
+          const float* sp = p.src[v] + (size_t)b * map_stride + 4 * sub;
+          nw = *reinterpret_cast<const float4*>(sp + (size_t)(t.ya * W + t.xa) * C);
+          ne = *reinterpret_cast<const float4*>(sp + (size_t)(t.ya * W + t.xb) * C);
+          sw = *reinterpret_cast<const float4*>(sp + (size_t)(t.yb * W + t.xa) * C);
+          se = *reinterpret_cast<const float4*>(sp + (size_t)(t.yb * W + t.xb) * C);
+        }
+        const float v0 = __fmaf_rn(se.x, t.wt[3], __fmaf_rn(sw.x, t.wt[2], __fmaf_rn(ne.x, t.wt[1], __fmul_rn(nw.x, t.wt[0]))));
+        const float v1 = __fmaf_rn(se.y, t.wt[3], __fmaf_rn(sw.y, t.wt[2], __fmaf_rn(ne.y, t.wt[1], __fmul_rn(nw.y, t.wt[0]))));
+        const float v2 = __fmaf_rn(se.z, t.wt[3], __fmaf_rn(sw.z, t.wt[2], __fmaf_rn(ne.z, t.wt[1], __fmul_rn(nw.z, t.wt[0]))));
+        const float v3 = __fmaf_rn(se.w, t.wt[3], __fmaf_rn(sw.w, t.wt[2], __fmaf_rn(ne.w, t.wt[1], __fmul_rn(nw.w, t.wt[0]))));
+        const float sim0 = __fmaf_rn(softmax2_p0(v0, v1), r[0], r[1]);
+        const float sim1 = __fmaf_rn(softmax2_p0(v2, v3), r[2], r[3]);
+        const float z = pixel_sum<LPP>(__fmaf_rn(cw0, sim0, cw1 * sim1));
+        const float u = __fmaf_rn(fmaxf(__fmaf_rn(z, alpha, beta), 0.0f), w2, b2);
+        const float wv = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-u * kLog2e));
+        wsum += wv;
+        acc0 += wv * sim0;
+        acc1 += wv * sim1;
+      }
+      if (!live) continue;
+      const size_t vox = ((size_t)b * p.D + d0 + dd) * hw + pix;
+      const float o0 = acc0 / wsum, o1 = acc1 / wsum;
+      if (p.out_ndhwc) {
+        *reinterpret_cast<float2*>(p.out + vox * G + 2 * sub) = make_float2(o0, o1);
+      } else {
+        const size_t cs = (size_t)p.D * hw;
+        float* o = p.out + ((size_t)b * G * p.D + d0 + dd) * hw + pix;
+        o[(size_t)(2 * sub) * cs] = o0;
+        o[(size_t)(2 * sub + 1) * cs] = o1;
+      }
+    }
+    __syncthreads();   // the next chunk overwrites tab, bb, wd and the pool
+  }
+}
+
+template <int C>
+int launch_win(Params& p, hipStream_t st) {
+  constexpr int ppb = kThreads / (C / 4);
+  const int hw = p.g.h * p.g.w;
+  p.nblk_x = (hw + ppb - 1) / ppb;
+  int dch = 512 / (p.n_src * ppb);
+  if (const char* e = getenv("MDF_WARP_DCHUNK")) { if (atoi(e) > 0) dch = atoi(e); }   // dev A/B
+  if (dch < 1) dch = 1;
+  if (dch > p.D) dch = p.D;
+  p.dchunk = dch;
+  int pool_kb = 64;
+  if (const char* e = getenv("MDF_WARP_POOL_KB")) { if (atoi(e) > 0) pool_kb = atoi(e); }   // dev A/B
+  const size_t tab_bytes = (size_t)dch * p.n_src * ppb * sizeof(TapXY);
+  const size_t lds = tab_bytes + (size_t)pool_kb * 1024;
+  if (lds > 150 * 1024) return MDF_EUNSUPPORTED;
+  static bool attr_done[64] = {};
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  if (dev_id < 0 || dev_id >= 64 || !attr_done[dev_id]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&warp_vec_win_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return mdf::fail(MDF_EHIP, "hipFuncSetAttribute(dynamic LDS): %s", hipGetErrorString(e));
+    if (dev_id >= 0 && dev_id < 64) attr_done[dev_id] = true;
+  }
+  hipLaunchKernelGGL((warp_vec_win_kernel<C>), dim3(p.nblk_x, p.B), dim3(kThreads), lds, st, p, pool_kb * 256);
+  return mdf::check_launch("warp_vec_win_kernel");
+}
+
 __global__ void corner_index_kernel(const float* __restrict__ proj, const float* __restrict__ hypos, int per_pixel,
                                     int32_t* __restrict__ out, Geom g, int B, int D) {
   const int hw = g.h * g.w;
@@ -285,6 +460,16 @@ extern "C" int mdf_warp_aggregate_vec_fwd(const float* ref_fea, const float* con
   p.proj = proj; p.hypos = hypos; p.wpar = w_params; p.out = cost;
   p.g = make_geom(h, w);
   p.B = B; p.D = D; p.n_src = n_src; p.hypos_per_pixel = hypos_per_pixel; p.out_ndhwc = (cost_layout == MDF_VOL_NDHWC);
+  // LDS-staged source windows: bit-identical, but measured SLOWER than the L1 gather on MI355X (r02: 1.37 ms vs 0.80 ms per
+  // cfg2 view at a 32-KiB pool, 3.0 ms at 64 KiB -- the kernel lives on occupancy), so it is opt-in
+  const char* we = getenv("MDF_WARP_WINDOW");
+  if (we && atoi(we) != 0) {
+    int rc = MDF_EUNSUPPORTED;
+    if (C == 64) rc = launch_win<64>(p, (hipStream_t)stream);
+    else if (C == 32) rc = launch_win<32>(p, (hipStream_t)stream);
+    else if (C == 16) rc = launch_win<16>(p, (hipStream_t)stream);
+    if (rc != MDF_EUNSUPPORTED) return rc;
+  }
   return launch<kVec>(p, C, (hipStream_t)stream);
 }
 

@@ -12,7 +12,7 @@
 // wave keeps the 9 (kh,kw) tap tiles of ONE (a-tile, b-tile, kd) triple in registers (36 accumulator VGPRs) while it walks its
 // share of the voxels in chunks of 16 along w (4 MFMA k-steps of v_mfma_f32_16x16x4_f32; exact fp32 fma chain); per
 // chunk the `small` fragment is loaded once and reused by the 27 taps.  Blocks write their partial tiles to a slab,
-// a second kernel sums the slab (deterministic, no float atomics on the 27*A*B hot addresses).
+// a second kernel sums the slab in a few dozen partial sums per element (no storm of float atomics on the 27*A*B hot addresses).
 //   A operand: lane l holds small[voxel 4j + (l>>4)][a = l&15]      C/D: lane l holds rows 4*(l>>4)..+3, column l&15
 //   B operand: lane l holds big  [voxel 4j + (l>>4)][b = l&15]
 #include "common.h"
@@ -124,20 +124,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   }
 }
 
-__global__ void slab_sum_kernel(const float* __restrict__ slab, int nslab, int n, float* __restrict__ out, int accumulate) {
+// out[i] (+)= sum over slabs: blockIdx.y takes every gridDim.y-th slab, partial sums meet in `out` through fp32 atomics
+// (a few thousand per launch, spread over n addresses)
+__global__ void slab_sum_kernel(const float* __restrict__ slab, int nslab, int n, float* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int k = 0;
-  for (; k + 3 < nslab; k += 4) {
+  float s0 = 0.f, s1 = 0.f;
+  int k = blockIdx.y;
+  for (; k + (int)gridDim.y < nslab; k += 2 * gridDim.y) {
     s0 += slab[(long long)k * n + i];
-    s1 += slab[(long long)(k + 1) * n + i];
-    s2 += slab[(long long)(k + 2) * n + i];
-    s3 += slab[(long long)(k + 3) * n + i];
+    s1 += slab[(long long)(k + gridDim.y) * n + i];
   }
-  for (; k < nslab; ++k) s0 += slab[(long long)k * n + i];
-  const float v = (s0 + s1) + (s2 + s3);
-  out[i] = accumulate ? out[i] + v : v;
+  if (k < nslab) s0 += slab[(long long)k * n + i];
+  unsafeAtomicAdd(&out[i], s0 + s1);
 }
 
 }  // namespace
@@ -176,6 +175,10 @@ extern "C" int mdf_conv3d_wgrad(const float* small_, const float* big, float* dw
   hipLaunchKernelGGL(wgrad_kernel, dim3(gx, gy, 3), dim3(256), 0, (hipStream_t)stream, p);
   if (int rc = mdf::check_launch("wgrad_kernel")) return rc;
   const int n = A * Bc * 27;
-  hipLaunchKernelGGL(slab_sum_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace, gx, n, dw, accumulate);
+  if (!accumulate) (void)hipMemsetAsync(dw, 0, (size_t)n * sizeof(float), (hipStream_t)stream);
+  int gys = gx / 8;                       // >= 8 slabs per partial sum
+  if (gys < 1) gys = 1;
+  if (gys > 32) gys = 32;
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((n + 255) / 256, gys), dim3(256), 0, (hipStream_t)stream, workspace, gx, n, dw);
   return mdf::check_launch("slab_sum_kernel");
 }

@@ -28,7 +28,7 @@ for _ in range(n): l = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 mode = "stock PyTorch-ROCm autograd" if os.environ.get("MDF_TRAIN_STOCK") == "1" else "HIP training kernels"
 print(f"train step {W}x{H}x{V} B=1 [{mode}]: {dt*1e3:.1f} ms  ({1/dt:.2f} samples/s), loss {float(l):.3f}, peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
-if os.environ.get("MDF_TRAIN_STOCK") != "1":
+if os.environ.get("MDF_TRAIN_STOCK") != "1" and not os.environ.get("MDF_TRAIN_NOPROFILE"):
     ops.profile_begin()
     step()
     fam = collections.OrderedDict()
