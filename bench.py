@@ -129,8 +129,11 @@ def measured_traffic():
         return json.load(f).get("families", {})
 
 
-def cpu_baseline(sample_views=1):
-    """Oracle (CPU port of the reference algorithm) on the host cores; bounded sample of the same workload."""
+def cpu_baseline(timed_views=3):
+    """Oracle (CPU port of the reference algorithm) on the host cores; bounded sample of the same workload: BASELINE.md
+    section 3's protocol -- 1 full-size warm-up view + 3 timed full-size views, median."""
+    import platform
+    import statistics
     from mdfnet_hip import synth
     from oracle import mvs_oracle as O
     model_sd = synth.seeded_state_dict(build("cpu").state_dict(), seed=1)
@@ -142,17 +145,26 @@ def cpu_baseline(sample_views=1):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, int(os.environ.get("MDF_CPU_BASELINE_THREADS", "16"))))
     torch.set_num_threads(cores)
+    cpu_model = platform.processor() or "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next(ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
+    times = []
     with torch.no_grad():
-        tiny = synth.make_scene(160, 128, 3, seed=0)
-        O.core_forward(model_sd, *tiny)  # warm oneDNN / thread pool
         scene = synth.make_scene(WIDTH, HEIGHT, VIEWS, seed=0)
-        t0 = time.time()
-        for _ in range(sample_views):
+        O.core_forward(model_sd, *scene)          # full-size warm-up (oneDNN primitives, thread pool, page faults)
+        for _ in range(timed_views):
+            t0 = time.time()
             O.core_forward(model_sd, *scene)
-        dt = time.time() - t0
-    return {"value": round(sample_views / dt, 4), "unit": "views/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{sample_views} full-size view(s) ({WIDTH}x{HEIGHT}x{VIEWS}, hypotheses 48/24/8) through oracle.core_forward "
-                      f"(torch {torch.__version__} CPU, {cores} threads), {dt:.1f} s"}
+            times.append(time.time() - t0)
+    med = statistics.median(times)
+    return {"value": round(1.0 / med, 4), "unit": "views/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu": cpu_model,
+            "sample": f"1 warm-up + {timed_views} timed full-size views ({WIDTH}x{HEIGHT}x{VIEWS}, hypotheses 48/24/8) through "
+                      f"oracle.core_forward (torch {torch.__version__} CPU, {cores} threads on {cpu_model}); median {med:.2f} s/view, "
+                      f"all {[round(t, 2) for t in times]}"}
 
 
 def main():
@@ -282,6 +294,8 @@ def main():
                                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                                    "traffic": (round(traffic["mfma_conv"]["hbm_bytes_per_forward"]) if "mfma_conv" in traffic else None),
                                    "traffic_unit": "HBM bytes per step over all launches of the family (PMC, offline)",
+                                   "mode": "one view at a time on one stream (profile pass after the timed region: per-launch HIP events "
+                                           "on the launch stream); compare with one_at_a_time, not with the in-flight headline",
                                    "ms_per_step": round(ms, 3),
                                    "launches_per_step": sum(k["launches_per_step"] for k in mf),
                                    "algorithmic_gflop_per_step": round(gf, 1)}

@@ -136,3 +136,31 @@ def test_full_size_cfg2_parity_vs_live_oracle(model, seeded_sd):
     assert out["depth"].shape == (1, 1184, 1600) and np.isfinite(err).all()
     assert err.mean() <= 1e-3
     assert cerr.mean() <= 1e-4
+
+
+@pytest.mark.parametrize("views", [7, 11])
+def test_full_size_cfg4_parity_vs_live_oracle(model, seeded_sd, views):
+    """BASELINE config 4 at its full size: Tanks&Temples 1920x1056 (1080 cropped as load/tankseval.py:36), metric-scale depth
+    range, 7 views (BASELINE.json) and 11 views (EvalTanks.nviews, config.py:119): the product against the oracle run live on
+    this host's CPU over the whole image, the metric's bar scaled to the depth range; determinism; finiteness."""
+    import time
+    w, h, rng = 1920, 1056, (0.5, 10.0)
+    imgs = synth.make_images(w, h, views, batch=1, seed=200 + views)
+    # baseline 0.03 scene units: the sweep's parallax (f*B/z = 3470*0.03/z px: 208 px at z = 0.5, 10 px at z = 10) stays inside
+    # the 1920-px frame, as for a camera orbiting a scene
+    intr, extr, dr = synth.make_cameras(w, h, views, batch=1, rot_deg=2.0, seed=300 + views, depth_range=rng, baseline=0.03)
+    with torch.no_grad():
+        out = model(imgs.to(DEV), extr.to(DEV), intr.to(DEV), dr.to(DEV))
+        out2 = model(imgs.to(DEV), extr.to(DEV), intr.to(DEV), dr.to(DEV))
+    assert torch.equal(out["depth"], out2["depth"]) and torch.equal(out["confidence"], out2["confidence"])
+    assert out["depth"].shape == (1, h, w) and bool(torch.isfinite(out["depth"]).all()) and bool(torch.isfinite(out["confidence"]).all())
+    t0 = time.time()
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    live = O.core_forward(seeded_sd, imgs, extr, intr, dr, warp=O.homo_warping_explicit)
+    err = np.abs(out["depth"].cpu().numpy() - live["depth"].numpy())
+    cerr = np.abs(out["confidence"].cpu().numpy() - live["confidence"].numpy())
+    span = rng[1] - rng[0]
+    print(f"\ncfg4 full size {w}x{h}x{views}: mean|d depth| {err.mean():.3e} (bar {1e-3 * span / 510.0:.2e}, range span {span}), max {err.max():.3e}; "
+          f"confidence mean|d| {cerr.mean():.3e}; oracle took {time.time() - t0:.1f} s")
+    assert err.mean() <= 1e-3 * span / 510.0          # BASELINE's 1e-3 mm is quoted at DTU scale (span 510 mm)
+    assert cerr.mean() <= 1e-4
