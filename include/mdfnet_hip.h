@@ -184,15 +184,20 @@ int mdf_consistency_fuse_fwd(const float* depth_ref, const float* conf, const fl
  *             running_mean/var are updated as nn.BatchNorm does (momentum, unbiased variance) and *nbt += 1
  *   apply:    z = [res +] relu(y*a + b)
  *   bwd_reduce: red[0..C) += sum dr, red[C..2C) += sum dr*xhat,  dr = dz*[y*a+b > 0], xhat = (y-mean)*invstd
- *   bwd:      dy = gamma*invstd*(dr - red0/N - xhat*red1/N);  dgamma[c] = red1, dbeta[c] = red0                      */
-int mdf_bn_stats_fwd(const float* y, long long N, int C, double* sums, void* stream);
+ *   bwd:      dy = gamma*invstd*(dr - red0/N - xhat*red1/N);  dgamma[c] = red1, dbeta[c] = red0
+ *   ngroups: the tensor is [ngroups][N][C] and every group is one call of the module with its own batch statistics
+ *   (the feature pyramid runs once per view, net/core.py:42): sums/red [ngroups][2C], aux [ngroups][4C], dgamma/dbeta
+ *   [ngroups][C]; finalize walks the groups in order for the running statistics and adds ngroups to *nbt.            */
+int mdf_bn_stats_fwd(const float* y, long long N, int C, int ngroups, double* sums, void* stream);
 int mdf_bn_finalize_fwd(const double* sums, const float* gamma, const float* beta, float eps, float momentum, long long N,
-                        int C, float* aux, float* running_mean, float* running_var, long long* num_batches_tracked,
-                        void* stream);
-int mdf_bn_relu_apply_fwd(const float* y, const float* aux, const float* res, float* z, long long N, int C, void* stream);
-int mdf_bn_relu_bwd_reduce(const float* dz, const float* y, const float* aux, long long N, int C, double* red, void* stream);
+                        int C, int ngroups, float* aux, float* running_mean, float* running_var,
+                        long long* num_batches_tracked, void* stream);
+int mdf_bn_relu_apply_fwd(const float* y, const float* aux, const float* res, float* z, long long N, int C, int ngroups,
+                          void* stream);
+int mdf_bn_relu_bwd_reduce(const float* dz, const float* y, const float* aux, long long N, int C, int ngroups, double* red,
+                           void* stream);
 int mdf_bn_relu_bwd(const float* dz, const float* y, const float* aux, const double* red, const float* gamma, long long N,
-                    int C, float* dy, float* dgamma, float* dbeta, void* stream);
+                    int C, int ngroups, float* dy, float* dgamma, float* dbeta, void* stream);
 
 /* ---- weight gradient of nn.Conv3d(k3,p1,stride s) / nn.ConvTranspose3d(k3,s2,p1,op1) (net/unit/regular.py:17-43,
  *      80-110) as ONE correlation on the fp32 matrix cores:
@@ -203,6 +208,12 @@ int mdf_bn_relu_bwd(const float* dz, const float* y, const float* aux, const dou
 int64_t mdf_conv3d_wgrad_workspace(int B, int Ds, int Hs, int Ws, int A, int Bc);
 int mdf_conv3d_wgrad(const float* small_, const float* big, float* dw, float* workspace, int B, int Ds, int Hs, int Ws,
                      int A, int Bc, int stride, int accumulate, void* stream);
+/* The same for the 2-D layers of the feature pyramid (net/unit/backbone.py:17-45; Conv2d k in {1,3,5}, pad (k-1)/2, stride s):
+ *      dw[a][b][kh][kw] (+)= sum_o small[o][a] * big[s*o + (kh,kw) - pad][b];  small = dy [B,Hs,Ws,A], big = x [B,s*Hs,s*Ws,Bc]
+ *      NHWC -> dw = torch [Cout,Cin,k,k].                                                                          */
+int64_t mdf_conv2d_wgrad_workspace(int B, int Hs, int Ws, int A, int Bc, int ksize);
+int mdf_conv2d_wgrad(const float* small_, const float* big, float* dw, float* workspace, int B, int Hs, int Ws, int A, int Bc,
+                     int ksize, int stride, int accumulate, void* stream);
 /* (input gradients of these layers are mdf_conv3d_fwd with re-packed weights: a stride-1 conv with flipped taps and
  *  swapped channels, the transposed conv for a stride-2 conv and vice versa.) */
 

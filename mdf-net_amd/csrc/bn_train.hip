@@ -7,6 +7,8 @@
 //   bn_relu_apply     z = [res +] relu(y*a + b)                                        reads y (+res), writes z
 //   bn_relu_bwd_reduce  S1 = sum dr, S2 = sum dr*xhat, dr = dz*[y*a+b > 0]             reads dz, y
 //   bn_relu_bwd       dy = gamma*invstd*(dr - S1/N - xhat*S2/N); dgamma = S2, dbeta = S1   reads dz, y, writes dy
+// Every entry takes `ngroups`: the tensor is [ngroups][N][C] and each group is normalised on its own (the feature pyramid
+// is called once per VIEW in training, net/core.py:42, so a batched pass over all views has one group per view; blockIdx.y).
 //
 // A block strides over the tensor in steps that are multiples of C floats, so a thread owns the same 4 channels for
 // the whole kernel: per-thread fp32 partial sums (a few dozen elements each), combined in fp64 through LDS and one
@@ -23,9 +25,12 @@ template <bool BWD>
 __global__ __launch_bounds__(kT) void bn_reduce_kernel(const float* __restrict__ y, const float* __restrict__ dz,
                                                        const float* __restrict__ aux, long long n4, int C,
                                                        double* __restrict__ out) {
-  // FWD: out[c] += sum y, out[C+c] += sum y^2.   BWD: out[c] += sum dr, out[C+c] += sum dr*xhat.
+  // FWD: out[c] += sum y, out[C+c] += sum y^2.   BWD: out[c] += sum dr, out[C+c] += sum dr*xhat.   blockIdx.y = group
   __shared__ double sm[128];
   const int tid = threadIdx.x;
+  y += (long long)blockIdx.y * n4 * 4;
+  if (BWD) { dz += (long long)blockIdx.y * n4 * 4; aux += (long long)blockIdx.y * 4 * C; }
+  out += (long long)blockIdx.y * 2 * C;
   if (tid < 2 * C) sm[tid] = 0.0;
   __syncthreads();
   const int c0 = (4 * tid) % C;
@@ -60,32 +65,40 @@ __global__ __launch_bounds__(kT) void bn_reduce_kernel(const float* __restrict__
 }
 
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float eps, float momentum, double n, int C, float* __restrict__ aux,
+                                   float eps, float momentum, double n, int C, int ngroups, float* __restrict__ aux,
                                    float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt) {
   const int c = threadIdx.x;
   if (c < C) {
-    const double mean = sums[c] / n;
-    double var = sums[C + c] / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float a = gamma[c] * invstd;
-    aux[c] = a;
-    aux[C + c] = beta[c] - (float)mean * a;
-    aux[2 * C + c] = (float)mean;
-    aux[3 * C + c] = invstd;
-    if (running_mean) {   // nn.BatchNorm: running = (1-m)*running + m*batch, variance unbiased
-      const double unb = (n > 1.0) ? var * n / (n - 1.0) : var;
-      running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
-      running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unb;
+    for (int g = 0; g < ngroups; ++g) {     // groups = successive calls of the module: the running statistics see them in order
+      const double* s = sums + (long long)g * 2 * C;
+      float* a4 = aux + (long long)g * 4 * C;
+      const double mean = s[c] / n;
+      double var = s[C + c] / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+      const float a = gamma[c] * invstd;
+      a4[c] = a;
+      a4[C + c] = beta[c] - (float)mean * a;
+      a4[2 * C + c] = (float)mean;
+      a4[3 * C + c] = invstd;
+      if (running_mean) {   // nn.BatchNorm: running = (1-m)*running + m*batch, variance unbiased
+        const double unb = (n > 1.0) ? var * n / (n - 1.0) : var;
+        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unb;
+      }
     }
   }
-  if (c == 0 && nbt) *nbt += 1;
+  if (c == 0 && nbt) *nbt += ngroups;
 }
 
 __global__ __launch_bounds__(kT) void bn_relu_apply_kernel(const float* __restrict__ y, const float* __restrict__ aux,
                                                            const float* __restrict__ res, float* __restrict__ z, long long n4, int C) {
   const int tid = threadIdx.x;
   const int c0 = (4 * tid) % C;
+  y += (long long)blockIdx.y * n4 * 4;
+  z += (long long)blockIdx.y * n4 * 4;
+  if (res) res += (long long)blockIdx.y * n4 * 4;
+  aux += (long long)blockIdx.y * 4 * C;
   float a[4], b[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) { a[k] = aux[c0 + k]; b[k] = aux[C + c0 + k]; }
@@ -111,6 +124,13 @@ __global__ __launch_bounds__(kT) void bn_relu_bwd_kernel(const float* __restrict
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, long long n4, int C) {
   const int tid = threadIdx.x;
   const int c0 = (4 * tid) % C;
+  dz += (long long)blockIdx.y * n4 * 4;
+  y += (long long)blockIdx.y * n4 * 4;
+  dy += (long long)blockIdx.y * n4 * 4;
+  aux += (long long)blockIdx.y * 4 * C;
+  red += (long long)blockIdx.y * 2 * C;
+  dgamma += (long long)blockIdx.y * C;
+  dbeta += (long long)blockIdx.y * C;
   float a[4], b[4], mu[4], is[4], m1[4], m2[4], gi[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -140,16 +160,18 @@ __global__ __launch_bounds__(kT) void bn_relu_bwd_kernel(const float* __restrict
 }
 
 // reductions: every block ends with 2C fp64 atomics on the same 2C addresses -- few, fat blocks
-int grid_for_reduce(long long n4) {
+int grid_for_reduce(long long n4, int ngroups) {
   long long g = (n4 + 4 * kT - 1) / (4 * kT);
-  if (g > 512) g = 512;
+  const long long cap = 512 / ngroups > 32 ? 512 / ngroups : 32;
+  if (g > cap) g = cap;
   if (g < 1) g = 1;
   return (int)g;
 }
 
-int grid_for(long long n4) {
+int grid_for(long long n4, int ngroups) {
   long long g = (n4 + kT - 1) / kT;
-  if (g > 2048) g = 2048;      // 8 blocks per CU: enough bytes in flight for an HBM stream
+  const long long cap = 2048 / ngroups > 64 ? 2048 / ngroups : 64;   // 8 blocks per CU: enough bytes in flight for an HBM stream
+  if (g > cap) g = cap;
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -163,47 +185,49 @@ int check_bn(const void* y, long long N, int C) {
 
 }  // namespace
 
-extern "C" int mdf_bn_stats_fwd(const float* y, long long N, int C, double* sums, void* stream) {
+extern "C" int mdf_bn_stats_fwd(const float* y, long long N, int C, int ngroups, double* sums, void* stream) {
   if (int rc = check_bn(y, N, C)) return rc;
-  MDF_REQUIRE(sums, "null pointer argument");
+  MDF_REQUIRE(sums && ngroups >= 1 && ngroups <= 65535, "bad argument");
   const long long n4 = N * C / 4;
-  hipLaunchKernelGGL(bn_reduce_kernel<false>, dim3(grid_for_reduce(n4)), dim3(kT), 0, (hipStream_t)stream, y, nullptr, nullptr, n4, C, sums);
+  hipLaunchKernelGGL(bn_reduce_kernel<false>, dim3(grid_for_reduce(n4, ngroups), ngroups), dim3(kT), 0, (hipStream_t)stream, y, nullptr, nullptr, n4, C, sums);
   return mdf::check_launch("bn_stats_kernel");
 }
 
 extern "C" int mdf_bn_finalize_fwd(const double* sums, const float* gamma, const float* beta, float eps, float momentum,
-                                   long long N, int C, float* aux, float* running_mean, float* running_var,
+                                   long long N, int C, int ngroups, float* aux, float* running_mean, float* running_var,
                                    long long* num_batches_tracked, void* stream) {
   MDF_REQUIRE(sums && gamma && beta && aux, "null pointer argument");
-  MDF_REQUIRE(C >= 1 && C <= 64 && N > 0, "bad shape");
+  MDF_REQUIRE(C >= 1 && C <= 64 && N > 0 && ngroups >= 1, "bad shape");
   MDF_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running_mean and running_var go together");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, gamma, beta, eps, momentum, (double)N, C, aux,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, gamma, beta, eps, momentum, (double)N, C, ngroups, aux,
                      running_mean, running_var, num_batches_tracked);
   return mdf::check_launch("bn_finalize_kernel");
 }
 
-extern "C" int mdf_bn_relu_apply_fwd(const float* y, const float* aux, const float* res, float* z, long long N, int C, void* stream) {
+extern "C" int mdf_bn_relu_apply_fwd(const float* y, const float* aux, const float* res, float* z, long long N, int C, int ngroups,
+                                     void* stream) {
   if (int rc = check_bn(y, N, C)) return rc;
-  MDF_REQUIRE(aux && z, "null pointer argument");
+  MDF_REQUIRE(aux && z && ngroups >= 1 && ngroups <= 65535, "bad argument");
   const long long n4 = N * C / 4;
-  hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(grid_for(n4)), dim3(kT), 0, (hipStream_t)stream, y, aux, res, z, n4, C);
+  hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(grid_for(n4, ngroups), ngroups), dim3(kT), 0, (hipStream_t)stream, y, aux, res, z, n4, C);
   return mdf::check_launch("bn_relu_apply_kernel");
 }
 
-extern "C" int mdf_bn_relu_bwd_reduce(const float* dz, const float* y, const float* aux, long long N, int C, double* red, void* stream) {
+extern "C" int mdf_bn_relu_bwd_reduce(const float* dz, const float* y, const float* aux, long long N, int C, int ngroups, double* red,
+                                      void* stream) {
   if (int rc = check_bn(y, N, C)) return rc;
-  MDF_REQUIRE(dz && aux && red, "null pointer argument");
+  MDF_REQUIRE(dz && aux && red && ngroups >= 1 && ngroups <= 65535, "bad argument");
   const long long n4 = N * C / 4;
-  hipLaunchKernelGGL(bn_reduce_kernel<true>, dim3(grid_for_reduce(n4)), dim3(kT), 0, (hipStream_t)stream, y, dz, aux, n4, C, red);
+  hipLaunchKernelGGL(bn_reduce_kernel<true>, dim3(grid_for_reduce(n4, ngroups), ngroups), dim3(kT), 0, (hipStream_t)stream, y, dz, aux, n4, C, red);
   return mdf::check_launch("bn_relu_bwd_reduce_kernel");
 }
 
 extern "C" int mdf_bn_relu_bwd(const float* dz, const float* y, const float* aux, const double* red, const float* gamma, long long N,
-                               int C, float* dy, float* dgamma, float* dbeta, void* stream) {
+                               int C, int ngroups, float* dy, float* dgamma, float* dbeta, void* stream) {
   if (int rc = check_bn(y, N, C)) return rc;
-  MDF_REQUIRE(dz && aux && red && gamma && dy && dgamma && dbeta, "null pointer argument");
+  MDF_REQUIRE(dz && aux && red && gamma && dy && dgamma && dbeta && ngroups >= 1 && ngroups <= 65535, "bad argument");
   const long long n4 = N * C / 4;
-  hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(grid_for(n4)), dim3(kT), 0, (hipStream_t)stream, dz, y, aux, red, gamma, 1.0 / (double)N, dy,
+  hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(grid_for(n4, ngroups), ngroups), dim3(kT), 0, (hipStream_t)stream, dz, y, aux, red, gamma, 1.0 / (double)N, dy,
                      dgamma, dbeta, n4, C);
   return mdf::check_launch("bn_relu_bwd_kernel");
 }

@@ -124,6 +124,99 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 2-D layers of the feature pyramid (net/unit/backbone.py:17-45: Conv2d k3 s1 / k5 s2, pad (k-1)/2), NHWC:
+//     dw[a][b][kh][kw] = sum over pixels o of  small[o][a] * big[s*o + (kh,kw) - pad][b]
+// Same split-K scheme; blockIdx.z = kernel row kh, a wave keeps the KS tap tiles of that row in registers.
+struct Wgrad2dParams {
+  const float* small_;   // [B,Hs,Ws,A]
+  const float* big;      // [B,Hb,Wb,Bc]
+  float* slab;           // [gridDim.x][A][Bc][KS*KS]
+  int B, Hs, Ws, Hb, Wb, A, Bc, stride;
+  int chunks_per_row;
+  long long n_items;     // B*Hs*chunks_per_row
+  int NB, split;
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void wgrad2d_kernel(const Wgrad2dParams p) {
+  constexpr int PAD = (KS - 1) / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, c16 = lane & 15;
+  const int pairs_per_block = 4 / p.split;
+  const int pair = blockIdx.y * pairs_per_block + wave / p.split;
+  const int part = wave % p.split;
+  const int na = pair / p.NB, nb = pair % p.NB;
+  const int a = na * 16 + c16, bcol = nb * 16 + c16;
+  const bool a_ok = a < p.A, b_ok = bcol < p.Bc;
+  const int kh = blockIdx.z;
+  f32x4 acc[KS];
+#pragma unroll
+  for (int t = 0; t < KS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int s = p.stride;
+  for (long long item = (long long)blockIdx.x * p.split + part; item < p.n_items; item += (long long)gridDim.x * p.split) {
+    const int ch = (int)(item % p.chunks_per_row);
+    const long long r = item / p.chunks_per_row;
+    const int oh = (int)(r % p.Hs);
+    const int n = (int)(r / p.Hs);
+    const int ih = oh * s + kh - PAD;
+    if (ih < 0 || ih >= p.Hb) continue;            // wave-uniform
+    const int ow0 = ch * 16;
+    float af[4];
+    const float* srow = p.small_ + ((long long)n * p.Hs + oh) * (long long)p.Ws * p.A;
+    const float* brow = p.big + ((long long)n * p.Hb + ih) * (long long)p.Wb * p.Bc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ow = ow0 + 4 * j + q;
+      af[j] = (a_ok && ow < p.Ws) ? srow[(long long)ow * p.A + a] : 0.0f;
+    }
+    float bf[KS][4];
+#pragma unroll
+    for (int kw = 0; kw < KS; ++kw) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int iw = (ow0 + 4 * j + q) * s + kw - PAD;
+        bf[kw][j] = (b_ok && iw >= 0 && iw < p.Wb) ? brow[(long long)iw * p.Bc + bcol] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int kw = 0; kw < KS; ++kw) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[kw][j], acc[kw], 0, 0, 0);
+    }
+  }
+  __shared__ float red[2][KS * 4 * 64];
+  float* mine = red[(wave / p.split) & 1];
+  for (int turn = 1; turn < p.split; ++turn) {
+    if (part == turn) {
+#pragma unroll
+      for (int t = 0; t < KS; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mine[(t * 4 + i) * 64 + lane] = acc[t][i];
+    }
+    __syncthreads();
+    if (part == 0) {
+#pragma unroll
+      for (int t = 0; t < KS; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] += mine[(t * 4 + i) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  if (part == 0 && b_ok) {
+    float* out = p.slab + (long long)blockIdx.x * p.A * p.Bc * (KS * KS);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = na * 16 + 4 * q + i;
+      if (row < p.A) {
+        float* o = out + ((long long)row * p.Bc + bcol) * (KS * KS) + kh * KS;
+#pragma unroll
+        for (int t = 0; t < KS; ++t) o[t] = acc[t][i];
+      }
+    }
+  }
+}
+
 // out[i] (+)= sum over slabs: blockIdx.y takes every gridDim.y-th slab, partial sums meet in `out` through fp32 atomics
 // (a few thousand per launch, spread over n addresses)
 __global__ void slab_sum_kernel(const float* __restrict__ slab, int nslab, int n, float* __restrict__ out) {
@@ -180,5 +273,53 @@ extern "C" int mdf_conv3d_wgrad(const float* small_, const float* big, float* dw
   if (gys < 1) gys = 1;
   if (gys > 32) gys = 32;
   hipLaunchKernelGGL(slab_sum_kernel, dim3((n + 255) / 256, gys), dim3(256), 0, (hipStream_t)stream, workspace, gx, n, dw);
+  return mdf::check_launch("slab_sum_kernel");
+}
+
+static long long wgrad2d_grid(int B, int Hs, int Ws, int A, int Bc, int ksize, int* split_out, int* gy_out) {
+  const long long items = (long long)B * Hs * ((Ws + 15) / 16);
+  const int pairs = ((A + 15) / 16) * ((Bc + 15) / 16);
+  const int split = pairs >= 4 ? 1 : (pairs == 2 ? 2 : 4);
+  const int gy = (pairs * split + 3) / 4;
+  long long g = 2048 / (ksize * gy);
+  if (g > items / split) g = items / split;
+  if (g < 1) g = 1;
+  if (split_out) *split_out = split;
+  if (gy_out) *gy_out = gy;
+  return g;
+}
+
+extern "C" int64_t mdf_conv2d_wgrad_workspace(int B, int Hs, int Ws, int A, int Bc, int ksize) {
+  if (B < 1 || Hs < 1 || Ws < 1 || A < 1 || Bc < 1 || ksize < 1) return 0;
+  return wgrad2d_grid(B, Hs, Ws, A, Bc, ksize, nullptr, nullptr) * A * Bc * ksize * ksize;
+}
+
+extern "C" int mdf_conv2d_wgrad(const float* small_, const float* big, float* dw, float* workspace, int B, int Hs, int Ws, int A, int Bc,
+                                int ksize, int stride, int accumulate, void* stream) {
+  MDF_REQUIRE(small_ && big && dw && workspace, "null pointer argument");
+  MDF_REQUIRE(B > 0 && Hs > 0 && Ws > 0, "bad shape");
+  MDF_REQUIRE(stride == 1 || stride == 2, "stride must be 1 or 2");
+  MDF_REQUIRE(ksize == 1 || ksize == 3 || ksize == 5, "ksize=%d not in {1,3,5}", ksize);
+  MDF_REQUIRE(A >= 1 && A <= 64 && Bc >= 1 && Bc <= 64, "channel counts out of range (A=%d, B=%d)", A, Bc);
+  Wgrad2dParams p{};
+  p.small_ = small_; p.big = big; p.slab = workspace;
+  p.B = B; p.Hs = Hs; p.Ws = Ws; p.Hb = Hs * stride; p.Wb = Ws * stride; p.A = A; p.Bc = Bc; p.stride = stride;
+  p.chunks_per_row = (Ws + 15) / 16;
+  p.n_items = (long long)B * Hs * p.chunks_per_row;
+  p.NB = (Bc + 15) / 16;
+  int gy = 1;
+  const int gx = (int)wgrad2d_grid(B, Hs, Ws, A, Bc, ksize, &p.split, &gy);
+  const dim3 grid(gx, gy, ksize);
+  hipStream_t st = (hipStream_t)stream;
+  if (ksize == 1) hipLaunchKernelGGL(wgrad2d_kernel<1>, grid, dim3(256), 0, st, p);
+  else if (ksize == 3) hipLaunchKernelGGL(wgrad2d_kernel<3>, grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(wgrad2d_kernel<5>, grid, dim3(256), 0, st, p);
+  if (int rc = mdf::check_launch("wgrad2d_kernel")) return rc;
+  const int n = A * Bc * ksize * ksize;
+  if (!accumulate) (void)hipMemsetAsync(dw, 0, (size_t)n * sizeof(float), st);
+  int gys = gx / 8;
+  if (gys < 1) gys = 1;
+  if (gys > 32) gys = 32;
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((n + 255) / 256, gys), dim3(256), 0, st, workspace, gx, n, dw);
   return mdf::check_launch("slab_sum_kernel");
 }

@@ -20,44 +20,50 @@ from .ops import _abi, _f32c, _need_gpu, _stream, _src_array, _hypos_arg
 BN_MOMENTUM = 0.1
 
 
-# --------------------------------------------------------------------------- BatchNorm3d(batch stats) + ReLU
-def bn_stats(y, n, c):
-    sums = torch.zeros(2 * c, device=y.device, dtype=torch.float64)
-    _abi("mdf_bn_stats_fwd", (y.data_ptr(), n, c, sums.data_ptr(), _stream(y)), tag=f"stats C{c} N{n}",
-         work={"bytes": 4.0 * n * c, "bound": "hbm"})
+# --------------------------------------------------------------------------- BatchNorm(batch stats) + ReLU
+# Tensors are channels-last [groups][n][c]: every group is one call of the module with its own batch statistics (the
+# regulariser layers: 1 group; the feature pyramid, called once per view: one group per view).
+def bn_stats(y, n, c, groups=1):
+    sums = torch.zeros(groups * 2 * c, device=y.device, dtype=torch.float64)
+    _abi("mdf_bn_stats_fwd", (y.data_ptr(), n, c, groups, sums.data_ptr(), _stream(y)), tag=f"stats C{c} N{n}x{groups}",
+         work={"bytes": 4.0 * n * c * groups, "bound": "hbm"})
     return sums
 
 
-def bn_finalize(sums, bn, n, c):
-    """-> aux [4C] = (a, b, mean, invstd); updates the module's running statistics like nn.BatchNorm3d.train()."""
-    aux = torch.empty(4 * c, device=sums.device, dtype=torch.float32)
+def bn_finalize(sums, bn, n, c, groups=1):
+    """-> aux [groups][4C] = (a, b, mean, invstd); updates the module's running statistics like `groups` successive calls of
+    nn.BatchNorm.train()."""
+    aux = torch.empty(groups * 4 * c, device=sums.device, dtype=torch.float32)
     track = bn.track_running_stats and bn.running_mean is not None
     mom = BN_MOMENTUM if bn.momentum is None else bn.momentum
     _abi("mdf_bn_finalize_fwd", (sums.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), ctypes.c_float(bn.eps), ctypes.c_float(mom),
-                                 n, c, aux.data_ptr(), bn.running_mean.data_ptr() if track else None,
+                                 n, c, groups, aux.data_ptr(), bn.running_mean.data_ptr() if track else None,
                                  bn.running_var.data_ptr() if track else None,
                                  bn.num_batches_tracked.data_ptr() if track else None, _stream(aux)))
     return aux
 
 
-def bn_relu_apply(y, aux, res, n, c):
+def bn_relu_apply(y, aux, res, n, c, groups=1):
     z = torch.empty_like(y)
-    _abi("mdf_bn_relu_apply_fwd", (y.data_ptr(), aux.data_ptr(), None if res is None else res.data_ptr(), z.data_ptr(), n, c, _stream(z)),
-         tag=f"apply C{c} N{n}", work={"bytes": 4.0 * n * c * (3 if res is not None else 2), "bound": "hbm"})
+    _abi("mdf_bn_relu_apply_fwd", (y.data_ptr(), aux.data_ptr(), None if res is None else res.data_ptr(), z.data_ptr(), n, c, groups,
+                                   _stream(z)),
+         tag=f"apply C{c} N{n}x{groups}", work={"bytes": 4.0 * n * c * groups * (3 if res is not None else 2), "bound": "hbm"})
     return z
 
 
-def bn_relu_backward(dz, y, aux, gamma, n, c):
-    """-> (dy, dgamma, dbeta)."""
-    red = torch.zeros(2 * c, device=y.device, dtype=torch.float64)
-    _abi("mdf_bn_relu_bwd_reduce", (dz.data_ptr(), y.data_ptr(), aux.data_ptr(), n, c, red.data_ptr(), _stream(y)),
-         tag=f"bwd-reduce C{c} N{n}", work={"bytes": 8.0 * n * c, "bound": "hbm"})
+def bn_relu_backward(dz, y, aux, gamma, n, c, groups=1):
+    """-> (dy, dgamma, dbeta)  (parameter gradients summed over the groups)."""
+    red = torch.zeros(groups * 2 * c, device=y.device, dtype=torch.float64)
+    _abi("mdf_bn_relu_bwd_reduce", (dz.data_ptr(), y.data_ptr(), aux.data_ptr(), n, c, groups, red.data_ptr(), _stream(y)),
+         tag=f"bwd-reduce C{c} N{n}x{groups}", work={"bytes": 8.0 * n * c * groups, "bound": "hbm"})
     dy = torch.empty_like(y)
-    dgamma = torch.empty(c, device=y.device, dtype=torch.float32)
-    dbeta = torch.empty(c, device=y.device, dtype=torch.float32)
-    _abi("mdf_bn_relu_bwd", (dz.data_ptr(), y.data_ptr(), aux.data_ptr(), red.data_ptr(), gamma.data_ptr(), n, c, dy.data_ptr(),
+    dgamma = torch.empty(groups * c, device=y.device, dtype=torch.float32)
+    dbeta = torch.empty(groups * c, device=y.device, dtype=torch.float32)
+    _abi("mdf_bn_relu_bwd", (dz.data_ptr(), y.data_ptr(), aux.data_ptr(), red.data_ptr(), gamma.data_ptr(), n, c, groups, dy.data_ptr(),
                              dgamma.data_ptr(), dbeta.data_ptr(), _stream(y)),
-         tag=f"bwd C{c} N{n}", work={"bytes": 12.0 * n * c, "bound": "hbm"})
+         tag=f"bwd C{c} N{n}x{groups}", work={"bytes": 12.0 * n * c * groups, "bound": "hbm"})
+    if groups > 1:
+        dgamma, dbeta = dgamma.view(groups, c).sum(0), dbeta.view(groups, c).sum(0)
     return dy, dgamma, dbeta
 
 
@@ -291,3 +297,134 @@ def aggregate_train(module, features, proj, hypos):
     head = module.depth_weight
     return AggregateTrainFn.apply(module, proj, hypos, head[0].conv.weight, head[0].bn.weight, head[0].bn.bias, head[1].weight, head[1].bias,
                                   *features)
+
+
+# --------------------------------------------------------------------------- feature-pyramid trunk (2-D) in training mode
+def conv2d_wgrad(small, big, ksize, stride, out_shape):
+    """dw[a][b][kh][kw] = sum_o small[o][a] * big[stride*o + (kh,kw) - pad][b]; small [B,Hs,Ws,A], big [B,s*Hs,s*Ws,Bc] NHWC."""
+    _need_gpu(small, big)
+    b, hs, ws, a = small.shape
+    bc = big.shape[-1]
+    assert tuple(big.shape[:3]) == (b, hs * stride, ws * stride), (small.shape, big.shape, stride)
+    assert small.is_contiguous() and big.is_contiguous()
+    n = lib().mdf_conv2d_wgrad_workspace(b, hs, ws, a, bc, ksize)
+    work = torch.empty(n, device=small.device, dtype=torch.float32)
+    dw = torch.empty((a, bc, ksize, ksize), device=small.device, dtype=torch.float32)
+    _abi("mdf_conv2d_wgrad", (small.data_ptr(), big.data_ptr(), dw.data_ptr(), work.data_ptr(), b, hs, ws, a, bc, ksize, stride, 0,
+                              _stream(dw)), tag=f"wgrad2d {a}x{bc} k{ksize}s{stride} {hs}x{ws}x{b}",
+         work={"flops": 2.0 * ksize * ksize * a * bc * b * hs * ws, "bytes": 4.0 * (small.numel() + big.numel()), "bound": "mfma"})
+    return dw if tuple(out_shape) == tuple(dw.shape) else dw[:, :out_shape[1]].contiguous()
+
+
+_K5_TAP = ((4, 2, 0), (-1, 3, 1))      # output parity p, 3x3 tap t -> 5x5 kernel index (-1: structurally zero)
+
+
+def _k5s2_dgrad_weight(w):
+    """Conv2d(k5,s2,p2) weight [Cout,Cin,5,5] -> weight [4*Cin, Cout, 3, 3] of the stride-1 3x3 conv over dy whose output
+    channel (py*2+px)*Cin + ci is dx[ci] at the pixels of parity (py,px): dx[2j+p] = sum_t dy[j+t-1] * w[k(p,t)]."""
+    cout, cin = w.shape[:2]
+    out = torch.zeros((2, 2, cin, cout, 3, 3), device=w.device, dtype=torch.float32)
+    wt = w.detach().float().permute(1, 0, 2, 3)                   # [Cin,Cout,5,5]
+    for py in range(2):
+        for px in range(2):
+            for ty in range(3):
+                for tx in range(3):
+                    ky, kx = _K5_TAP[py][ty], _K5_TAP[px][tx]
+                    if ky >= 0 and kx >= 0:
+                        out[py, px, :, :, ty, tx] = wt[:, :, ky, kx]
+    return out.reshape(4 * cin, cout, 3, 3)
+
+
+def conv2d_dgrad(conv, dy):
+    """Input gradient of a Conv2d(k3,s1,p1) or Conv2d(k5,s2,p2) layer, NHWC, on the forward conv kernels."""
+    from .layers import cache_of_key
+    k, stride, cin, cout = conv.kernel_size[0], conv.stride[0], conv.in_channels, conv.out_channels
+    w = conv.weight
+    if k == 3 and stride == 1:
+        wp = cache_of_key(conv, "dgrad").get((w,), lambda: ops.pack_conv2d_weight(w.detach().flip(2, 3).transpose(0, 1).contiguous()))
+        return ops.conv2d_nhwc(dy, wp, cout, cin, 3, 1)
+    if k == 5 and stride == 2:
+        nout = 4 * cin
+        parts = [(0, nout)] if nout <= 64 else [(0, nout // 2), (nout // 2, nout)]
+
+        def build():
+            w4 = _k5s2_dgrad_weight(w)
+            return [ops.pack_conv2d_weight(w4[a:b].contiguous()) for a, b in parts]
+        packs = cache_of_key(conv, "dgrad").get((w,), build)
+        zs = [ops.conv2d_nhwc(dy, wp, cout, b - a, 3, 1) for wp, (a, b) in zip(packs, parts)]
+        z = zs[0] if len(zs) == 1 else torch.cat(zs, dim=-1)
+        b_, ho, wo, _ = z.shape
+        return z.view(b_, ho, wo, 2, 2, cin).permute(0, 1, 3, 2, 4, 5).reshape(b_, 2 * ho, 2 * wo, cin)      # the 4 parity classes interleaved
+    raise NotImplementedError(f"conv2d input gradient for k={k} stride={stride}")
+
+
+class Tape2D:
+    """Forward record of the feature pyramid's Conv2d + BatchNorm2d(batch statistics) + ReLU chain (backbone.py:17-45),
+    `groups` independent module calls batched along the image axis (one group per view)."""
+
+    def __init__(self, groups):
+        self.groups, self.layers = groups, []
+
+    def layer(self, conv, bn, x, planar_in=False, x_for_wgrad=None):
+        k, stride = conv.kernel_size[0], conv.stride[0]
+        from .layers import cache_of_key
+        wp = cache_of_key(conv, "fwd").get((conv.weight,), lambda: ops.pack_conv2d_weight(conv.weight))
+        y = ops.conv2d_nhwc(x, wp, conv.in_channels, conv.out_channels, k, stride, planar_in=planar_in)        # raw conv
+        c = conv.out_channels
+        n = y.numel() // c // self.groups
+        aux = bn_finalize(bn_stats(y, n, c, self.groups), bn, n, c, self.groups)
+        z = bn_relu_apply(y, aux, None, n, c, self.groups)
+        self.layers.append((conv, bn, x if x_for_wgrad is None else x_for_wgrad, y, aux, z, x_for_wgrad is not None))
+        return z
+
+    def backward(self, grads):
+        pg = {}
+        for conv, bn, x, y, aux, z, is_input in reversed(self.layers):
+            dz = grads.pop(id(z))
+            c = conv.out_channels
+            n = y.numel() // c // self.groups
+            dy, pg[bn.weight], pg[bn.bias] = bn_relu_backward(dz.contiguous(), y, aux, bn.weight, n, c, self.groups)
+            pg[conv.weight] = conv2d_wgrad(dy, x, conv.kernel_size[0], conv.stride[0], tuple(conv.weight.shape))
+            if not is_input:
+                dx = conv2d_dgrad(conv, dy)
+                grads[id(x)] = dx if id(x) not in grads else grads[id(x)] + dx
+        return pg
+
+
+class TrunkTrainFn(torch.autograd.Function):
+    """(images [G*B,3,H,W], G groups) -> (t2 [.,16,H/2,W/2], t3 [.,32,H/4,W/4], t4 [.,64,H/8,W/8]) of FPN_4Scales in training mode."""
+
+    @staticmethod
+    def forward(ctx, module, groups, imgs, *params):
+        tape = Tape2D(groups)
+        x = imgs.detach().float().contiguous()                              # planar, as the loader hands it over
+        x4 = torch.zeros((x.shape[0], x.shape[2], x.shape[3], 4), device=x.device, dtype=torch.float32)
+        x4[..., :3] = x.permute(0, 2, 3, 1)                                 # NHWC (padded to 4) for the first layer's weight gradient
+        first = module.conv01[0]
+        t = tape.layer(first.conv, first.bn, x, planar_in=True, x_for_wgrad=x4)
+        outs = []
+        for seq in (module.conv01[1:], module.conv12, module.conv23, module.conv34):
+            for blk in seq:
+                t = tape.layer(blk.conv, blk.bn, t)
+            outs.append(t)
+        ctx.tape, ctx.params, ctx.outs = tape, params, outs[1:]
+        ctx.set_materialize_grads(False)
+        return tuple(o.permute(0, 3, 1, 2) for o in outs[1:])
+
+    @staticmethod
+    def backward(ctx, *douts):
+        grads = {}
+        for o, g in zip(ctx.outs, douts):
+            if g is not None:
+                grads[id(o)] = g.permute(0, 2, 3, 1).contiguous()
+        for o in ctx.outs:
+            if id(o) not in grads:
+                grads[id(o)] = torch.zeros_like(o)
+        pg = ctx.tape.backward(grads)
+        ctx.tape = None
+        return (None, None, None) + tuple(pg.get(p) for p in ctx.params)
+
+
+def trunk_train(module, imgs, groups):
+    params = tuple(p for seq in (module.conv01, module.conv12, module.conv23, module.conv34) for p in seq.parameters())
+    return TrunkTrainFn.apply(module, groups, imgs, *params)

@@ -43,6 +43,8 @@ class CoreNet(torch.nn.Module):
                     t.record_stream(cur)
                 out.append(pyr)
             return out
+        if self.training and imgs.is_cuda and hasattr(self.Backbone, "forward_views") and layers.hip_train(self.Backbone, imgs):
+            return self.Backbone.forward_views(imgs)          # all views in one pass, BatchNorm statistics per view
         if getattr(self.Backbone, "batch_views", False) and not self.training:
             # eval BatchNorm is per-sample: one batched pass over the B*V images == V separate calls (core.py:42)
             f = self.Backbone(imgs.reshape(nb * nv, *imgs.shape[2:]))

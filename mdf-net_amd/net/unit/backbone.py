@@ -76,10 +76,29 @@ class FPN_4Scales(nn.Module):
             y2 = head(hd["y2"], t2, res_up=c3)                            # out2(up(up3) + lat2(t2))        @1/2
         return ops.from_nhwc(y4), ops.from_nhwc(y3), ops.from_nhwc(y2)
 
+    def _heads(self, t2, t3, t4):
+        up3 = F.interpolate(t4, scale_factor=2.0, mode="bilinear", align_corners=False) + self.lat3(t3)
+        up2 = F.interpolate(up3, scale_factor=2.0, mode="bilinear", align_corners=False) + self.lat2(t2)
+        return self.out4(t4), self.out3(up3), self.out2(up2)
+
+    def forward_views(self, imgs):
+        """Training on the GPU, all views at once: imgs [B,V,3,H,W] -> list over views of (f8, f4, f2).  The conv trunk
+        (11 Conv2d + BatchNorm2d + ReLU layers, forward and backward) runs on the hand-written training kernels with one
+        BatchNorm group per view -- the statistics of V separate calls, net/core.py:42 -- and the bias-only 1x1 heads, which
+        have no batch statistics, run batched through their stock modules."""
+        from mdfnet_hip import train_ops
+        b, v = imgs.shape[:2]
+        x = imgs.transpose(0, 1).reshape(v * b, *imgs.shape[2:])           # view-major: group g = view g
+        y4, y3, y2 = self._heads(*train_ops.trunk_train(self, x, groups=v))
+        return [(y4[g * b:(g + 1) * b], y3[g * b:(g + 1) * b], y2[g * b:(g + 1) * b]) for g in range(v)]
+
     def forward(self, x: torch.Tensor):
         """[B,3,H,W] -> (1/8: 64ch, 1/4: 32ch, 1/2: 16ch)   (backbone.py:50-66)."""
         if layers.hip_eval(self, x):
             return self._hip_forward(x)
+        if layers.hip_train(self, x):
+            from mdfnet_hip import train_ops
+            return self._heads(*train_ops.trunk_train(self, x, groups=1))
         t2 = self.conv12(self.conv01(x))
         t3 = self.conv23(t2)
         t4 = self.conv34(t3)

@@ -321,3 +321,60 @@ def test_full_size_cfg3_training_step():
     assert out["depth"][3].shape == (1, 576, 768) and all(np.isfinite(losses))
     assert torch.isfinite(bucket.flat).all() and float(bucket.flat.abs().max()) > 0
     print("\ncfg3 full-size losses:", losses, "peak memory GiB:", torch.cuda.max_memory_allocated() / 2 ** 30)
+
+
+# ----------------------------------------------------------------------------------------------- feature pyramid (2-D)
+@pytest.mark.parametrize("cin,cout,k,stride", [(8, 8, 3, 1), (16, 16, 3, 1), (32, 32, 3, 1), (64, 64, 3, 1), (8, 16, 5, 2), (16, 32, 5, 2),
+                                                (32, 64, 5, 2), (3, 8, 3, 1)])
+def test_conv2d_input_and_weight_gradients(cin, cout, k, stride):
+    torch.manual_seed(cin + cout + k)
+    h, w = (12, 36) if stride == 1 else (16, 40)
+    conv = nn.Conv2d(cin, cout, k, stride=stride, padding=(k - 1) // 2, bias=False)
+    x = torch.randn(3, cin, h, w, requires_grad=True)
+    y = conv(x)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    convd = conv.to(DEV)
+    dyd = ops.to_nhwc(dy.to(DEV))
+    if cin == 3:
+        x4 = torch.zeros(3, h, w, 4, device=DEV)
+        x4[..., :3] = x.detach().to(DEV).permute(0, 2, 3, 1)
+        dw = train_ops.conv2d_wgrad(dyd, x4, k, stride, tuple(conv.weight.shape))
+    else:
+        xd = ops.to_nhwc(x.detach().to(DEV))
+        dw = train_ops.conv2d_wgrad(dyd, xd, k, stride, tuple(conv.weight.shape))
+        dx = train_ops.conv2d_dgrad(convd, dyd)
+        assert _rel(ops.from_nhwc(dx), x.grad) < 2e-5
+    assert _rel(dw, conv.weight.grad.cpu()) < 3e-5
+
+
+def test_feature_pyramid_training_forward_backward():
+    """FPN_4Scales in training mode, 3 views x batch 2 in one pass with per-view BatchNorm statistics: outputs, every
+    parameter gradient and the running statistics vs V separate calls of the stock modules on the CPU (fp32) and in float64."""
+    import copy
+    from net.unit.backbone import FPN_4Scales
+    torch.manual_seed(5)
+    ref = FPN_4Scales().train()
+    ref64 = copy.deepcopy(ref).double()
+    mod = copy.deepcopy(ref).to(DEV)
+    b, v, h, w = 2, 3, 64, 96
+    imgs = torch.rand(b, v, 3, h, w)
+    outs_ref = [ref(imgs[:, i]) for i in range(v)]
+    gouts = [[torch.randn_like(t) for t in o] for o in outs_ref]
+    sum((t * g).sum() for o, go in zip(outs_ref, gouts) for t, g in zip(o, go)).backward()
+    outs64 = [ref64(imgs[:, i].double()) for i in range(v)]
+    sum((t * g.double()).sum() for o, go in zip(outs64, gouts) for t, g in zip(o, go)).backward()
+    outs = mod.forward_views(imgs.to(DEV))
+    sum((t * g.to(DEV)).sum() for o, go in zip(outs, gouts) for t, g in zip(o, go)).backward()
+    for i in range(v):
+        for a, r_, r64 in zip(outs[i], outs_ref[i], outs64[i]):
+            assert a.shape == r_.shape and _l2(a, r64) <= max(3 * _l2(r_, r64), 2e-6)
+    worst = 0.0
+    for (k, pa), (_, pr), (_, p64) in zip(mod.named_parameters(), ref.named_parameters(), ref64.named_parameters()):
+        assert pa.grad is not None, k
+        e_hip, e_cpu = _l2(pa.grad, p64.grad), _l2(pr.grad, p64.grad)
+        worst = max(worst, e_hip)
+        assert e_hip <= max(3 * e_cpu, 2e-5), (k, e_hip, e_cpu)
+    for (k, ba), (_, br) in zip(mod.named_buffers(), ref.named_buffers()):
+        assert _rel(ba.float(), br.float()) < 1e-4, k
+    print(f"\nfeature pyramid: worst parameter-gradient L2 error vs float64 {worst:.2e}")
