@@ -79,10 +79,13 @@ def launch_ranks(n, argv, port=None, timeout=None):
     never execs -- the children are ordinary subprocesses (a process that has initialised the GPU must not be replaced)."""
     procs = []
     for r, env in enumerate(rank_environments(n, port)):
-        procs.append(subprocess.Popen([sys.executable] + list(argv), env=env,
-                                      stdout=(None if r == 0 else subprocess.DEVNULL)))
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=env, text=True,
+                                      stdout=(subprocess.PIPE if r == 0 else subprocess.DEVNULL)))
     status = 0
     try:
+        for line in procs[0].stdout:          # rank 0's record goes to our stdout; library chatter (e.g. gloo's) to stderr
+            (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+            sys.stdout.flush()
         for p in procs:
             rc = p.wait(timeout=timeout)
             status = status or rc

@@ -9,15 +9,17 @@ rows = list(csv.DictReader(open(stats)))
 os.makedirs(os.path.dirname(dst), exist_ok=True)
 shutil.copy(stats, dst + "_kernel_stats.csv")
 ours = ("conv_lds_kernel", "prob_head_tiled", "conv3d_kernel", "warp_kernel", "prob_head_kernel", "prob_from_partials", "regress_kernel", "confidence_kernel", "hypos_", "pack_weights",
-        "corner_index", "conv2d_kernel", "refine_")
+        "corner_index", "conv2d_kernel", "refine_", "wgrad", "warp_train_kernel", "warp_bwd_kernel", "warp_vec_win", "bn_reduce", "bn_finalize", "bn_relu",
+        "slab_sum", "softmax_regress_bwd", "prob_conv_dgrad", "consistency_")
+unit = sys.argv[5] if len(sys.argv) > 5 else "forward"
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 tune = sum(float(r["TotalDurationNs"]) for r in rows if r["Name"].startswith("naive_conv"))
 mine = sum(float(r["TotalDurationNs"]) for r in rows if any(k in r["Name"] for k in ours))
 with open(dst + ".md", "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats summary\n\ncommand: `{cmd}`\n\n")
-    f.write(f"forward passes in the run (warm-up + timed): {steps}\n\n")
+    f.write(f"{unit} passes in the run (warm-up + timed): {steps}\n\n")
     f.write(f"* all kernels: {tot/1e6:.2f} ms; MIOpen find-mode `naive_conv*` (first call only): {tune/1e6:.2f} ms\n")
-    f.write(f"* steady state per forward: {(tot-tune)/steps/1e6:.3f} ms GPU-busy, of which hand-written HIP kernels "
+    f.write(f"* steady state per {unit}: {(tot-tune)/steps/1e6:.3f} ms GPU-busy, of which hand-written HIP kernels "
             f"{mine/steps/1e6:.3f} ms\n\n| kernel | calls | calls/fwd | total ms | avg us | min us | max us |\n|---|---|---|---|---|---|---|\n")
     for r in rows[:45]:
         name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:110]
