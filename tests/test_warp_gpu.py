@@ -131,3 +131,28 @@ def test_full_size_stage2_against_oracle_and_plane_independence(seeded_sd):
     aten = O.homo_warping(feas[1], sps[0], rp, hyp[:, 2:3].contiguous())
     expl = O.homo_warping_explicit(feas[1], sps[0], rp, hyp[:, 2:3].contiguous())
     print("host ATen-vs-explicit warp mismatches on this CPU:", int((aten != expl).sum()), "of", aten.numel())
+
+
+@pytest.mark.parametrize("stage,rot,nv", [(0, 3.0, 5), (1, 3.0, 5), (2, 3.0, 5), (2, 25.0, 3), (0, 0.0, 11)])
+def test_lds_window_variant_is_bit_identical(seeded_sd, stage, rot, nv, monkeypatch):
+    """The LDS-staged-window form of the eval aggregation (warp_vec_win_kernel, opt-in with MDF_WARP_WINDOW=1: measured
+    slower than the L1 gather) returns the plain kernel's cost volume bit for bit -- including a strongly rotated
+    view whose footprint does not fit the window pool (per-view fallback to the memory gather) and 10 source views."""
+    from net.unit.scale import scale_cam
+    c, g, d = ((64, 32, 48), (32, 16, 24), (16, 8, 8))[stage]
+    h, w = (37, 50) if stage == 0 else ((74, 100) if stage == 1 else (148, 200))
+    torch.manual_seed(stage * 7 + nv)
+    intr, extr, dr = synth.make_cameras(w * 2 ** (3 - stage), h * 2 ** (3 - stage), nv, batch=2, rot_deg=rot, seed=3)
+    rp, sps = scale_cam(intr, extr, stage)
+    proj = ops.relative_projections(rp, list(sps)).to(DEV)
+    feats = [torch.randn(2, c, h, w, device=DEV) for _ in range(nv)]
+    if stage == 0:
+        hyp = torch.linspace(425, 935, d, device=DEV).reshape(1, d, 1, 1).repeat(2, 1, 1, 1)
+    else:
+        hyp = (425 + 510 * torch.rand(2, 1, h, w, device=DEV)) + torch.linspace(-20, 20, d, device=DEV).reshape(1, d, 1, 1)
+    wpar = torch.randn(g + 4, device=DEV)
+    monkeypatch.delenv("MDF_WARP_WINDOW", raising=False)
+    plain = ops.warp_aggregate_vec(feats, proj, hyp, wpar, g).clone()
+    monkeypatch.setenv("MDF_WARP_WINDOW", "1")
+    win = ops.warp_aggregate_vec(feats, proj, hyp, wpar, g)
+    assert torch.equal(plain, win)
