@@ -16,7 +16,7 @@ ARCH = "gfx950"
 # -ffp-contract=off: every fma in the kernels is explicit (bit-exact warp arithmetic)
 # -munsafe-fp-atomics: fp32/fp64 atomic adds of the training kernels compile to hardware atomics, not CAS loops
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics", f"--offload-arch={ARCH}", "-I", INCLUDE, "-I", CSRC,
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function"] + os.environ.get("MDF_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def sources():
