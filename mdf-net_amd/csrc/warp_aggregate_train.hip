@@ -283,6 +283,27 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
       float* gp = p.dsrc[v] + (size_t)b * gmap_stride + 2 * sub;
       const float s1 = (float)p.red_in[2 * v], s2 = (float)p.red_in[2 * v + 1];
       const float al = vpar[4 * v], be = vpar[4 * v + 1], mu = vpar[4 * v + 2], is = vpar[4 * v + 3];
+      float pend0[4] = {0.f, 0.f, 0.f, 0.f}, pend1[4] = {0.f, 0.f, 0.f, 0.f};   // pending tap sums of the current corner set
+      int cxa = -1, cxb = -1, cya = -1, cyb = -1;
+      auto flush_taps = [&](int xa, int xb, int ya, int yb) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float a0 = pend0[k], a1 = pend1[k];
+          pend0[k] = 0.f; pend1[k] = 0.f;
+          if (a0 != 0.0f || a1 != 0.0f) {      // zero-weight (out-of-bounds) taps never leave the registers
+            const int tx = (k & 1) ? xb : xa, ty = (k & 2) ? yb : ya;
+            if (use_win) {
+              float* o = win + ((ty - ymin) * ww + (tx - xmin)) * G + 2 * sub;
+              atomicAdd(o, a0);
+              atomicAdd(o + 1, a1);
+            } else {
+              float* o = gp + (size_t)(ty * W + tx) * G;
+              unsafeAtomicAdd(o, a0);
+              unsafeAtomicAdd(o + 1, a1);
+            }
+          }
+        }
+      };
       for (int dd = 0; dd < nd; ++dd) {
         const TapXY t = tab[(dd * p.n_src + v) * PPB + pl];
         const int o0 = (t.ya * W + t.xa), o1 = (t.ya * W + t.xb), o2 = (t.yb * W + t.xa), o3 = (t.yb * W + t.xb);
@@ -322,25 +343,20 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
           gref1 = fmaf(ds1, 2.0f * q1 - 1.0f, gref1);
           const float g0 = ds0 * r[0] * q0 * (1.0f - q0);   // d sim / d q0 = p0 - p1; softmax pair: d v1 = -d v0
           const float g1 = ds1 * r[2] * q1 * (1.0f - q1);
-          const int oo[4] = {o0, o1, o2, o3};
+          // neighbouring planes of a pixel mostly hit the SAME four texels (per-pixel hypotheses span a fraction of a
+          // source pixel per plane): keep the tap sums in registers while the corners do not move, send them on when they do
+          if (t.xa != cxa || t.ya != cya || t.xb != cxb || t.yb != cyb) {
+            flush_taps(cxa, cxb, cya, cyb);
+            cxa = t.xa; cxb = t.xb; cya = t.ya; cyb = t.yb;
+          }
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const float wk = t.wt[k];
-            if (wk != 0.0f) {
-              if (use_win) {
-                const int tx = ((k & 1) ? t.xb : t.xa) - xmin, ty = ((k & 2) ? t.yb : t.ya) - ymin;
-                float* o = win + (ty * ww + tx) * G + 2 * sub;
-                atomicAdd(o, wk * g0);
-                atomicAdd(o + 1, wk * g1);
-              } else {
-                float* o = gp + (size_t)oo[k] * G;
-                unsafeAtomicAdd(o, wk * g0);
-                unsafeAtomicAdd(o + 1, wk * g1);
-              }
-            }
+            pend0[k] = fmaf(t.wt[k], g0, pend0[k]);
+            pend1[k] = fmaf(t.wt[k], g1, pend1[k]);
           }
         }
       }
+      flush_taps(cxa, cxb, cya, cyb);
       if (use_win) {
         __syncthreads();
         float* gv = p.dsrc[v] + (size_t)b * gmap_stride;

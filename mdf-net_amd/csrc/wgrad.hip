@@ -125,6 +125,53 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// A = 1 (the `prob` conv, regular.py:43/110): a 1-row `small` would use 1/16 of every MFMA tile.  Re-index the sum by the
+// voxel of `big` instead:  dw[0][b][kd][kh][kw] = sum_o' small[o' - (0,kh-1,kw-1)] * big[o' + (kd-1,0,0)][b], and put the
+// nine (kh,kw) shifts of `small` in the ROWS of the tile: one MFMA step yields all nine taps of a depth tap (27 -> 3 MFMA
+// steps per chunk, `big` read once per kd instead of nine times).  blockIdx.z = kd; the 4 waves of a block split the chunks.
+__global__ __launch_bounds__(256) void wgrad_a1_kernel(const WgradParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, c16 = lane & 15;
+  const int kd = blockIdx.z;
+  const int kh = c16 / 3, kw = c16 % 3;            // row r = c16 < 9
+  const bool r_ok = c16 < 9, b_ok = c16 < p.Bc;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (long long item = (long long)blockIdx.x * 4 + wave; item < p.n_items; item += (long long)gridDim.x * 4) {
+    const int ch = (int)(item % p.chunks_per_row);
+    long long r = item / p.chunks_per_row;
+    const int h = (int)(r % p.Hs); r /= p.Hs;
+    const int d = (int)(r % p.Ds);
+    const int n = (int)(r / p.Ds);
+    const int id = d + kd - 1;
+    if (id < 0 || id >= p.Ds) continue;            // wave-uniform
+    const int hs = h - (kh - 1);                   // row of `small` this lane's tile row reads
+    const bool hs_ok = r_ok && hs >= 0 && hs < p.Hs;
+    const float* srow = p.small_ + (((long long)n * p.Ds + d) * p.Hs + (hs_ok ? hs : 0)) * (long long)p.Ws;
+    const float* brow = p.big + (((long long)n * p.Ds + id) * p.Hs + h) * (long long)p.Ws * p.Bc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int w = ch * 16 + 4 * j + q;
+      const int wsm = w - (kw - 1);
+      const float a = (hs_ok && w < p.Ws && wsm >= 0 && wsm < p.Ws) ? srow[wsm] : 0.0f;
+      const float bv = (b_ok && w < p.Ws) ? brow[(long long)w * p.Bc + c16] : 0.0f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc, 0, 0, 0);
+    }
+  }
+  __shared__ float red[4][4 * 64];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) red[wave][i * 64 + lane] = acc[i];
+  __syncthreads();
+  if (wave == 0 && b_ok) {
+    float* out = p.slab + (long long)blockIdx.x * p.Bc * 27;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 4 * q + i;
+      if (row < 9) out[(long long)c16 * 27 + kd * 9 + row] = red[0][i * 64 + lane] + red[1][i * 64 + lane] + red[2][i * 64 + lane] + red[3][i * 64 + lane];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // 2-D layers of the feature pyramid (net/unit/backbone.py:17-45: Conv2d k3 s1 / k5 s2, pad (k-1)/2), NHWC:
 //     dw[a][b][kh][kw] = sum over pixels o of  small[o][a] * big[s*o + (kh,kw) - pad][b]
 // Same split-K scheme; blockIdx.z = kernel row kh, a wave keeps the KS tap tiles of that row in registers.
@@ -265,7 +312,10 @@ extern "C" int mdf_conv3d_wgrad(const float* small_, const float* big, float* dw
   p.split = pairs >= 4 ? 1 : (pairs == 2 ? 2 : 4);
   const int gy = (pairs * p.split + 3) / 4;
   const int gx = (int)(mdf_conv3d_wgrad_workspace(B, Ds, Hs, Ws, A, Bc) / ((long long)A * Bc * 27));
-  hipLaunchKernelGGL(wgrad_kernel, dim3(gx, gy, 3), dim3(256), 0, (hipStream_t)stream, p);
+  if (A == 1 && Bc <= 16 && stride == 1)
+    hipLaunchKernelGGL(wgrad_a1_kernel, dim3(gx, 1, 3), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(wgrad_kernel, dim3(gx, gy, 3), dim3(256), 0, (hipStream_t)stream, p);
   if (int rc = mdf::check_launch("wgrad_kernel")) return rc;
   const int n = A * Bc * 27;
   if (!accumulate) (void)hipMemsetAsync(dw, 0, (size_t)n * sizeof(float), (hipStream_t)stream);

@@ -15,7 +15,7 @@ class _Folded:
         self.key, self.val, self.ev, self.seen = None, None, None, ()
 
     def get(self, tensors, build):
-        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors if t is not None)
+        key = tuple((t.data_ptr(), t._version, t.device.index) for t in tensors if t is not None)
         dev = next((t.device for t in tensors if t is not None and t.is_cuda), None)
         if key != self.key:
             with torch.no_grad():

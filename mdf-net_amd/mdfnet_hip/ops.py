@@ -57,7 +57,14 @@ class _single_thread:
             torch.set_num_threads(self.n)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(t):
+    """The current HIP stream of t's device as a raw handle (the private fast getter when this torch has it: ~10x cheaper than
+    building a torch.cuda.Stream object per launch, which matters at ~450 launches per training step)."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(t.device.index if t.device.index is not None else torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 

@@ -23,8 +23,24 @@ BN_MOMENTUM = 0.1
 # --------------------------------------------------------------------------- BatchNorm(batch stats) + ReLU
 # Tensors are channels-last [groups][n][c]: every group is one call of the module with its own batch statistics (the
 # regulariser layers: 1 group; the feature pyramid, called once per view: one group per view).
-def bn_stats(y, n, c, groups=1):
-    sums = torch.zeros(groups * 2 * c, device=y.device, dtype=torch.float64)
+class ZeroPool:
+    """Zeroed fp64 scratch for the reduction kernels of one forward or backward sweep: one fill per sweep instead of one
+    allocation + fill launch per layer (the step is host-bound at ~900 launches, every launch saved is ~10 us)."""
+
+    def __init__(self, device, n=16384):
+        self.device, self.n = device, n
+        self.buf, self.off = torch.zeros(n, device=device, dtype=torch.float64), 0
+
+    def take(self, k):
+        if self.off + k > self.n:
+            self.buf, self.off = torch.zeros(max(self.n, k), device=self.device, dtype=torch.float64), 0
+        v = self.buf[self.off:self.off + k]
+        self.off += k
+        return v
+
+
+def bn_stats(y, n, c, groups=1, pool=None):
+    sums = torch.zeros(groups * 2 * c, device=y.device, dtype=torch.float64) if pool is None else pool.take(groups * 2 * c)
     _abi("mdf_bn_stats_fwd", (y.data_ptr(), n, c, groups, sums.data_ptr(), _stream(y)), tag=f"stats C{c} N{n}x{groups}",
          work={"bytes": 4.0 * n * c * groups, "bound": "hbm"})
     return sums
@@ -51,9 +67,9 @@ def bn_relu_apply(y, aux, res, n, c, groups=1):
     return z
 
 
-def bn_relu_backward(dz, y, aux, gamma, n, c, groups=1):
+def bn_relu_backward(dz, y, aux, gamma, n, c, groups=1, pool=None):
     """-> (dy, dgamma, dbeta)  (parameter gradients summed over the groups)."""
-    red = torch.zeros(groups * 2 * c, device=y.device, dtype=torch.float64)
+    red = torch.zeros(groups * 2 * c, device=y.device, dtype=torch.float64) if pool is None else pool.take(groups * 2 * c)
     _abi("mdf_bn_relu_bwd_reduce", (dz.data_ptr(), y.data_ptr(), aux.data_ptr(), n, c, groups, red.data_ptr(), _stream(y)),
          tag=f"bwd-reduce C{c} N{n}x{groups}", work={"bytes": 8.0 * n * c * groups, "bound": "hbm"})
     dy = torch.empty_like(y)
@@ -136,16 +152,18 @@ class Tape:
     """Forward record of the regulariser's layer program (net/unit/regular.py: `features`), replayed backwards."""
 
     def __init__(self):
-        self.layers = []
+        self.layers, self.pool = [], None
 
     def layer(self, conv, bn, x, res):
+        if self.pool is None:
+            self.pool = ZeroPool(x.device)
         tr = isinstance(conv, torch.nn.ConvTranspose3d)
         stride = conv.stride[0]
         wp = ops_pack_fwd(conv, tr)
         y = ops.conv3d_ndhwc(x, wp, conv.in_channels, conv.out_channels, stride, tr, None, None, False, None)   # raw conv
         c = conv.out_channels
         n = y.numel() // c
-        aux = bn_finalize(bn_stats(y, n, c), bn, n, c)
+        aux = bn_finalize(bn_stats(y, n, c, pool=self.pool), bn, n, c)
         z = bn_relu_apply(y, aux, res, n, c)
         self.layers.append((conv, bn, tr, stride, x, y, aux, res, z))
         return z
@@ -154,13 +172,14 @@ class Tape:
         """grads: {id(tensor): gradient} holding the gradient of the last layer's output; returns parameter grads
         {param: grad} and leaves the input gradients in `grads`."""
         pg = {}
+        pool = ZeroPool(self.layers[0][4].device)
         for conv, bn, tr, stride, x, y, aux, res, z in reversed(self.layers):
             dz = grads.pop(id(z))
             if res is not None:
                 grads[id(res)] = dz if id(res) not in grads else grads[id(res)] + dz
             c = conv.out_channels
             n = y.numel() // c
-            dy, pg[bn.weight], pg[bn.bias] = bn_relu_backward(dz, y, aux, bn.weight, n, c)
+            dy, pg[bn.weight], pg[bn.bias] = bn_relu_backward(dz, y, aux, bn.weight, n, c, pool=pool)
             if tr:      # ConvTranspose3d: small = x (input), big = dy (twice the size)
                 pg[conv.weight] = conv3d_wgrad(x, dy, 2, tuple(conv.weight.shape))
             else:
@@ -215,6 +234,7 @@ def regulariser_train(module, cost, hypos):
 
 # --------------------------------------------------------------------------- VectorAggregate in training mode
 _PASS_STATS, _PASS_FWD, _PASS_BWD_REDUCE, _PASS_BWD = 0, 1, 2, 3
+_COEF = {}
 
 
 def _agg_call(pass_, ref, srcs, proj, hyp, pp, par, red_in, dcost, cost, wsum, red_out, dref, dsrcs, dcw, b, c, g, d, h, w):
@@ -254,7 +274,10 @@ class AggregateTrainFn(torch.autograd.Function):
         if bn.track_running_stats and bn.running_mean is not None:
             # the module is called once per source view (homoaggregate.py:35-40): n_src sequential momentum updates
             mom = BN_MOMENTUM if bn.momentum is None else bn.momentum
-            coef = torch.tensor([mom * (1.0 - mom) ** (nsrc - 1 - v) for v in range(nsrc)], dtype=torch.float64).to(dev, non_blocking=True)
+            ck = (dev, nsrc, mom)
+            coef = _COEF.get(ck)
+            if coef is None:
+                coef = _COEF[ck] = torch.tensor([mom * (1.0 - mom) ** (nsrc - 1 - v) for v in range(nsrc)], dtype=torch.float64).to(dev)
             keep = (1.0 - mom) ** nsrc
             unb = var * (n / max(n - 1, 1))
             bn.running_mean.mul_(keep).add_((coef * mean).sum().float())
@@ -317,45 +340,48 @@ def conv2d_wgrad(small, big, ksize, stride, out_shape):
 
 
 _K5_TAP = ((4, 2, 0), (-1, 3, 1))      # output parity p, 3x3 tap t -> 5x5 kernel index (-1: structurally zero)
+_K5_IDX = {}
 
 
 def _k5s2_dgrad_weight(w):
     """Conv2d(k5,s2,p2) weight [Cout,Cin,5,5] -> weight [4*Cin, Cout, 3, 3] of the stride-1 3x3 conv over dy whose output
     channel (py*2+px)*Cin + ci is dx[ci] at the pixels of parity (py,px): dx[2j+p] = sum_t dy[j+t-1] * w[k(p,t)]."""
     cout, cin = w.shape[:2]
-    out = torch.zeros((2, 2, cin, cout, 3, 3), device=w.device, dtype=torch.float32)
-    wt = w.detach().float().permute(1, 0, 2, 3)                   # [Cin,Cout,5,5]
-    for py in range(2):
-        for px in range(2):
-            for ty in range(3):
-                for tx in range(3):
-                    ky, kx = _K5_TAP[py][ty], _K5_TAP[px][tx]
-                    if ky >= 0 and kx >= 0:
-                        out[py, px, :, :, ty, tx] = wt[:, :, ky, kx]
-    return out.reshape(4 * cin, cout, 3, 3)
+    wt = torch.nn.functional.pad(w.detach().float().permute(1, 0, 2, 3), (0, 1, 0, 1))          # [Cin,Cout,6,6], index 5 = zero
+    idx = _K5_IDX.get(w.device)                                                                  # (p,t) -> kernel index
+    if idx is None:     # built once per device: torch.tensor(list, device=...) is a blocking copy (0.9 ms behind a busy GPU)
+        idx = _K5_IDX[w.device] = torch.tensor([k if k >= 0 else 5 for p_ in _K5_TAP for k in p_], device=w.device)
+    g = wt.index_select(2, idx).index_select(3, idx).reshape(cin, cout, 2, 3, 2, 3)              # [ci,co,py,ty,px,tx]
+    return g.permute(2, 4, 0, 1, 3, 5).reshape(4 * cin, cout, 3, 3).contiguous()
 
 
-def conv2d_dgrad(conv, dy):
-    """Input gradient of a Conv2d(k3,s1,p1) or Conv2d(k5,s2,p2) layer, NHWC, on the forward conv kernels."""
+def _dgrad2d_pack(conv):
     from .layers import cache_of_key
-    k, stride, cin, cout = conv.kernel_size[0], conv.stride[0], conv.in_channels, conv.out_channels
+    k, stride, cin = conv.kernel_size[0], conv.stride[0], conv.in_channels
     w = conv.weight
     if k == 3 and stride == 1:
-        wp = cache_of_key(conv, "dgrad").get((w,), lambda: ops.pack_conv2d_weight(w.detach().flip(2, 3).transpose(0, 1).contiguous()))
-        return ops.conv2d_nhwc(dy, wp, cout, cin, 3, 1)
+        return cache_of_key(conv, "dgrad").get((w,), lambda: ops.pack_conv2d_weight(w.detach().flip(2, 3).transpose(0, 1).contiguous()))
     if k == 5 and stride == 2:
         nout = 4 * cin
         parts = [(0, nout)] if nout <= 64 else [(0, nout // 2), (nout // 2, nout)]
 
         def build():
             w4 = _k5s2_dgrad_weight(w)
-            return [ops.pack_conv2d_weight(w4[a:b].contiguous()) for a, b in parts]
-        packs = cache_of_key(conv, "dgrad").get((w,), build)
-        zs = [ops.conv2d_nhwc(dy, wp, cout, b - a, 3, 1) for wp, (a, b) in zip(packs, parts)]
-        z = zs[0] if len(zs) == 1 else torch.cat(zs, dim=-1)
-        b_, ho, wo, _ = z.shape
-        return z.view(b_, ho, wo, 2, 2, cin).permute(0, 1, 3, 2, 4, 5).reshape(b_, 2 * ho, 2 * wo, cin)      # the 4 parity classes interleaved
+            return [(ops.pack_conv2d_weight(w4[a:b].contiguous()), b - a) for a, b in parts]
+        return cache_of_key(conv, "dgrad").get((w,), build)
     raise NotImplementedError(f"conv2d input gradient for k={k} stride={stride}")
+
+
+def conv2d_dgrad(conv, dy):
+    """Input gradient of a Conv2d(k3,s1,p1) or Conv2d(k5,s2,p2) layer, NHWC, on the forward conv kernels."""
+    k, cin, cout = conv.kernel_size[0], conv.in_channels, conv.out_channels
+    packs = _dgrad2d_pack(conv)
+    if k == 3:
+        return ops.conv2d_nhwc(dy, packs, cout, cin, 3, 1)
+    zs = [ops.conv2d_nhwc(dy, wp, cout, n, 3, 1) for wp, n in packs]
+    z = zs[0] if len(zs) == 1 else torch.cat(zs, dim=-1)
+    b_, ho, wo, _ = z.shape
+    return z.view(b_, ho, wo, 2, 2, cin).permute(0, 1, 3, 2, 4, 5).reshape(b_, 2 * ho, 2 * wo, cin)      # the 4 parity classes interleaved
 
 
 class Tape2D:
@@ -363,27 +389,30 @@ class Tape2D:
     `groups` independent module calls batched along the image axis (one group per view)."""
 
     def __init__(self, groups):
-        self.groups, self.layers = groups, []
+        self.groups, self.layers, self.pool = groups, [], None
 
     def layer(self, conv, bn, x, planar_in=False, x_for_wgrad=None):
         k, stride = conv.kernel_size[0], conv.stride[0]
         from .layers import cache_of_key
+        if self.pool is None:
+            self.pool = ZeroPool(x.device)
         wp = cache_of_key(conv, "fwd").get((conv.weight,), lambda: ops.pack_conv2d_weight(conv.weight))
         y = ops.conv2d_nhwc(x, wp, conv.in_channels, conv.out_channels, k, stride, planar_in=planar_in)        # raw conv
         c = conv.out_channels
         n = y.numel() // c // self.groups
-        aux = bn_finalize(bn_stats(y, n, c, self.groups), bn, n, c, self.groups)
+        aux = bn_finalize(bn_stats(y, n, c, self.groups, pool=self.pool), bn, n, c, self.groups)
         z = bn_relu_apply(y, aux, None, n, c, self.groups)
         self.layers.append((conv, bn, x if x_for_wgrad is None else x_for_wgrad, y, aux, z, x_for_wgrad is not None))
         return z
 
     def backward(self, grads):
         pg = {}
+        pool = ZeroPool(self.layers[0][3].device)
         for conv, bn, x, y, aux, z, is_input in reversed(self.layers):
             dz = grads.pop(id(z))
             c = conv.out_channels
             n = y.numel() // c // self.groups
-            dy, pg[bn.weight], pg[bn.bias] = bn_relu_backward(dz.contiguous(), y, aux, bn.weight, n, c, self.groups)
+            dy, pg[bn.weight], pg[bn.bias] = bn_relu_backward(dz.contiguous(), y, aux, bn.weight, n, c, self.groups, pool=pool)
             pg[conv.weight] = conv2d_wgrad(dy, x, conv.kernel_size[0], conv.stride[0], tuple(conv.weight.shape))
             if not is_input:
                 dx = conv2d_dgrad(conv, dy)
@@ -428,3 +457,30 @@ class TrunkTrainFn(torch.autograd.Function):
 def trunk_train(module, imgs, groups):
     params = tuple(p for seq in (module.conv01, module.conv12, module.conv23, module.conv34) for p in seq.parameters())
     return TrunkTrainFn.apply(module, groups, imgs, *params)
+
+
+# --------------------------------------------------------------------------- weight packing off the critical path
+def prepack(model):
+    """Pack the forward and input-gradient weights of every conv layer the training kernels will use in this step (the
+    optimizer has just changed them: ~85 tiny launches).  Called on a side stream at the top of CoreNet.forward; the cache
+    entries carry an event, the consuming stream waits for it (mdfnet_hip/layers.py:_Folded)."""
+    import torch.nn as nn
+    from .layers import cache_of_key
+    for reg in model.Regular:
+        for m in reg.modules():
+            if isinstance(m, nn.ConvTranspose3d):
+                ops_pack_fwd(m, True)
+                dgrad_pack(m, True)
+            elif isinstance(m, nn.Conv3d) and m.out_channels > 1 and tuple(m.kernel_size) == (3, 3, 3):
+                ops_pack_fwd(m, False)
+                dgrad_pack(m, False)
+    bb = model.Backbone
+    if hasattr(bb, "conv34"):
+        first = True
+        for seq in (bb.conv01, bb.conv12, bb.conv23, bb.conv34):
+            for blk in seq:
+                conv = blk.conv
+                cache_of_key(conv, "fwd").get((conv.weight,), lambda c=conv: ops.pack_conv2d_weight(c.weight))
+                if not first:
+                    _dgrad2d_pack(conv)
+                first = False

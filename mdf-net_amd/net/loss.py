@@ -12,5 +12,11 @@ class Loss(torch.nn.Module):
         for est, gt in zip(outputs["depth"], depth_gt.values()):
             valid = gt > floor
             for e in (est if isinstance(est, (list, tuple)) else [est]):
-                total = total + F.smooth_l1_loss(e[valid], gt[valid], reduction="mean")
+                if e.is_cuda:
+                    # the same masked mean without boolean indexing: `e[valid]` has a data-dependent size, i.e. a device->host
+                    # synchronisation in the middle of every training step (2.7 ms of stalled issue at cfg3)
+                    per = F.smooth_l1_loss(e, gt, reduction="none")
+                    total = total + (per * valid).sum() / valid.sum()
+                else:
+                    total = total + F.smooth_l1_loss(e[valid], gt[valid], reduction="mean")
         return total
