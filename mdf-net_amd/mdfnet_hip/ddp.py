@@ -5,6 +5,8 @@ re-broadcast every forward, gradients reduce-added to GPU 0, BatchNorm statistic
 running stats surviving.  Here each rank owns a full replica; the 1,206,380 gradients (158 tensors, 4.83 MB) are
 views into one contiguous buffer so a step costs exactly one RCCL all-reduce over xGMI (backend "nccl" on ROCm; "gloo"
 on CPU for the tests), and rank 0's BatchNorm buffers are broadcast to mirror DataParallel's semantics."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -21,6 +23,7 @@ class FlatBucket:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self._pad = self._recv = None
 
     def zero_grad(self):
         self.flat.zero_()
@@ -51,8 +54,27 @@ class FlatBucket:
             for b in self.module.buffers():
                 dist.broadcast(b, src)
 
-    def allreduce_gradients(self):
-        """Mean over ranks of the flat gradient buffer: one collective per step."""
-        if self.world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.div_(self.world)
+    def allreduce_gradients(self, mode=None):
+        """Mean over ranks of the flat gradient buffer.
+        mode "allreduce" (default): ONE collective per step (RCCL picks ring/tree; gloo in the CPU tests).
+        mode "direct" (MDF_GRAD_EXCHANGE=direct): the two-step exchange SURVEY section 5 proposes for a fully connected xGMI
+        node -- every rank sends shard j of its 4.83-MB buffer straight to rank j (all-to-all: all 7 links busy at once, 0.6 MB
+        per link), sums the shards it owns, and the owners' sums are all-gathered: 2 latency steps instead of the 14 of a ring.
+        Same result up to summation order (asserted in tests/test_train_cpu.py); unmeasured on hardware, hence not the default."""
+        if self.world <= 1:
+            return
+        mode = mode or os.environ.get("MDF_GRAD_EXCHANGE", "allreduce")
+        if mode == "direct":
+            n, w = self.flat.numel(), self.world
+            shard = (n + w - 1) // w
+            if self._pad is None or self._pad.numel() != shard * w:
+                self._pad = torch.zeros(shard * w, dtype=torch.float32, device=self.flat.device)
+                self._recv = torch.empty_like(self._pad)
+            self._pad[:n].copy_(self.flat)
+            dist.all_to_all_single(self._recv, self._pad)                 # row r of _recv: rank r's copy of MY shard
+            mine = self._recv.view(w, shard).sum(0).div_(w)
+            dist.all_gather_into_tensor(self._pad, mine)
+            self.flat.copy_(self._pad[:n])
+            return
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self.flat.div_(self.world)

@@ -112,3 +112,40 @@ def test_two_rank_gloo_flat_bucket_matches_mean_of_replica_gradients(tmp_path, s
     torch.set_num_threads(nthreads)
     exp = (acc / 2).numpy()
     np.testing.assert_allclose(got["flat"], exp, rtol=1e-4, atol=1e-6 * float(np.abs(exp).max()))
+
+
+EXCH_WORKER = r'''
+import os, sys, json
+sys.path[:0] = [%(pkg)r]
+import torch, torch.distributed as dist
+from mdfnet_hip import ddp, shard
+rank, world, _ = shard.init("gloo")
+torch.manual_seed(0)
+lin = torch.nn.Sequential(torch.nn.Linear(37, 11), torch.nn.Linear(11, 3))     # 37*11+11+11*3+3 = 454 elements: not a multiple of 3
+res = {}
+for mode in ("allreduce", "direct"):
+    b = ddp.FlatBucket(lin)
+    g = torch.Generator().manual_seed(100 + rank)
+    b.flat.copy_(torch.randn(b.flat.numel(), generator=g))
+    b.allreduce_gradients(mode)
+    res[mode] = b.flat.clone()
+exp = sum(torch.randn(res["direct"].numel(), generator=torch.Generator().manual_seed(100 + r)) for r in range(world)) / world
+ok = bool(torch.allclose(res["direct"], exp, rtol=1e-6, atol=1e-7)) and bool(torch.allclose(res["allreduce"], exp, rtol=1e-6, atol=1e-7))
+views = all(p.grad.data_ptr() >= b.flat.data_ptr() for p in lin.parameters())
+gathered = [None] * world
+dist.all_gather_object(gathered, [ok, views])
+if rank == 0:
+    print(json.dumps({"world": world, "ok": all(g[0] for g in gathered), "views": all(g[1] for g in gathered), "n": int(res["direct"].numel())}))
+'''
+
+
+def test_three_rank_gloo_direct_gradient_exchange_equals_allreduce(tmp_path):
+    """SURVEY section 5's exchange for a fully connected xGMI node (all-to-all of shards, local sum, all-gather) gives the mean of
+    the replica gradients, like the one all-reduce; 3 ranks and a buffer whose length is not a multiple of the world size."""
+    script = tmp_path / "x.py"
+    script.write_text(EXCH_WORKER % {"pkg": os.path.join(ROOT, "mdf-net_amd")})
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr",
+                        "127.0.0.1", "--master-port", "29643", str(script)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec == {"world": 3, "ok": True, "views": True, "n": 454}
