@@ -217,6 +217,10 @@ int mdf_conv2d_wgrad(const float* small_, const float* big, float* dw, float* wo
 /* (input gradients of these layers are mdf_conv3d_fwd with re-packed weights: a stride-1 conv with flipped taps and
  *  swapped channels, the transposed conv for a stride-2 conv and vice versa.) */
 
+/* ---- adjoint of the FPN's bilinear x2 upsampling (backbone.py:60,62; F.interpolate(scale_factor=2, "bilinear",
+ *      align_corners=False)), NHWC: dcoarse [B,h,w,C] (+)= up^T(dfine [B,2h,2w,C]); C % 4 == 0.                  */
+int mdf_upsample2_bilinear_bwd(const float* dfine, float* dcoarse, int B, int h, int w, int C, int accumulate, void* stream);
+
 /* ---- backward of the `prob` head: softmax over D + soft-argmin (regular.py:69/133, regress.py:5-7), and the input
  *      gradient of its Conv3d(C->1,k3,p1).   dlogit [B,D,h,w]; ddepth [B,h,w] and/or dprob [B,D,h,w] (either may be
  *      NULL); w torch [1,C,3,3,3]; dx NDHWC [B,D,h,w,C], C in {8,16}.                                           */

@@ -56,6 +56,7 @@ SIGNATURES = {
     "mdf_conv3d_wgrad": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp]),
     "mdf_conv2d_wgrad_workspace": (c_i64, [c_int] * 6),
     "mdf_conv2d_wgrad": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp]),
+    "mdf_upsample2_bilinear_bwd": (c_int, [c_fp, c_fp] + [c_int] * 5 + [c_fp]),
     "mdf_prob_softmax_regress_bwd": (c_int, [c_fp, c_fp, c_int, c_fp, c_fp, c_fp] + [c_int] * 4 + [c_fp]),
     "mdf_prob_conv_dgrad": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 5 + [c_fp]),
     "mdf_warp_aggregate_vec_train": (c_int, [c_int, c_fp, ctypes.POINTER(c_fp), c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,

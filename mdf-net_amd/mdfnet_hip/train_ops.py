@@ -484,3 +484,88 @@ def prepack(model):
                 if not first:
                     _dgrad2d_pack(conv)
                 first = False
+
+
+# --------------------------------------------------------------------------- FPN heads (1x1 convs + top-down adds) in training mode
+def upsample2_backward(dfine, dcoarse=None):
+    """up^T: [B,2h,2w,C] -> [B,h,w,C]; added into `dcoarse` when given (adjoint of F.interpolate x2 bilinear, backbone.py:60,62)."""
+    b, h2, w2, c = dfine.shape
+    out = torch.empty((b, h2 // 2, w2 // 2, c), device=dfine.device, dtype=torch.float32) if dcoarse is None else dcoarse
+    _abi("mdf_upsample2_bilinear_bwd", (dfine.data_ptr(), out.data_ptr(), b, h2 // 2, w2 // 2, c, int(dcoarse is not None), _stream(out)),
+         tag=f"upT {h2}x{w2}x{c}", work={"bytes": 4.0 * (dfine.numel() + out.numel()), "bound": "hbm"})
+    return out
+
+
+def _pack1x1(conv, transposed):
+    from .layers import cache_of_key
+    w = conv.weight
+    if transposed:
+        return cache_of_key(conv, "dgrad").get((w,), lambda: ops.pack_conv2d_weight(w.detach().transpose(0, 1).contiguous()))
+    return cache_of_key(conv, "fwd").get((w,), lambda: ops.pack_conv2d_weight(w))
+
+
+def _conv1x1(conv, x, transposed=False, res_up=None):
+    cin, cout = (conv.out_channels, conv.in_channels) if transposed else (conv.in_channels, conv.out_channels)
+    bias = None if (transposed or conv.bias is None) else conv.bias.detach()
+    return ops.conv2d_nhwc(x, _pack1x1(conv, transposed), cin, cout, 1, 1, None, bias, False, None, 1.0, res_up)
+
+
+class FPNHeadsTrainFn(torch.autograd.Function):
+    """(t2, t3, t4) -> (out4(t4), out3(up(t4) + lat3(t3)), out2(up(up3) + lat2(t2)))   (backbone.py:59-63), NHWC kernels:
+    the lateral 1x1 conv, its bias and the bilinear top-down add are one launch; backward = 1x1 convs with transposed weights,
+    the adjoint upsampling kernel, 1x1 weight gradients on the MFMA wgrad kernel, bias gradients on the BN-statistics kernel."""
+
+    @staticmethod
+    def forward(ctx, m, t2, t3, t4, *params):
+        t2n, t3n, t4n = ops.to_nhwc(t2.detach()), ops.to_nhwc(t3.detach()), ops.to_nhwc(t4.detach())
+        up3 = _conv1x1(m.lat3, t3n, res_up=t4n)
+        up2 = _conv1x1(m.lat2, t2n, res_up=up3)
+        y4, y3, y2 = _conv1x1(m.out4, t4n), _conv1x1(m.out3, up3), _conv1x1(m.out2, up2)
+        ctx.m, ctx.saved, ctx.params = m, (t2n, t3n, t4n, up3, up2), params
+        ctx.set_materialize_grads(False)
+        return ops.from_nhwc(y4), ops.from_nhwc(y3), ops.from_nhwc(y2)
+
+    @staticmethod
+    def backward(ctx, dy4, dy3, dy2):
+        m = ctx.m
+        t2n, t3n, t4n, up3, up2 = ctx.saved
+
+        def nh(g, like):
+            return torch.zeros_like(like) if g is None else ops.to_nhwc(g)
+        dy4, dy3, dy2 = nh(dy4, t4n), ops.to_nhwc(dy3) if dy3 is not None else None, ops.to_nhwc(dy2) if dy2 is not None else None
+        pg = {}
+        pool = ZeroPool(t2n.device, 1024)
+
+        def bias_grad(g):
+            c = g.shape[-1]
+            return bn_stats(g, g.numel() // c, c, pool=pool)[:c].float()
+        d_up3 = None
+        if dy2 is not None:
+            d_up2 = _conv1x1(m.out2, dy2, transposed=True)
+            pg[m.out2.weight] = conv2d_wgrad(dy2, up2, 1, 1, tuple(m.out2.weight.shape))
+            pg[m.lat2.weight] = conv2d_wgrad(d_up2, t2n, 1, 1, tuple(m.lat2.weight.shape))
+            pg[m.lat2.bias] = bias_grad(d_up2)
+            dt2 = _conv1x1(m.lat2, d_up2, transposed=True)
+            d_up3 = upsample2_backward(d_up2)
+        else:
+            dt2 = torch.zeros_like(t2n)
+        if dy3 is not None:
+            g3 = _conv1x1(m.out3, dy3, transposed=True)
+            pg[m.out3.weight] = conv2d_wgrad(dy3, up3, 1, 1, tuple(m.out3.weight.shape))
+            d_up3 = g3 if d_up3 is None else d_up3.add_(g3)
+        dt4 = _conv1x1(m.out4, dy4, transposed=True)
+        pg[m.out4.weight] = conv2d_wgrad(dy4, t4n, 1, 1, tuple(m.out4.weight.shape))
+        if d_up3 is not None:
+            pg[m.lat3.weight] = conv2d_wgrad(d_up3, t3n, 1, 1, tuple(m.lat3.weight.shape))
+            pg[m.lat3.bias] = bias_grad(d_up3)
+            dt3 = _conv1x1(m.lat3, d_up3, transposed=True)
+            upsample2_backward(d_up3, dt4)
+        else:
+            dt3 = torch.zeros_like(t3n)
+        ctx.saved = None
+        return (None, ops.from_nhwc(dt2), ops.from_nhwc(dt3), ops.from_nhwc(dt4)) + tuple(pg.get(p) for p in ctx.params)
+
+
+def fpn_heads_train(module, t2, t3, t4):
+    params = tuple(p for mod in (module.lat2, module.lat3, module.out2, module.out3, module.out4) for p in mod.parameters())
+    return FPNHeadsTrainFn.apply(module, t2, t3, t4, *params)

@@ -77,6 +77,9 @@ class FPN_4Scales(nn.Module):
         return ops.from_nhwc(y4), ops.from_nhwc(y3), ops.from_nhwc(y2)
 
     def _heads(self, t2, t3, t4):
+        if layers.hip_train(self, t2, t3, t4):
+            from mdfnet_hip import train_ops
+            return train_ops.fpn_heads_train(self, t2, t3, t4)
         up3 = F.interpolate(t4, scale_factor=2.0, mode="bilinear", align_corners=False) + self.lat3(t3)
         up2 = F.interpolate(up3, scale_factor=2.0, mode="bilinear", align_corners=False) + self.lat2(t2)
         return self.out4(t4), self.out3(up3), self.out2(up2)
@@ -84,8 +87,8 @@ class FPN_4Scales(nn.Module):
     def forward_views(self, imgs):
         """Training on the GPU, all views at once: imgs [B,V,3,H,W] -> list over views of (f8, f4, f2).  The conv trunk
         (11 Conv2d + BatchNorm2d + ReLU layers, forward and backward) runs on the hand-written training kernels with one
-        BatchNorm group per view -- the statistics of V separate calls, net/core.py:42 -- and the bias-only 1x1 heads, which
-        have no batch statistics, run batched through their stock modules."""
+        BatchNorm group per view -- the statistics of V separate calls, net/core.py:42 -- and the bias-only 1x1 heads with their
+        bilinear top-down adds, which have no batch statistics, run batched on the same kernels (train_ops.FPNHeadsTrainFn)."""
         from mdfnet_hip import train_ops
         b, v = imgs.shape[:2]
         x = imgs.transpose(0, 1).reshape(v * b, *imgs.shape[2:])           # view-major: group g = view g
