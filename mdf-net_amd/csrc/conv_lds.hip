@@ -978,6 +978,7 @@ int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha
   LDS_CASE(64, 64, 64, 1, 1, 1, 1)
   LDS_CASE(32, 32, 32, 1, 1, 1, 2) LDS_CASE(32, 32, 16, 1, 1, 1, 2) LDS_CASE(16, 16, 16, 1, 1, 1, 4)   // composed FPN heads
   LDS_CASE(4, 1, 8, 1, 3, 1, 4) LDS_CASE(8, 8, 32, 1, 3, 1, 4) LDS_CASE(8, 8, 1, 1, 3, 1, 4)
+  LDS_CASE(32, 32, 8, 1, 3, 1, 2)                                       // input gradient of the refinement net's 8 -> 32 conv (training)
   LDS_CASE(16, 16, 32, 1, 3, 1, 2) LDS_CASE(32, 32, 64, 1, 3, 1, 1)   // input gradients of the k5-s2 layers (training): 3x3 over dy, 4 parity classes as channels
   LDS_CASE(16, 16, 4, 1, 3, 1, 4) LDS_CASE(8, 8, 4, 1, 3, 1, 4)   // prob head as per-plane partial sums (prob_head.hip)
   return MDF_EUNSUPPORTED;

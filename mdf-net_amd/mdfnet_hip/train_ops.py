@@ -569,3 +569,69 @@ class FPNHeadsTrainFn(torch.autograd.Function):
 def fpn_heads_train(module, t2, t3, t4):
     params = tuple(p for mod in (module.lat2, module.lat3, module.out2, module.out3, module.out4) for p in mod.parameters())
     return FPNHeadsTrainFn.apply(module, t2, t3, t4, *params)
+
+
+# --------------------------------------------------------------------------- refinement net in training mode
+def _conv3x3(conv, x, relu=False, res=None, res_scale=1.0, shuffle=False, transposed=False):
+    from .layers import cache_of_key
+    w = conv.weight
+    if transposed:     # input gradient: flipped taps, swapped channels
+        wp = cache_of_key(conv, "dgrad").get((w,), lambda: ops.pack_conv2d_weight(w.detach().flip(2, 3).transpose(0, 1).contiguous()))
+        return ops.conv2d_nhwc(x, wp, conv.out_channels, conv.in_channels, 3, 1, None, None, relu, res, res_scale)
+    if shuffle:
+        wp = cache_of_key(conv, "fwd").get((w,), lambda: ops.pack_conv2d_weight(ops.shuffle2_rows(w)))
+    else:
+        wp = cache_of_key(conv, "fwd").get((w,), lambda: ops.pack_conv2d_weight(w))
+    return ops.conv2d_nhwc(x, wp, conv.in_channels, conv.out_channels, 3, 1, None, None, relu, res, res_scale, pixel_shuffle2=shuffle)
+
+
+class RefineTrainFn(torch.autograd.Function):
+    """RefineNet2.forward (refine.py:25-46) in training mode on the 2-D conv kernels; the depth input is detached in the
+    reference (refine.py:29), so the backward produces weight gradients only."""
+
+    @staticmethod
+    def forward(ctx, m, depth, lo, span, *params):
+        x = ((depth.detach().unsqueeze(1) - lo) / span).permute(0, 2, 3, 1).contiguous()          # [B,h,w,1]
+        x0 = _conv3x3(m.conv0, x)
+        y, chain = x0, []
+        for blk in m.ress:                                                                          # y + 0.1*conv(relu(conv(y)))
+            t = _conv3x3(blk.conv[0], y, relu=True)
+            y_new = _conv3x3(blk.conv[2], t, res=y, res_scale=0.1)
+            chain.append((blk, y, t))
+            y = y_new
+        z = _conv3x3(m.conv1, y, res=x0)
+        s_ = _conv3x3(m.conv2[0], z, shuffle=True)                                                  # [B,2h,2w,8]
+        o = _conv3x3(m.conv2[2], s_)                                                                # [B,2h,2w,1]
+        ctx.m, ctx.saved, ctx.params, ctx.span = m, (x, x0, chain, y, z, s_), params, span
+        return (lo + o.permute(0, 3, 1, 2) * span).squeeze(1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        m = ctx.m
+        x, x0, chain, y3, z, s_ = ctx.saved
+        b, h, w, _ = z.shape
+        pg = {}
+
+        def wg(conv, small, big):
+            pg[conv.weight] = conv2d_wgrad(small, big, 3, 1, tuple(conv.weight.shape))
+        do = (dout.unsqueeze(1) * ctx.span).permute(0, 2, 3, 1).contiguous()                       # [B,2h,2w,1]
+        wg(m.conv2[2], do, s_)
+        ds = _conv3x3(m.conv2[2], do, transposed=True)                                              # [B,2h,2w,8]
+        dq = ds.view(b, h, 2, w, 2, 8).permute(0, 1, 3, 5, 2, 4).reshape(b, h, w, 32)                # un-shuffle: channel c*4 + dy*2 + dx
+        wg(m.conv2[0], dq, z)
+        dz = _conv3x3(m.conv2[0], dq, transposed=True)                                              # d (x0 + conv1(y3))
+        wg(m.conv1, dz, y3)
+        dy = _conv3x3(m.conv1, dz, transposed=True)
+        for blk, y_in, t in reversed(chain):
+            g = dy * 0.1
+            wg(blk.conv[2], g, t)
+            dt = _conv3x3(blk.conv[2], g, transposed=True) * (t > 0)
+            wg(blk.conv[0], dt, y_in)
+            dy = _conv3x3(blk.conv[0], dt, transposed=True, res=dy)                                 # dy + d conv_a
+        wg(m.conv0, dz + dy, x)
+        ctx.saved = None
+        return (None, None, None, None) + tuple(pg.get(p) for p in ctx.params)
+
+
+def refine_train(module, depth, lo, span):
+    return RefineTrainFn.apply(module, depth, lo, span, *tuple(module.parameters()))

@@ -35,6 +35,9 @@ class RefineNet2(nn.Module):
                 y = layers.conv2d_layer(self.conv2[0], None, y, pixel_shuffle2=True)               # conv + PixelShuffle(2): [B,2h,2w,8]
                 y = layers.conv2d_layer(self.conv2[2], None, y)                                    # [B,2h,2w,1]
                 return (lo + y.permute(0, 3, 1, 2) * span).squeeze(1)
+        if layers.hip_train(self, depth):
+            from mdfnet_hip import train_ops
+            return train_ops.refine_train(self, depth, lo, span)
         x0 = self.conv0((depth.detach().unsqueeze(1) - lo) / span)
         y = x0
         for blk in self.ress:

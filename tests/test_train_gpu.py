@@ -378,3 +378,29 @@ def test_feature_pyramid_training_forward_backward():
     for (k, ba), (_, br) in zip(mod.named_buffers(), ref.named_buffers()):
         assert _rel(ba.float(), br.float()) < 1e-4, k
     print(f"\nfeature pyramid: worst parameter-gradient L2 error vs float64 {worst:.2e}")
+
+
+def test_refine_net_training_forward_backward():
+    """RefineNet2 in training mode (no BatchNorm; detached input): output and every weight gradient vs the stock modules on the
+    CPU (fp32) and in float64."""
+    import copy
+    from net.unit.refine import RefineNet2
+    torch.manual_seed(9)
+    ref = RefineNet2().train()
+    ref64 = copy.deepcopy(ref).double()
+    mod = copy.deepcopy(ref).to(DEV)
+    b, h, w = 2, 48, 72
+    depth = 425 + 510 * torch.rand(b, h, w)
+    dr = torch.tensor([[425.0, 935.0], [425.0, 935.0]], dtype=torch.float64)
+    gout = torch.randn(b, 2 * h, 2 * w)
+    out_ref = ref(depth, dr)
+    (out_ref * gout).sum().backward()
+    out64 = ref64(depth.double(), dr)
+    (out64 * gout.double()).sum().backward()
+    out = mod(depth.to(DEV), dr.to(DEV))
+    (out * gout.to(DEV)).sum().backward()
+    assert out.shape == out_ref.shape and _l2(out, out64) <= max(3 * _l2(out_ref, out64), 1e-6)
+    for (k, pa), (_, pr), (_, p64) in zip(mod.named_parameters(), ref.named_parameters(), ref64.named_parameters()):
+        assert pa.grad is not None, k
+        e_hip, e_cpu = _l2(pa.grad, p64.grad), _l2(pr.grad, p64.grad)
+        assert e_hip <= max(3 * e_cpu, 2e-5), (k, e_hip, e_cpu)
