@@ -2,7 +2,7 @@
 """Headline benchmark: views/sec of the 4-scale MVS eval forward at DTU 1600x1184 (cropped 1600x1200), 5 views,
 hypotheses (48,24,8), batch 1 per rank (BASELINE.json configs[1]); synthetic DTU-shaped tensors, seeded weights.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 200 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -170,8 +170,8 @@ def cpu_baseline(timed_views=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)     # ~0.9 s of timed region at 4.4 ms/step
+    ap.add_argument("--warmup", type=int, default=10)
     from mdfnet_hip.pipeline import DEFAULT_IN_FLIGHT
     ap.add_argument("--in-flight", type=int, default=int(os.environ.get("MDF_BENCH_IN_FLIGHT", DEFAULT_IN_FLIGHT)),
                     help="items in flight on that many HIP streams (the eval driver's pipelining); 1 = strictly one at a time")

@@ -15,11 +15,31 @@
 // a second kernel sums the slab in a few dozen partial sums per element (no storm of float atomics on the 27*A*B hot addresses).
 //   A operand: lane l holds small[voxel 4j + (l>>4)][a = l&15]      C/D: lane l holds rows 4*(l>>4)..+3, column l&15
 //   B operand: lane l holds big  [voxel 4j + (l>>4)][b = l&15]
+#include <cstdlib>
 #include "common.h"
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+typedef unsigned u32;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);   // raw buffer, dword format (gfx9)
+}
+// One operand element: buffer load at {lane-constant byte offset} + {scalar byte offset}.  No per-load address arithmetic on
+// the VALU (the first version spent 284 VALU instructions per 12 MFMAs on 64-bit addresses, divisions and predicated loads:
+// PMC SQ_INSTS_VALU / SQ_INSTS_MFMA = 23.6); out-of-range offsets (also "negative" ones, which wrap) return 0.
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, u32 lane_off, u32 s_off) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_off, (int)s_off, 0));
+}
+// The same with a spatial mask (edge chunks only).  The empty asm pins the load: a bare select lets the compiler sink the
+// load under the select's condition, i.e. a branch and a wait per load.
+__device__ __forceinline__ float bload_masked(__amdgpu_buffer_rsrc_t r, u32 lane_off, u32 s_off, bool ok) {
+  float v = bload(r, lane_off, s_off);
+  asm volatile("" : "+v"(v));
+  return ok ? v : 0.0f;
+}
 
 struct WgradParams {
   const float* small_;   // [B,Ds,Hs,Ws,A]
@@ -33,7 +53,8 @@ struct WgradParams {
 };
 
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: the item bookkeeping below runs on the scalar unit
   const int q = lane >> 4, c16 = lane & 15;
   // which (a-tile, b-tile) pair this wave owns, and which slice of the block's chunk stream
   const int pairs_per_block = 4 / p.split;
@@ -41,52 +62,90 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   const int part = wave % p.split;
   const int na = pair / p.NB, nb = pair % p.NB;
   const int a = na * 16 + c16, bcol = nb * 16 + c16;
-  const bool a_ok = a < p.A, b_ok = bcol < p.Bc;
+  const bool b_ok = bcol < p.Bc;
+  // lanes past the channel count read a clamped channel: their tile rows / columns are never stored, no masking needed
+  const int ac = min(a, p.A - 1), bc = min(bcol, p.Bc - 1);
+  const int s = p.stride;
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.small_, (unsigned)((long long)p.B * p.Ds * p.Hs * p.Ws * p.A * 4));
+  const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.big, (unsigned)((long long)p.B * p.Db * p.Hb * p.Wb * p.Bc * 4));
+  const u32 la = (u32)((q * p.A + ac) * 4), lb = (u32)((q * s * p.Bc + bc) * 4);
 
   const int kd = blockIdx.z;          // one depth tap per block: 9 accumulator tiles per wave, 3x the independent work
   f32x4 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int s = p.stride;
-  for (long long item = (long long)blockIdx.x * p.split + part; item < p.n_items; item += (long long)gridDim.x * p.split) {
+  // Software pipeline over the wave's items: the 40 operand loads of item i+1 are in flight while the 36 MFMAs of item i run
+  // (the first version loaded, waited and multiplied one kernel row at a time: three exposed memory latencies per item).
+  auto issue = [&](long long item, float (&af)[4], float (&bf)[9][4]) -> int {
     const int ch = (int)(item % p.chunks_per_row);
     long long r = item / p.chunks_per_row;
     const int oh = (int)(r % p.Hs); r /= p.Hs;
     const int od = (int)(r % p.Ds);
     const int n = (int)(r / p.Ds);
+    const int id = od * s + kd - 1;
+    if (id < 0 || id >= p.Db) return 0;            // wave-uniform
     const int ow0 = ch * 16;
-    float af[4];
-    const float* srow = p.small_ + (((long long)n * p.Ds + od) * p.Hs + oh) * (long long)p.Ws * p.A;
+    const u32 srow = (u32)(((((long long)n * p.Ds + od) * p.Hs + oh) * p.Ws + ow0) * p.A * 4);
+    const bool edge = (ow0 == 0) || ((ow0 + 16) * s + 1 > p.Wb) || (ow0 + 16 > p.Ws);   // wave-uniform
+    if (!edge) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int ow = ow0 + 4 * j + q;
-      af[j] = (a_ok && ow < p.Ws) ? srow[(long long)ow * p.A + a] : 0.0f;
+      for (int j = 0; j < 4; ++j) af[j] = bload(rs, la, srow + (u32)(4 * j * p.A * 4));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) af[j] = bload_masked(rs, la, srow + (u32)(4 * j * p.A * 4), ow0 + 4 * j + q < p.Ws);
     }
-    {
-      const int id = od * s + kd - 1;
-      if (id < 0 || id >= p.Db) continue;          // wave-uniform
+    int mask = 0;
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int ih = oh * s + kh - 1;
-        if (ih < 0 || ih >= p.Hb) continue;        // wave-uniform
-        const float* brow = p.big + (((long long)n * p.Db + id) * p.Hb + ih) * (long long)p.Wb * p.Bc;
-        float bf[3][4];
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = oh * s + kh - 1;
+      if (ih < 0 || ih >= p.Hb) continue;        // wave-uniform
+      mask |= 1 << kh;
+      const long long brow = ((((long long)n * p.Db + id) * p.Hb + ih) * p.Wb + (long long)ow0 * s - 1) * p.Bc * 4;   // tap kw = 0 of voxel ow0
+      if (!edge) {
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bf[kh * 3 + kw][j] = bload(rb, lb, (u32)(brow + (long long)(4 * j * s + kw) * p.Bc * 4));
+      } else {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
+            // (the hardware adds lane and scalar offsets WITHOUT wrapping, so a "negative" scalar part is out of range for every
+            //  lane: at the row start the offset is formed per lane from the clamped coordinate instead)
             const int iw = (ow0 + 4 * j + q) * s + kw - 1;
-            bf[kw][j] = (b_ok && iw >= 0 && iw < p.Wb) ? brow[(long long)iw * p.Bc + bcol] : 0.0f;
+            const int base = max(ow0 * s - 1, 0);             // first voxel any lane of this chunk can need
+            bf[kh * 3 + kw][j] = bload_masked(rb, (u32)(((max(iw, 0) - base) * p.Bc + bc) * 4),
+                                              (u32)(brow + (long long)(base - (ow0 * s - 1)) * p.Bc * 4), iw >= 0 && iw < p.Wb);
           }
-        }
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[kw][j], acc[kh * 3 + kw], 0, 0, 0);
-        }
       }
+    }
+    return mask;
+  };
+  auto compute = [&](const float (&af)[4], const float (&bf)[9][4], int mask) {
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      if (!((mask >> kh) & 1)) continue;         // wave-uniform
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[kh * 3 + kw][j], acc[kh * 3 + kw], 0, 0, 0);
+    }
+  };
+  {
+    const long long step = (long long)gridDim.x * p.split;
+    long long it = (long long)blockIdx.x * p.split + part;
+    float a0[4], b0[9][4], a1[4], b1[9][4];
+    int m0 = (it < p.n_items) ? issue(it, a0, b0) : 0, m1 = 0;
+    while (it < p.n_items) {
+      const long long nx = it + step;
+      m1 = (nx < p.n_items) ? issue(nx, a1, b1) : 0;
+      compute(a0, b0, m0);
+      if (nx >= p.n_items) break;
+      it = nx + step;
+      m0 = (it < p.n_items) ? issue(it, a0, b0) : 0;
+      compute(a1, b1, m1);
     }
   }
 
@@ -152,8 +211,10 @@ __global__ __launch_bounds__(256) void wgrad_a1_kernel(const WgradParams p) {
     for (int j = 0; j < 4; ++j) {
       const int w = ch * 16 + 4 * j + q;
       const int wsm = w - (kw - 1);
-      const float a = (hs_ok && w < p.Ws && wsm >= 0 && wsm < p.Ws) ? srow[wsm] : 0.0f;
-      const float bv = (b_ok && w < p.Ws) ? brow[(long long)w * p.Bc + c16] : 0.0f;
+      const float av = srow[min(max(wsm, 0), p.Ws - 1)];
+      const float bl = brow[min(w, p.Ws - 1) * p.Bc + min(c16, p.Bc - 1)];
+      const float a = av * ((hs_ok && w < p.Ws && wsm >= 0 && wsm < p.Ws) ? 1.0f : 0.0f);
+      const float bv = bl * ((b_ok && w < p.Ws) ? 1.0f : 0.0f);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc, 0, 0, 0);
     }
   }
@@ -188,48 +249,77 @@ struct Wgrad2dParams {
 template <int KS>
 __global__ __launch_bounds__(256) void wgrad2d_kernel(const Wgrad2dParams p) {
   constexpr int PAD = (KS - 1) / 2;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, c16 = lane & 15;
   const int pairs_per_block = 4 / p.split;
   const int pair = blockIdx.y * pairs_per_block + wave / p.split;
   const int part = wave % p.split;
   const int na = pair / p.NB, nb = pair % p.NB;
   const int a = na * 16 + c16, bcol = nb * 16 + c16;
-  const bool a_ok = a < p.A, b_ok = bcol < p.Bc;
+  const bool b_ok = bcol < p.Bc;
+  const int ac = min(a, p.A - 1), bc = min(bcol, p.Bc - 1);
   const int kh = blockIdx.z;
+  const int s = p.stride;
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.small_, (unsigned)((long long)p.B * p.Hs * p.Ws * p.A * 4));
+  const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.big, (unsigned)((long long)p.B * p.Hb * p.Wb * p.Bc * 4));
+  const u32 la = (u32)((q * p.A + ac) * 4), lb = (u32)((q * s * p.Bc + bc) * 4);
   f32x4 acc[KS];
 #pragma unroll
   for (int t = 0; t < KS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int s = p.stride;
-  for (long long item = (long long)blockIdx.x * p.split + part; item < p.n_items; item += (long long)gridDim.x * p.split) {
+  auto issue = [&](long long item, float (&af)[4], float (&bf)[KS][4]) -> int {
     const int ch = (int)(item % p.chunks_per_row);
     const long long r = item / p.chunks_per_row;
     const int oh = (int)(r % p.Hs);
     const int n = (int)(r / p.Hs);
     const int ih = oh * s + kh - PAD;
-    if (ih < 0 || ih >= p.Hb) continue;            // wave-uniform
+    if (ih < 0 || ih >= p.Hb) return 0;            // wave-uniform
     const int ow0 = ch * 16;
-    float af[4];
-    const float* srow = p.small_ + ((long long)n * p.Hs + oh) * (long long)p.Ws * p.A;
-    const float* brow = p.big + ((long long)n * p.Hb + ih) * (long long)p.Wb * p.Bc;
+    const u32 srow = (u32)((((long long)n * p.Hs + oh) * p.Ws + ow0) * p.A * 4);
+    const long long brow = (((long long)n * p.Hb + ih) * p.Wb + (long long)ow0 * s - PAD) * p.Bc * 4;      // tap kw = 0 of voxel ow0
+    const bool edge = (ow0 * s < PAD) || ((ow0 + 16) * s + PAD > p.Wb) || (ow0 + 16 > p.Ws);              // wave-uniform
+    if (!edge) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int ow = ow0 + 4 * j + q;
-      af[j] = (a_ok && ow < p.Ws) ? srow[(long long)ow * p.A + a] : 0.0f;
+      for (int j = 0; j < 4; ++j) af[j] = bload(rs, la, srow + (u32)(4 * j * p.A * 4));
+#pragma unroll
+      for (int kw = 0; kw < KS; ++kw)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[kw][j] = bload(rb, lb, (u32)(brow + (long long)(4 * j * s + kw) * p.Bc * 4));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) af[j] = bload_masked(rs, la, srow + (u32)(4 * j * p.A * 4), ow0 + 4 * j + q < p.Ws);
+#pragma unroll
+      for (int kw = 0; kw < KS; ++kw)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int iw = (ow0 + 4 * j + q) * s + kw - PAD;      // (offsets do not wrap: formed per lane from the clamped coordinate)
+          const int base = max(ow0 * s - PAD, 0);             // first pixel any lane of this chunk can need
+          bf[kw][j] = bload_masked(rb, (u32)(((max(iw, 0) - base) * p.Bc + bc) * 4), (u32)(brow + (long long)(base - (ow0 * s - PAD)) * p.Bc * 4),
+                                   iw >= 0 && iw < p.Wb);
+        }
     }
-    float bf[KS][4];
+    return 1;
+  };
+  auto compute = [&](const float (&af)[4], const float (&bf)[KS][4], int mask) {
+    if (!mask) return;                             // wave-uniform
 #pragma unroll
-    for (int kw = 0; kw < KS; ++kw) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int iw = (ow0 + 4 * j + q) * s + kw - PAD;
-        bf[kw][j] = (b_ok && iw >= 0 && iw < p.Wb) ? brow[(long long)iw * p.Bc + bcol] : 0.0f;
-      }
-    }
-#pragma unroll
-    for (int kw = 0; kw < KS; ++kw) {
+    for (int kw = 0; kw < KS; ++kw)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[kw][j], acc[kw], 0, 0, 0);
+  };
+  {   // software pipeline: item i+1's loads in flight under item i's MFMAs
+    const long long step = (long long)gridDim.x * p.split;
+    long long it = (long long)blockIdx.x * p.split + part;
+    float a0[4], b0[KS][4], a1[4], b1[KS][4];
+    int m0 = (it < p.n_items) ? issue(it, a0, b0) : 0, m1 = 0;
+    while (it < p.n_items) {
+      const long long nx = it + step;
+      m1 = (nx < p.n_items) ? issue(nx, a1, b1) : 0;
+      compute(a0, b0, m0);
+      if (nx >= p.n_items) break;
+      it = nx + step;
+      m0 = (it < p.n_items) ? issue(it, a0, b0) : 0;
+      compute(a1, b1, m1);
     }
   }
   __shared__ float red[2][KS * 4 * 64];
@@ -281,6 +371,13 @@ __global__ void slab_sum_kernel(const float* __restrict__ slab, int nslab, int n
 
 }  // namespace
 
+int mdf_wgrad_lds_dispatch(const float* small_, const float* big, float* workspace, int* gx_io, int B, int Ds, int Hs, int Ws, int A, int Bc,
+                           int stride, int ksize, int is3d, void* stream);
+static bool wgrad_use_lds() {
+  static const bool on = [] { const char* e = getenv("MDF_WGRAD_LDS"); return e ? atoi(e) != 0 : true; }();   // dev A/B
+  return on;
+}
+
 extern "C" int64_t mdf_conv3d_wgrad_workspace(int B, int Ds, int Hs, int Ws, int A, int Bc) {
   if (B < 1 || Ds < 1 || Hs < 1 || Ws < 1 || A < 1 || Bc < 1) return 0;
   const long long items = (long long)B * Ds * Hs * ((Ws + 15) / 16);
@@ -290,6 +387,8 @@ extern "C" int64_t mdf_conv3d_wgrad_workspace(int B, int Ds, int Hs, int Ws, int
   // enough blocks to fill the chip several times over (3 depth taps x gy pair groups x g), at least `split` chunks each
   long long g = 2048 / (3 * gy);
   if (g > items / split) g = items / split;
+  const long long slab_cap = (8ll << 20) / ((long long)A * Bc * 27 * 4);   // <= 8 MiB of partial tiles: the slab is written and read once
+  if (g > slab_cap && slab_cap >= 16 && items / slab_cap <= 8) g = slab_cap;   // tiny volumes only: there the slab round trip dominates
   if (g < 1) g = 1;
   return g * A * Bc * 27;   // floats
 }
@@ -300,7 +399,8 @@ extern "C" int mdf_conv3d_wgrad(const float* small_, const float* big, float* dw
   MDF_REQUIRE(B > 0 && Ds > 0 && Hs > 0 && Ws > 0, "bad shape");
   MDF_REQUIRE(stride == 1 || stride == 2, "stride must be 1 or 2");
   MDF_REQUIRE(A >= 1 && A <= 64 && Bc >= 1 && Bc <= 64, "channel counts out of range (A=%d, B=%d)", A, Bc);
-  MDF_REQUIRE((long long)B * Ds * Hs * Ws * stride * stride * stride * (A > Bc ? A : Bc) < (1ll << 40), "volume too large");
+  MDF_REQUIRE((long long)B * Ds * Hs * Ws * A * 4 < (1ll << 32) && (long long)B * Ds * Hs * Ws * stride * stride * stride * Bc * 4 < (1ll << 32),
+              "operand volumes must fit 32-bit byte offsets");
   WgradParams p{};
   p.small_ = small_; p.big = big; p.slab = workspace;
   p.B = B; p.Ds = Ds; p.Hs = Hs; p.Ws = Ws; p.Db = Ds * stride; p.Hb = Hs * stride; p.Wb = Ws * stride; p.A = A; p.Bc = Bc; p.stride = stride;
@@ -312,17 +412,28 @@ extern "C" int mdf_conv3d_wgrad(const float* small_, const float* big, float* dw
   p.split = pairs >= 4 ? 1 : (pairs == 2 ? 2 : 4);
   const int gy = (pairs * p.split + 3) / 4;
   const int gx = (int)(mdf_conv3d_wgrad_workspace(B, Ds, Hs, Ws, A, Bc) / ((long long)A * Bc * 27));
-  if (A == 1 && Bc <= 16 && stride == 1)
+  int gx_used = gx;
+  int rc_lds = MDF_EUNSUPPORTED;
+  if (A == 1 && Bc <= 16 && stride == 1) {
     hipLaunchKernelGGL(wgrad_a1_kernel, dim3(gx, 1, 3), dim3(256), 0, (hipStream_t)stream, p);
-  else
-    hipLaunchKernelGGL(wgrad_kernel, dim3(gx, gy, 3), dim3(256), 0, (hipStream_t)stream, p);
+  } else {
+    if (wgrad_use_lds()) {
+      gx_used = gx;
+      rc_lds = mdf_wgrad_lds_dispatch(small_, big, workspace, &gx_used, B, Ds, Hs, Ws, A, Bc, stride, 3, 1, stream);
+      if (rc_lds != MDF_OK && rc_lds != MDF_EUNSUPPORTED) return rc_lds;
+    }
+    if (rc_lds == MDF_EUNSUPPORTED) {
+      gx_used = gx;
+      hipLaunchKernelGGL(wgrad_kernel, dim3(gx, gy, 3), dim3(256), 0, (hipStream_t)stream, p);
+    }
+  }
   if (int rc = mdf::check_launch("wgrad_kernel")) return rc;
   const int n = A * Bc * 27;
   if (!accumulate) (void)hipMemsetAsync(dw, 0, (size_t)n * sizeof(float), (hipStream_t)stream);
-  int gys = gx / 8;                       // >= 8 slabs per partial sum
+  int gys = gx_used / 8;                  // >= 8 slabs per partial sum
   if (gys < 1) gys = 1;
   if (gys > 32) gys = 32;
-  hipLaunchKernelGGL(slab_sum_kernel, dim3((n + 255) / 256, gys), dim3(256), 0, (hipStream_t)stream, workspace, gx, n, dw);
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((n + 255) / 256, gys), dim3(256), 0, (hipStream_t)stream, workspace, gx_used, n, dw);
   return mdf::check_launch("slab_sum_kernel");
 }
 
@@ -333,6 +444,8 @@ static long long wgrad2d_grid(int B, int Hs, int Ws, int A, int Bc, int ksize, i
   const int gy = (pairs * split + 3) / 4;
   long long g = 2048 / (ksize * gy);
   if (g > items / split) g = items / split;
+  const long long slab_cap = (8ll << 20) / ((long long)A * Bc * ksize * ksize * 4);
+  if (g > slab_cap && slab_cap >= 16 && items / slab_cap <= 8) g = slab_cap;
   if (g < 1) g = 1;
   if (split_out) *split_out = split;
   if (gy_out) *gy_out = gy;
@@ -351,6 +464,8 @@ extern "C" int mdf_conv2d_wgrad(const float* small_, const float* big, float* dw
   MDF_REQUIRE(stride == 1 || stride == 2, "stride must be 1 or 2");
   MDF_REQUIRE(ksize == 1 || ksize == 3 || ksize == 5, "ksize=%d not in {1,3,5}", ksize);
   MDF_REQUIRE(A >= 1 && A <= 64 && Bc >= 1 && Bc <= 64, "channel counts out of range (A=%d, B=%d)", A, Bc);
+  MDF_REQUIRE((long long)B * Hs * Ws * A * 4 < (1ll << 32) && (long long)B * Hs * Ws * stride * stride * Bc * 4 < (1ll << 32),
+              "operand maps must fit 32-bit byte offsets");
   Wgrad2dParams p{};
   p.small_ = small_; p.big = big; p.slab = workspace;
   p.B = B; p.Hs = Hs; p.Ws = Ws; p.Hb = Hs * stride; p.Wb = Ws * stride; p.A = A; p.Bc = Bc; p.stride = stride;
@@ -361,15 +476,24 @@ extern "C" int mdf_conv2d_wgrad(const float* small_, const float* big, float* dw
   const int gx = (int)wgrad2d_grid(B, Hs, Ws, A, Bc, ksize, &p.split, &gy);
   const dim3 grid(gx, gy, ksize);
   hipStream_t st = (hipStream_t)stream;
-  if (ksize == 1) hipLaunchKernelGGL(wgrad2d_kernel<1>, grid, dim3(256), 0, st, p);
-  else if (ksize == 3) hipLaunchKernelGGL(wgrad2d_kernel<3>, grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(wgrad2d_kernel<5>, grid, dim3(256), 0, st, p);
-  if (int rc = mdf::check_launch("wgrad2d_kernel")) return rc;
+  int gx_used = gx, rc_lds = MDF_EUNSUPPORTED;
+  if (wgrad_use_lds()) {
+    gx_used = gx;
+    rc_lds = mdf_wgrad_lds_dispatch(small_, big, workspace, &gx_used, B, 1, Hs, Ws, A, Bc, stride, ksize, 0, stream);
+    if (rc_lds != MDF_OK && rc_lds != MDF_EUNSUPPORTED) return rc_lds;
+  }
+  if (rc_lds == MDF_EUNSUPPORTED) {
+    gx_used = gx;
+    if (ksize == 1) hipLaunchKernelGGL(wgrad2d_kernel<1>, grid, dim3(256), 0, st, p);
+    else if (ksize == 3) hipLaunchKernelGGL(wgrad2d_kernel<3>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(wgrad2d_kernel<5>, grid, dim3(256), 0, st, p);
+    if (int rc = mdf::check_launch("wgrad2d_kernel")) return rc;
+  }
   const int n = A * Bc * ksize * ksize;
   if (!accumulate) (void)hipMemsetAsync(dw, 0, (size_t)n * sizeof(float), st);
-  int gys = gx / 8;
+  int gys = gx_used / 8;
   if (gys < 1) gys = 1;
   if (gys > 32) gys = 32;
-  hipLaunchKernelGGL(slab_sum_kernel, dim3((n + 255) / 256, gys), dim3(256), 0, st, workspace, gx, n, dw);
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((n + 255) / 256, gys), dim3(256), 0, st, workspace, gx_used, n, dw);
   return mdf::check_launch("slab_sum_kernel");
 }

@@ -1,0 +1,266 @@
+// LDS-staged weight-gradient kernels (the fast path of mdf_conv3d_wgrad / mdf_conv2d_wgrad, wgrad.hip).
+//
+// Why: the first kernels fed every MFMA operand with one `global_load_dword` per lane.  The texture-address unit retires
+// 4 lanes per clock whatever the width, so a 64-lane dword load costs the CU 16 clocks -- and 1.1-1.3 such loads are needed
+// per MFMA (8 CU-clocks): PMC showed the kernels TA-issue-bound at 8-40 TFLOP/s, with every `big` element fetched once per
+// tap (9-27 times).  Here a block copies a 64-voxel row segment of `small` and the (KH rows x (64*s + KW - 1) voxels) patch
+// of `big` into LDS with 16-byte loads (each element once per tile, out-of-range voxels zero-filled, next tile's loads in
+// flight in registers during the MFMAs), and the waves take their operands from LDS with `ds_read_b32` (2 LDS clocks per
+// 64-lane read).  Voxel strides in LDS are padded so that the two 16-lane groups of a 32-lane half hit disjoint banks.
+//
+//     dw[a][b][z][kh][kw] (+)= sum_o small[o][a] * big[s*o + tap - pad][b]       z = blockIdx.z (kd in 3-D, kh in 2-D)
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct WgradLdsParams {
+  const float* small_;   // rows of Ws voxels x A channels
+  const float* big;      // rows of Wb voxels x Bc channels
+  float* slab;           // [gridDim.x][A][Bc][ntaps_total]
+  int B, Ds, Hs, Ws, Db, Hb, Wb, A, Bc, stride;
+  int AS, BS;            // padded voxel strides in LDS (floats)
+  int wtiles;            // ceil(Ws/64)
+  long long n_tiles;     // rows * wtiles
+  int NB, split;
+  int ntaps_total;       // 27 (3-D) or KS*KS (2-D)
+  int pad;               // spatial padding of the taps inside a row (and of the z tap)
+  int tv;                // voxels of `small` per tile along w: 64, or 256 for few-channel layers (more MFMAs per barrier)
+};
+
+// copy `nvox` voxels x C channels from a global row (voxel x0 ..; zero outside [0, W)) into LDS with voxel stride CS
+template <typename F>
+__device__ __forceinline__ void for_each_piece(int nvox, int C, F&& f) {
+  const int c4n = C >> 2;                       // float4 pieces per voxel (C % 4 == 0)
+  const int total = nvox * c4n;
+  for (int i = threadIdx.x; i < total; i += 256) f(i / c4n, i % c4n, i);
+}
+
+// KH kernel rows x KW taps per block; MODE3D: z = kd and the rows are the 3 kh rows of depth plane od*s+kd-1;
+// otherwise (2-D): z = kh, one row.
+template <int KH, int KW, bool MODE3D>
+__global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int s = p.stride;
+  const int WB = p.tv * s + KW - 1;              // voxels of `big` per staged row
+  float* sm_small = lds;                         // [tv][AS]
+  float* sm_big = lds + p.tv * p.AS;             // [KH][WB][BS]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, c16 = lane & 15;
+  const int pairs_per_block = 4 / p.split;
+  const int pair = blockIdx.y * pairs_per_block + wave / p.split;
+  const int part = wave % p.split;
+  const int na = pair / p.NB, nb = pair % p.NB;
+  const int a = na * 16 + c16, bcol = nb * 16 + c16;
+  const bool b_ok = bcol < p.Bc;
+  const int ac = min(a, p.A - 1), bc = min(bcol, p.Bc - 1);   // clamped lanes feed tile rows / columns that are never stored
+  const int z = blockIdx.z;
+
+  f32x4 acc[KH * KW];
+#pragma unroll
+  for (int t = 0; t < KH * KW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Register staging of the next tile in 16-byte pieces.  A row segment is CONTIGUOUS in memory (NHWC / NDHWC), so piece i of a
+  // row is `row4[first + i]`: no per-piece index arithmetic beyond a bound check; its LDS slot (voxel i >> log2(C/4), channel
+  // quad i & (C/4 - 1), padded voxel stride) does not depend on the tile and is computed once.
+  constexpr int NS = 4;                          // small: 64 * A/4 <= 1024 pieces
+  constexpr int NPR = MODE3D ? 4 : 5;            // big: pieces per staged row and thread (host checks WB * Bc/4 <= 256 * NPR)
+  float4 st_small[NS], st_big[KH][NPR];
+  const int c4a = p.A >> 2, c4b = p.Bc >> 2;
+  const int la2 = 31 - __clz(c4a), lb2 = 31 - __clz(c4b);
+  const int small_pieces = p.tv * c4a, row_pieces = WB * c4b;
+  int lds_small[NS], lds_big[NPR];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) { const int i = threadIdx.x + 256 * k; lds_small[k] = (i >> la2) * p.AS + 4 * (i & (c4a - 1)); }
+#pragma unroll
+  for (int k = 0; k < NPR; ++k) { const int i = threadIdx.x + 256 * k; lds_big[k] = (i >> lb2) * p.BS + 4 * (i & (c4b - 1)); }
+
+  auto decode = [&](long long tile, int& n, int& od, int& oh, int& ow0) {
+    const int wt = (int)(tile % p.wtiles);
+    long long r = tile / p.wtiles;
+    oh = (int)(r % p.Hs); r /= p.Hs;
+    od = (int)(r % p.Ds);
+    n = (int)(r / p.Ds);
+    ow0 = wt * p.tv;
+  };
+  auto stage = [&](long long tile) {          // global -> registers (zero for out-of-range voxels / rows)
+    int n, od, oh, ow0;
+    decode(tile, n, od, oh, ow0);             // wave-uniform (scalar unit)
+    const float4* srow = reinterpret_cast<const float4*>(p.small_) + ((((long long)n * p.Ds + od) * p.Hs + oh) * p.Ws + ow0) * c4a;
+    const int s_hi = min(p.tv, p.Ws - ow0) * c4a;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      st_small[k] = (i < s_hi) ? srow[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int id = MODE3D ? od * s + z - p.pad : 0;
+    const int v_first = ow0 * s - p.pad;                                  // big voxel of staged slot 0
+    const int b_lo = max(0, -v_first) * c4b, b_hi = min(WB, p.Wb - v_first) * c4b;
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh) {
+      const int ih = MODE3D ? oh * s + kh - p.pad : oh * s + z - p.pad;
+      const bool row_ok = (!MODE3D || (id >= 0 && id < p.Db)) && ih >= 0 && ih < p.Hb;      // wave-uniform
+      const long long row = MODE3D ? (((long long)n * p.Db + id) * p.Hb + ih) : ((long long)n * p.Hb + ih);
+      const float4* brow = reinterpret_cast<const float4*>(p.big) + (row * p.Wb + v_first) * c4b;
+#pragma unroll
+      for (int k = 0; k < NPR; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        st_big[kh][k] = (row_ok && i >= b_lo && i < b_hi) ? brow[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  auto commit = [&]() {                        // registers -> LDS
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+      if (threadIdx.x + 256 * k < small_pieces) *reinterpret_cast<float4*>(sm_small + lds_small[k]) = st_small[k];
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+      for (int k = 0; k < NPR; ++k)
+        if (threadIdx.x + 256 * k < row_pieces) *reinterpret_cast<float4*>(sm_big + kh * WB * p.BS + lds_big[k]) = st_big[kh][k];
+  };
+
+  // chunks of the tile this wave multiplies: the `split` waves that share a pair take every split-th chunk
+  const int nchunk = (p.tv / 16) / p.split;
+  const float* la = sm_small + q * p.AS + ac;
+  const float* lb = sm_big + q * s * p.BS + bc;
+
+  long long tile = blockIdx.x;
+  if (tile < p.n_tiles) stage(tile);
+  while (tile < p.n_tiles) {
+    commit();
+    __syncthreads();
+    const long long next = tile + gridDim.x;
+    if (next < p.n_tiles) stage(next);         // in flight during the MFMAs below
+    for (int cq = 0; cq < nchunk; ++cq) {
+      const int v0 = (part + cq * p.split) * 16;   // first voxel of the chunk inside the tile
+      float af[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) af[j] = la[(v0 + 4 * j) * p.AS];
+#pragma unroll
+      for (int kh = 0; kh < KH; ++kh) {
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) {
+          float bf[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bf[j] = lb[(kh * WB + (v0 + 4 * j) * s + kw) * p.BS];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[kh * KW + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[j], acc[kh * KW + kw], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();                            // everybody is done with this tile's LDS image
+    tile = next;
+  }
+
+  // partial tiles of the `split` waves that share a pair: summed through LDS (the staging area is free now)
+  float* mine = lds + (wave / p.split) * (KH * KW * 4 * 64);
+  for (int turn = 1; turn < p.split; ++turn) {
+    if (part == turn) {
+#pragma unroll
+      for (int t = 0; t < KH * KW; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mine[(t * 4 + i) * 64 + lane] = acc[t][i];
+    }
+    __syncthreads();
+    if (part == 0) {
+#pragma unroll
+      for (int t = 0; t < KH * KW; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] += mine[(t * 4 + i) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  if (part == 0 && b_ok) {
+    float* out = p.slab + (long long)blockIdx.x * p.A * p.Bc * p.ntaps_total;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = na * 16 + 4 * q + i;
+      if (row < p.A) {
+        float* o = out + ((long long)row * p.Bc + bcol) * p.ntaps_total + z * (KH * KW);
+#pragma unroll
+        for (int t = 0; t < KH * KW; ++t) o[t] = acc[t][i];
+      }
+    }
+  }
+}
+
+// voxel stride (floats) such that q and q+1 (voxels `step` apart) land 16 banks apart: stride*step = 16 (mod 32)
+int padded_stride(int C, int step) {
+  if (C <= 8) return C;                         // 8 (or 4) valid lanes per voxel: q groups cannot collide within 32 banks
+  for (int S = C; S < C + 32; S += 4)
+    if (((S * step) & 31) == 16) return S;
+  return C + 4;
+}
+
+}  // namespace
+
+// returns MDF_EUNSUPPORTED when the shape has no LDS instantiation (the caller falls back to the direct kernels)
+int mdf_wgrad_lds_dispatch(const float* small_, const float* big, float* workspace, int* gx_io, int B, int Ds, int Hs, int Ws, int A, int Bc,
+                           int stride, int ksize, int is3d, void* stream) {
+  if ((A & 3) || (Bc & 3)) return MDF_EUNSUPPORTED;
+  WgradLdsParams p{};
+  p.small_ = small_; p.big = big; p.slab = workspace;
+  p.B = B; p.Ds = Ds; p.Hs = Hs; p.Ws = Ws; p.Db = Ds * stride; p.Hb = Hs * stride; p.Wb = Ws * stride; p.A = A; p.Bc = Bc; p.stride = stride;
+  if (!is3d) { p.Ds = 1; p.Db = 1; }
+  p.pad = (ksize - 1) / 2;
+  p.AS = padded_stride(A, 1);
+  p.BS = padded_stride(Bc, stride);
+  const int NA = (A + 15) / 16;
+  p.NB = (Bc + 15) / 16;
+  const int pairs = NA * p.NB;
+  p.split = pairs >= 4 ? 1 : (pairs == 2 ? 2 : 4);
+  const int gy = (pairs * p.split + 3) / 4;
+  const int KH = is3d ? 3 : 1, KW = ksize;
+  p.ntaps_total = is3d ? 27 : ksize * ksize;
+  // tile width along w: a multiple of 16*split voxels, as wide as the register staging and ~64 KiB of LDS allow (more MFMAs per
+  // barrier pair), chosen to waste the fewest voxels of the row's last tile
+  const int npr = is3d ? 4 : 5;
+  int best_tv = 0;
+  long long best_cost = 0;
+  size_t best_lds = 0;
+  for (int tv = 16 * p.split; tv <= 256; tv += 16 * p.split) {
+    const int WB = tv * stride + KW - 1;
+    if (tv * (A / 4) > 4 * 256 || WB * (Bc / 4) > npr * 256) break;            // register staging capacity
+    const size_t lds = (size_t)(tv * p.AS + KH * WB * p.BS) * sizeof(float);
+    if (lds > 72 * 1024) break;
+    const long long cost = (long long)((Ws + tv - 1) / tv) * (tv + 24);          // + ~24 voxel-times of fixed cost per tile
+    if (best_tv == 0 || cost <= best_cost) { best_tv = tv; best_cost = cost; best_lds = lds; }
+  }
+  if (best_tv == 0) return MDF_EUNSUPPORTED;
+  p.tv = best_tv;
+  p.wtiles = (Ws + p.tv - 1) / p.tv;
+  p.n_tiles = (long long)B * p.Ds * Hs * p.wtiles;
+  size_t lds = best_lds;
+  const size_t red = (size_t)2 * KH * KW * 4 * 64 * sizeof(float);
+  if (lds < red) lds = red;
+  if (lds > 150 * 1024) return MDF_EUNSUPPORTED;
+  int gx = *gx_io;                               // in: slabs the workspace holds; out: blocks launched (= slabs written)
+  if (gx > p.n_tiles) gx = (int)p.n_tiles;
+  if (gx < 1) gx = 1;
+  *gx_io = gx;
+  const dim3 grid(gx, gy, is3d ? 3 : ksize);
+  hipStream_t st = (hipStream_t)stream;
+#define WG_LAUNCH(KHv, KWv, M3)                                                                                            \
+  {                                                                                                                        \
+    static bool attr_done[64] = {};                                                                                        \
+    int dev_id = 0;                                                                                                        \
+    (void)hipGetDevice(&dev_id);                                                                                           \
+    if (dev_id < 0 || dev_id >= 64 || !attr_done[dev_id]) {                                                                \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lds_kernel<KHv, KWv, M3>),                   \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);                          \
+      if (e != hipSuccess) return mdf::fail(MDF_EHIP, "hipFuncSetAttribute(dynamic LDS): %s", hipGetErrorString(e));       \
+      if (dev_id >= 0 && dev_id < 64) attr_done[dev_id] = true;                                                            \
+    }                                                                                                                      \
+    hipLaunchKernelGGL((wgrad_lds_kernel<KHv, KWv, M3>), grid, dim3(256), lds, st, p);                                      \
+    return mdf::check_launch("wgrad_lds_kernel");                                                                          \
+  }
+  if (is3d && ksize == 3) WG_LAUNCH(3, 3, true)
+  if (!is3d && ksize == 3) WG_LAUNCH(1, 3, false)
+  if (!is3d && ksize == 5) WG_LAUNCH(1, 5, false)
+  if (!is3d && ksize == 1) WG_LAUNCH(1, 1, false)
+#undef WG_LAUNCH
+  return MDF_EUNSUPPORTED;
+}
