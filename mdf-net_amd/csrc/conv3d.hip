@@ -51,6 +51,7 @@ struct Frag<4> {
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
   }
   __device__ __forceinline__ void zero() { v[0] = v[1] = v[2] = v[3] = 0.f; }
+  __device__ __forceinline__ void scale(float m) { v[0] *= m; v[1] *= m; v[2] *= m; v[3] *= m; }
 };
 template <>
 struct Frag<2> {
@@ -60,6 +61,7 @@ struct Frag<2> {
     v[0] = t.x; v[1] = t.y;
   }
   __device__ __forceinline__ void zero() { v[0] = v[1] = 0.f; }
+  __device__ __forceinline__ void scale(float m) { v[0] *= m; v[1] *= m; }
 };
 
 // SPLITK = 4: the four waves of a block share ONE wave tile and each takes every 4th tap; partial accumulators are summed
@@ -192,8 +194,12 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
       Frag<KPL> bf[MT];
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
-        if ((vmask[t] & need) == need) bf[t].load(xq + in_off[t] + tapoff + ch * CK);
-        else bf[t].zero();
+        // branch-free: an out-of-range tap reads the voxel's own (valid) position and is zeroed by a multiply.  A predicated
+        // load compiles to a branch and a wait per load (s_and_saveexec / s_cbranch_execz), which serialises the fetches of
+        // a tap step; a select instead of the multiply lets the compiler sink the load back under the condition.
+        const bool ok = (vmask[t] & need) == need;
+        bf[t].load(xq + in_off[t] + (ok ? tapoff : 0) + ch * CK);
+        bf[t].scale(ok ? 1.0f : 0.0f);
       }
       Frag<KPL> af[NT];
 #pragma unroll

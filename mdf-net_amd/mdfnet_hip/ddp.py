@@ -24,11 +24,24 @@ class FlatBucket:
             off += p.numel()
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self._pad = self._recv = None
+        self._view_list = list(self._views())
 
     def zero_grad(self):
-        self.flat.zero_()
-        for p, g in zip(self.params, self._views()):   # optimizers may have replaced .grad (set_to_none)
-            p.grad = g
+        """Gradients are GATHERED into the bucket after the backward pass (one batched copy) instead of being accumulated into
+        pre-assigned views: with .grad = None autograd simply hands over each gradient tensor -- no zero fill and no
+        158 tiny `grad += new` launches per step (0.7 ms of GPU time and ~1.5 ms of issue time at cfg3)."""
+        for p in self.params:
+            p.grad = None
+
+    def gather(self):
+        """Copy the parameters' gradients into the flat buffer (parameters without a gradient contribute zeros) and make
+        every .grad a view into it, which is what the optimizer then consumes."""
+        grads = [p.grad for p in self.params]
+        if any(g is None for g in grads) or any(g.data_ptr() != v.data_ptr() for g, v in zip(grads, self._view_list)):
+            pieces = [(torch.zeros_like(p).reshape(-1) if g is None else g.detach().reshape(-1).to(torch.float32)) for p, g in zip(self.params, grads)]
+            torch.cat(pieces, out=self.flat)
+            for p, v in zip(self.params, self._view_list):
+                p.grad = v
 
     def _views(self):
         off = 0
@@ -61,6 +74,7 @@ class FlatBucket:
         node -- every rank sends shard j of its 4.83-MB buffer straight to rank j (all-to-all: all 7 links busy at once, 0.6 MB
         per link), sums the shards it owns, and the owners' sums are all-gathered: 2 latency steps instead of the 14 of a ring.
         Same result up to summation order (asserted in tests/test_train_cpu.py); unmeasured on hardware, hence not the default."""
+        self.gather()
         if self.world <= 1:
             return
         mode = mode or os.environ.get("MDF_GRAD_EXCHANGE", "allreduce")
