@@ -82,8 +82,13 @@ __global__ __launch_bounds__(256) void consistency_fuse_kernel(const FuseParams 
     const int xa = (int)fminf(fmaxf(x0f, 0.f), mw), xb = (int)fminf(fmaxf(x1f, 0.f), mw);
     const int ya = (int)fminf(fmaxf(y0f, 0.f), mh), yb = (int)fminf(fmaxf(y1f, 0.f), mh);
     const float* ds = p.src[v];
-    const float t_nw = (bx0 && by0) ? ds[ya * p.w + xa] : 0.f, t_ne = (bx1 && by0) ? ds[ya * p.w + xb] : 0.f;
-    const float t_sw = (bx0 && by1) ? ds[yb * p.w + xa] : 0.f, t_se = (bx1 && by1) ? ds[yb * p.w + xb] : 0.f;
+    // the four taps are loaded unconditionally (the corners are clamped into the map) and out-of-bounds ones replaced by 0
+    // afterwards; the empty asm pins the loads -- with a bare select the compiler sinks each load under its condition, i.e.
+    // four branch + wait pairs per view in a dependent chain
+    float l_nw = ds[ya * p.w + xa], l_ne = ds[ya * p.w + xb], l_sw = ds[yb * p.w + xa], l_se = ds[yb * p.w + xb];
+    asm volatile("" : "+v"(l_nw), "+v"(l_ne), "+v"(l_sw), "+v"(l_se));
+    const float t_nw = (bx0 && by0) ? l_nw : 0.f, t_ne = (bx1 && by0) ? l_ne : 0.f;
+    const float t_sw = (bx0 && by1) ? l_sw : 0.f, t_se = (bx1 && by1) ? l_se : 0.f;
     const float samp = __fmaf_rn(t_se, __fmul_rn(fn, fw), __fmaf_rn(t_sw, __fmul_rn(fn, fe),
                        __fmaf_rn(t_ne, __fmul_rn(fs, fw), __fmul_rn(t_nw, __fmul_rn(fs, fe)))));
     // back to the reference view with the SAMPLED source depth                  (:226-236)

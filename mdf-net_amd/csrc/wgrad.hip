@@ -373,6 +373,12 @@ __global__ void slab_sum_kernel(const float* __restrict__ slab, int nslab, int n
 
 int mdf_wgrad_lds_dispatch(const float* small_, const float* big, float* workspace, int* gx_io, int B, int Ds, int Hs, int Ws, int A, int Bc,
                            int stride, int ksize, int is3d, void* stream);
+// blocks per launch: every block writes one partial tile set to the slab (PMC: 2 GB written + 2 GB re-read per cfg3 step at
+// 2048 blocks), so no more blocks than it takes to fill the chip a few times over
+static int wgrad_target_blocks() {
+  static const int n = [] { const char* e = getenv("MDF_WGRAD_BLOCKS"); return (e && atoi(e) > 0) ? atoi(e) : 1024; }();
+  return n;
+}
 static bool wgrad_use_lds() {
   static const bool on = [] { const char* e = getenv("MDF_WGRAD_LDS"); return e ? atoi(e) != 0 : true; }();   // dev A/B
   return on;
@@ -385,7 +391,7 @@ extern "C" int64_t mdf_conv3d_wgrad_workspace(int B, int Ds, int Hs, int Ws, int
   const int split = pairs >= 4 ? 1 : (pairs == 2 ? 2 : 4);
   const int gy = (pairs * split + 3) / 4;
   // enough blocks to fill the chip several times over (3 depth taps x gy pair groups x g), at least `split` chunks each
-  long long g = 2048 / (3 * gy);
+  long long g = wgrad_target_blocks() / (3 * gy);
   if (g > items / split) g = items / split;
   const long long slab_cap = (8ll << 20) / ((long long)A * Bc * 27 * 4);   // <= 8 MiB of partial tiles: the slab is written and read once
   if (g > slab_cap && slab_cap >= 16 && items / slab_cap <= 8) g = slab_cap;   // tiny volumes only: there the slab round trip dominates
@@ -442,7 +448,7 @@ static long long wgrad2d_grid(int B, int Hs, int Ws, int A, int Bc, int ksize, i
   const int pairs = ((A + 15) / 16) * ((Bc + 15) / 16);
   const int split = pairs >= 4 ? 1 : (pairs == 2 ? 2 : 4);
   const int gy = (pairs * split + 3) / 4;
-  long long g = 2048 / (ksize * gy);
+  long long g = wgrad_target_blocks() / (ksize * gy);
   if (g > items / split) g = items / split;
   const long long slab_cap = (8ll << 20) / ((long long)A * Bc * ksize * ksize * 4);
   if (g > slab_cap && slab_cap >= 16 && items / slab_cap <= 8) g = slab_cap;

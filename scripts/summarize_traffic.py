@@ -8,6 +8,14 @@ fetch_dir, write_dir, forwards, out = sys.argv[1], sys.argv[2], int(sys.argv[3])
 
 
 def family(name):
+    if "wgrad" in name or "slab_sum" in name:
+        return "wgrad"
+    if "warp_bwd_kernel" in name:
+        return "aggregate_scatter"
+    if "warp_train_kernel" in name:
+        return "aggregate_train_passes"
+    if "bn_" in name:
+        return "batchnorm_train"
     if "conv_lds_kernel" in name or "conv3d_kernel" in name:
         return "mfma_conv"
     if "warp_kernel" in name:
