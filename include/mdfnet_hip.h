@@ -194,6 +194,11 @@ int mdf_bn_finalize_fwd(const double* sums, const float* gamma, const float* bet
                         long long* num_batches_tracked, void* stream);
 int mdf_bn_relu_apply_fwd(const float* y, const float* aux, const float* res, float* z, long long N, int C, int ngroups,
                           void* stream);
+/* finalize + apply as one launch (what the training path uses): z = [res +] relu(y*a + b) with (a, b) derived from `sums` in
+ * the kernel; aux [ngroups][4C] is written for the backward pass, the running statistics are updated as by finalize.   */
+int mdf_bn_finalize_apply_fwd(const float* y, const double* sums, const float* gamma, const float* beta, float eps, float momentum,
+                              const float* res, float* z, float* aux, float* running_mean, float* running_var,
+                              long long* num_batches_tracked, long long N, int C, int ngroups, void* stream);
 int mdf_bn_relu_bwd_reduce(const float* dz, const float* y, const float* aux, long long N, int C, int ngroups, double* red,
                            void* stream);
 int mdf_bn_relu_bwd(const float* dz, const float* y, const float* aux, const double* red, const float* gamma, long long N,

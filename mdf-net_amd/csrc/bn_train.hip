@@ -118,6 +118,63 @@ __global__ __launch_bounds__(kT) void bn_relu_apply_kernel(const float* __restri
   }
 }
 
+// finalize + apply in one launch: every block derives (a, b) of its 4 channels from the statistics itself (a few fp64
+// operations), block 0 of each group also publishes aux for the backward pass, block (0,0) updates the running statistics
+// of all groups in call order.
+__global__ __launch_bounds__(kT) void bn_finalize_apply_kernel(const float* __restrict__ y, const double* __restrict__ sums,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                               float momentum, double n, const float* __restrict__ res,
+                                                               float* __restrict__ z, float* __restrict__ aux,
+                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                               long long* __restrict__ nbt, long long n4, int C, int ngroups) {
+  const int tid = threadIdx.x, g = blockIdx.y;
+  const int c0 = (4 * tid) % C;
+  const double* s = sums + (long long)g * 2 * C;
+  float a[4], b[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double mean = s[c0 + k] / n;
+    double var = s[C + c0 + k] / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    a[k] = gamma[c0 + k] * invstd;
+    b[k] = beta[c0 + k] - (float)mean * a[k];
+    if (blockIdx.x == 0 && 4 * tid < C) {      // threads 0..C/4-1 cover every channel once
+      float* a4 = aux + (long long)g * 4 * C;
+      a4[c0 + k] = a[k]; a4[C + c0 + k] = b[k]; a4[2 * C + c0 + k] = (float)mean; a4[3 * C + c0 + k] = invstd;
+    }
+  }
+  if (blockIdx.x == 0 && g == 0 && running_mean && tid < C) {
+    for (int gg = 0; gg < ngroups; ++gg) {      // groups = successive calls of the module
+      const double* sg = sums + (long long)gg * 2 * C;
+      const double mean = sg[tid] / n;
+      double var = sg[C + tid] / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const double unb = (n > 1.0) ? var * n / (n - 1.0) : var;
+      running_mean[tid] = (1.0f - momentum) * running_mean[tid] + momentum * (float)mean;
+      running_var[tid] = (1.0f - momentum) * running_var[tid] + momentum * (float)unb;
+    }
+    if (tid == 0 && nbt) *nbt += ngroups;
+  }
+  y += (long long)g * n4 * 4;
+  z += (long long)g * n4 * 4;
+  if (res) res += (long long)g * n4 * 4;
+  const long long stride = (long long)gridDim.x * kT;
+  for (long long i = (long long)blockIdx.x * kT + tid; i < n4; i += stride) {
+    const float4 v = reinterpret_cast<const float4*>(y)[i];
+    float4 o;
+    o.x = fmaxf(fmaf(v.x, a[0], b[0]), 0.0f);
+    o.y = fmaxf(fmaf(v.y, a[1], b[1]), 0.0f);
+    o.z = fmaxf(fmaf(v.z, a[2], b[2]), 0.0f);
+    o.w = fmaxf(fmaf(v.w, a[3], b[3]), 0.0f);
+    if (res) {
+      const float4 r = reinterpret_cast<const float4*>(res)[i];
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    reinterpret_cast<float4*>(z)[i] = o;
+  }
+}
+
 __global__ __launch_bounds__(kT) void bn_relu_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ y,
                                                          const float* __restrict__ aux, const double* __restrict__ red,
                                                          const float* __restrict__ gamma, double inv_n, float* __restrict__ dy,
@@ -230,4 +287,16 @@ extern "C" int mdf_bn_relu_bwd(const float* dz, const float* y, const float* aux
   hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(grid_for(n4, ngroups), ngroups), dim3(kT), 0, (hipStream_t)stream, dz, y, aux, red, gamma, 1.0 / (double)N, dy,
                      dgamma, dbeta, n4, C);
   return mdf::check_launch("bn_relu_bwd_kernel");
+}
+
+extern "C" int mdf_bn_finalize_apply_fwd(const float* y, const double* sums, const float* gamma, const float* beta, float eps, float momentum,
+                                         const float* res, float* z, float* aux, float* running_mean, float* running_var,
+                                         long long* num_batches_tracked, long long N, int C, int ngroups, void* stream) {
+  if (int rc = check_bn(y, N, C)) return rc;
+  MDF_REQUIRE(sums && gamma && beta && z && aux && ngroups >= 1 && ngroups <= 65535, "bad argument");
+  MDF_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running_mean and running_var go together");
+  const long long n4 = N * C / 4;
+  hipLaunchKernelGGL(bn_finalize_apply_kernel, dim3(grid_for(n4, ngroups), ngroups), dim3(kT), 0, (hipStream_t)stream, y, sums, gamma, beta, eps,
+                     momentum, (double)N, res, z, aux, running_mean, running_var, num_batches_tracked, n4, C, ngroups);
+  return mdf::check_launch("bn_finalize_apply_kernel");
 }

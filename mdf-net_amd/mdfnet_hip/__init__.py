@@ -50,6 +50,7 @@ SIGNATURES = {
     "mdf_bn_stats_fwd": (c_int, [c_fp, c_i64, c_int, c_int, c_fp, c_fp]),
     "mdf_bn_finalize_fwd": (c_int, [c_fp, c_fp, c_fp, ctypes.c_float, ctypes.c_float, c_i64, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "mdf_bn_relu_apply_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_fp]),
+    "mdf_bn_finalize_apply_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, ctypes.c_float, ctypes.c_float, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_fp]),
     "mdf_bn_relu_bwd_reduce": (c_int, [c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_fp, c_fp]),
     "mdf_bn_relu_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_fp, c_fp, c_fp, c_fp]),
     "mdf_conv3d_wgrad_workspace": (c_i64, [c_int] * 6),

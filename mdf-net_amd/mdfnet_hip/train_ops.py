@@ -59,6 +59,20 @@ def bn_finalize(sums, bn, n, c, groups=1):
     return aux
 
 
+def bn_finalize_apply(sums, bn, y, res, n, c, groups=1):
+    """finalize + apply in one launch -> (z, aux)."""
+    aux = torch.empty(groups * 4 * c, device=y.device, dtype=torch.float32)
+    z = torch.empty_like(y)
+    track = bn.track_running_stats and bn.running_mean is not None
+    mom = BN_MOMENTUM if bn.momentum is None else bn.momentum
+    _abi("mdf_bn_finalize_apply_fwd", (y.data_ptr(), sums.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), ctypes.c_float(bn.eps),
+                                       ctypes.c_float(mom), None if res is None else res.data_ptr(), z.data_ptr(), aux.data_ptr(),
+                                       bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
+                                       bn.num_batches_tracked.data_ptr() if track else None, n, c, groups, _stream(z)),
+         tag=f"finalize+apply C{c} N{n}x{groups}", work={"bytes": 4.0 * n * c * groups * (3 if res is not None else 2), "bound": "hbm"})
+    return z, aux
+
+
 def bn_relu_apply(y, aux, res, n, c, groups=1):
     z = torch.empty_like(y)
     _abi("mdf_bn_relu_apply_fwd", (y.data_ptr(), aux.data_ptr(), None if res is None else res.data_ptr(), z.data_ptr(), n, c, groups,
@@ -163,8 +177,7 @@ class Tape:
         y = ops.conv3d_ndhwc(x, wp, conv.in_channels, conv.out_channels, stride, tr, None, None, False, None)   # raw conv
         c = conv.out_channels
         n = y.numel() // c
-        aux = bn_finalize(bn_stats(y, n, c, pool=self.pool), bn, n, c)
-        z = bn_relu_apply(y, aux, res, n, c)
+        z, aux = bn_finalize_apply(bn_stats(y, n, c, pool=self.pool), bn, y, res, n, c)
         self.layers.append((conv, bn, tr, stride, x, y, aux, res, z))
         return z
 
@@ -400,8 +413,7 @@ class Tape2D:
         y = ops.conv2d_nhwc(x, wp, conv.in_channels, conv.out_channels, k, stride, planar_in=planar_in)        # raw conv
         c = conv.out_channels
         n = y.numel() // c // self.groups
-        aux = bn_finalize(bn_stats(y, n, c, self.groups, pool=self.pool), bn, n, c, self.groups)
-        z = bn_relu_apply(y, aux, None, n, c, self.groups)
+        z, aux = bn_finalize_apply(bn_stats(y, n, c, self.groups, pool=self.pool), bn, y, None, n, c, self.groups)
         self.layers.append((conv, bn, x if x_for_wgrad is None else x_for_wgrad, y, aux, z, x_for_wgrad is not None))
         return z
 
