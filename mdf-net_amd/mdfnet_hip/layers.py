@@ -17,14 +17,6 @@ class _Folded:
     def get(self, tensors, build):
         key = tuple((t.data_ptr(), t._version, t.device.index) for t in tensors if t is not None)
         dev = next((t.device for t in tensors if t is not None and t.is_cuda), None)
-        capturing = dev is not None and torch.cuda.is_current_stream_capturing()
-        if capturing:
-            # inside a hipGraph capture the build is part of the captured sequence (it re-runs on every replay, reading the
-            # current weights); nothing is cached across the capture boundary and no event is recorded or queried
-            with torch.no_grad():
-                val = build()
-            self.key, self.val, self.ev, self.seen = None, None, None, ()
-            return val
         if key != self.key:
             with torch.no_grad():
                 self.val = build()

@@ -10,7 +10,6 @@
 PyTorch is plumbing (memory, streams, the autograd graph between the slots); no op here falls back to ATen compute.
 """
 import ctypes
-import os
 
 import torch
 
@@ -162,71 +161,6 @@ def prob_head_backward(prob, hypos, ddepth, dprob, x_feat, weight):
     return dx, dw
 
 
-# --------------------------------------------------------------------------- hipGraph capture of static launch sequences
-# A regulariser's training forward is 43 launches and its backward 84, identical every step (same shapes, same parameter
-# and buffer addresses, weights re-packed inside the sequence): captured once after a few eager steps and replayed, they cost
-# the host one call each instead of ~1.5 ms of Python + launch overhead per section.  Inputs are copied into static buffers,
-# outputs and the tape's intermediates live in the graph's memory pool.  MDF_TRAIN_GRAPHS=0 keeps everything eager; a capture
-# that fails disables itself.
-GRAPHS = bool(int(os.environ.get("MDF_TRAIN_GRAPHS", "0")))   # opt-in: see DESIGN 3.6
-GRAPH_WARMUP = 2          # eager calls with the same key before capturing
-
-
-def capturing():
-    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
-
-
-class GraphSlot:
-    """One captured section.  run(key, fn, inputs): fn(*static_inputs) -> tuple of tensors (+ side effects kept by the caller)."""
-
-    def __init__(self):
-        self.key, self.seen, self.graph, self.static_in, self.out, self.extra, self.dead = None, 0, None, None, None, None, False
-
-    def run(self, key, fn, inputs):
-        """-> (outputs, extra, replayed).  `fn` returns (outputs tuple, extra object kept alive with the graph)."""
-        if self.dead or not GRAPHS or ops._prof is not None or capturing():
-            out, extra = fn(*inputs)
-            return out, extra, False
-        if self.graph is not None and key == self.key:
-            for s, t in zip(self.static_in, inputs):
-                if s.data_ptr() != t.data_ptr():
-                    s.copy_(t)
-            self.graph.replay()
-            return self.out, self.extra, True
-        if key != self.key:
-            self.key, self.seen, self.graph = key, 0, None
-        self.seen += 1
-        if self.seen <= GRAPH_WARMUP:
-            out, extra = fn(*inputs)
-            return out, extra, False
-        try:
-            static_in = [torch.empty_like(t).copy_(t) for t in inputs]
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out, extra = fn(*static_in)
-            g.replay()                        # the capture itself does not execute
-            self.graph, self.static_in, self.out, self.extra = g, static_in, out, extra
-            return out, extra, True
-        except Exception as e:                # capture is an optimisation: never fail the step over it
-            import warnings
-            warnings.warn(f"hipGraph capture failed ({type(e).__name__}: {e}); this section stays eager")
-            self.dead, self.graph = True, None
-            torch.cuda.synchronize()
-            out, extra = fn(*inputs)
-            return out, extra, False
-
-
-def graph_slot(module, name):
-    d = module.__dict__.get("_mdf_graphs")
-    if d is None:
-        d = module.__dict__["_mdf_graphs"] = {}
-    sl = d.get(name)
-    if sl is None:
-        sl = d[name] = GraphSlot()
-    return sl
-
-
 # --------------------------------------------------------------------------- regulariser: layer tape
 class Tape:
     """Forward record of the regulariser's layer program (net/unit/regular.py: `features`), replayed backwards."""
@@ -277,61 +211,30 @@ class RegulariserTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, module, hypos, cost, *params):
-        x_in = ops.to_ndhwc(cost.detach())
-        hyp_in = _f32c(hypos.detach())
-
-        def fwd(x0, hyp):
-            tape = Tape()
-            feat = module.features(x0, tape=tape)
-            wpack = ops.pack_prob_weight(module.prob.weight)
-            prob, depth = ops.prob_head(feat, module.prob.weight, hyp, wpack=wpack)
-            return (prob, depth), (tape, x0, feat, hyp)
-        key = (tuple(x_in.shape), tuple(hyp_in.shape), x_in.device.index)
-        (prob, depth), (tape, x0, feat, hyp), replayed = graph_slot(module, "fwd").run(key, fwd, (x_in, hyp_in))
-        ctx.module, ctx.tape, ctx.x0, ctx.feat, ctx.params, ctx.hypos, ctx.prob = module, tape, x0, feat, params, hyp, prob
-        ctx.replayed = replayed
+        tape = Tape()
+        x0 = ops.to_ndhwc(cost.detach())
+        feat = module.features(x0, tape=tape)
+        wpack = ops.pack_prob_weight(module.prob.weight)
+        prob, depth = ops.prob_head(feat, module.prob.weight, hypos.detach(), wpack=wpack)
+        ctx.module, ctx.tape, ctx.x0, ctx.feat, ctx.params = module, tape, x0, feat, params
+        ctx.hypos = hypos.detach()
+        ctx.save_for_backward(prob)
         ctx.set_materialize_grads(False)
-        if replayed:      # fresh tensor objects over the graph's static outputs (the same storage every step)
-            return prob.view_as(prob), depth.view_as(depth)
         return prob, depth
 
     @staticmethod
     def backward(ctx, dprob, ddepth):
-        module, tape, prob = ctx.module, ctx.tape, ctx.prob
+        (prob,) = ctx.saved_tensors
+        module, tape = ctx.module, ctx.tape
         if dprob is None and ddepth is None:
             return (None,) * (3 + len(ctx.params))
-        params = ctx.params
-
-        def bwd(dd, *maybe_dp):
-            dp = maybe_dp[0] if maybe_dp else None
-            dfeat, dwp = prob_head_backward(prob, ctx.hypos, dd, dp, ctx.feat, module.prob.weight)
-            grads = {id(ctx.feat): dfeat}
-            pg = tape.backward(grads)
-            pg[module.prob.weight] = dwp
-            dcost = grads.pop(id(ctx.x0))
-            # all parameter gradients in ONE buffer: the graph's outputs are static storage, so what is handed to autograd is
-            # one clone of this buffer (split into views) instead of ~60 separately cloned tensors
-            flat = torch.cat([(pg[p_].reshape(-1) if p_ in pg else torch.zeros(p_.numel(), device=dcost.device)) for p_ in params])
-            return (dcost, flat), None
-        if ddepth is None:      # (only the probability volume was used downstream: rare, eager)
-            outs, _ = bwd(None, _f32c(dprob))
-        else:
-            inputs = (_f32c(ddepth),) + ((_f32c(dprob),) if dprob is not None else ())
-            # the backward graph reads the forward section's intermediates: it is only valid on top of a REPLAYED forward
-            # (static tape); an eager forward has a fresh tape every step
-            if ctx.replayed:
-                key = (tuple(i.shape for i in inputs), id(tape))
-                outs, _, _ = graph_slot(module, "bwd").run(key, bwd, inputs)
-            else:
-                outs, _ = bwd(*inputs)
+        dfeat, dwp = prob_head_backward(prob, ctx.hypos, ddepth, dprob, ctx.feat, module.prob.weight)
+        grads = {id(ctx.feat): dfeat}
+        pg = tape.backward(grads)
+        pg[module.prob.weight] = dwp
+        dcost = ops.from_ndhwc(grads.pop(id(ctx.x0)))
         ctx.tape = None
-        dcost, flat = outs
-        flat = flat.clone()
-        pgrads, off = [], 0
-        for p_ in params:
-            pgrads.append(flat[off:off + p_.numel()].view_as(p_))
-            off += p_.numel()
-        return (None, None, ops.from_ndhwc(dcost.view_as(dcost))) + tuple(pgrads)
+        return (None, None, dcost) + tuple(pg.get(p) for p in ctx.params)
 
 
 def regulariser_train(module, cost, hypos):
@@ -576,8 +479,6 @@ def prepack(model):
     import torch.nn as nn
     from .layers import cache_of_key
     for reg in model.Regular:
-        if graph_slot(reg, "fwd").graph is not None:
-            continue                          # captured: the packs are part of the graph
         for m in reg.modules():
             if isinstance(m, nn.ConvTranspose3d):
                 ops_pack_fwd(m, True)
