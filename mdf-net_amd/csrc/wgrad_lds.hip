@@ -3,7 +3,7 @@
 // Why: the first kernels fed every MFMA operand with one `global_load_dword` per lane.  The texture-address unit retires
 // 4 lanes per clock whatever the width, so a 64-lane dword load costs the CU 16 clocks -- and 1.1-1.3 such loads are needed
 // per MFMA (8 CU-clocks): PMC showed the kernels TA-issue-bound at 8-40 TFLOP/s, with every `big` element fetched once per
-// tap (9-27 times).  Here a block copies a 64-voxel row segment of `small` and the (KH rows x (64*s + KW - 1) voxels) patch
+// tap (9-27 times).  Here a block copies a tv-voxel row segment of `small` and the (KH rows x (tv*s + KW - 1) voxels) patch
 // of `big` into LDS with 16-byte loads (each element once per tile, out-of-range voxels zero-filled, next tile's loads in
 // flight in registers during the MFMAs), and the waves take their operands from LDS with `ds_read_b32` (2 LDS clocks per
 // 64-lane read).  Voxel strides in LDS are padded so that the two 16-lane groups of a 32-lane half hit disjoint banks.
@@ -21,21 +21,13 @@ struct WgradLdsParams {
   float* slab;           // [gridDim.x][A][Bc][ntaps_total]
   int B, Ds, Hs, Ws, Db, Hb, Wb, A, Bc, stride;
   int AS, BS;            // padded voxel strides in LDS (floats)
-  int wtiles;            // ceil(Ws/64)
+  int wtiles;            // ceil(Ws/tv)
   long long n_tiles;     // rows * wtiles
   int NB, split;
   int ntaps_total;       // 27 (3-D) or KS*KS (2-D)
   int pad;               // spatial padding of the taps inside a row (and of the z tap)
   int tv;                // voxels of `small` per tile along w: 64, or 256 for few-channel layers (more MFMAs per barrier)
 };
-
-// copy `nvox` voxels x C channels from a global row (voxel x0 ..; zero outside [0, W)) into LDS with voxel stride CS
-template <typename F>
-__device__ __forceinline__ void for_each_piece(int nvox, int C, F&& f) {
-  const int c4n = C >> 2;                       // float4 pieces per voxel (C % 4 == 0)
-  const int total = nvox * c4n;
-  for (int i = threadIdx.x; i < total; i += 256) f(i / c4n, i % c4n, i);
-}
 
 // KH kernel rows x KW taps per block; MODE3D: z = kd and the rows are the 3 kh rows of depth plane od*s+kd-1;
 // otherwise (2-D): z = kh, one row.
@@ -65,7 +57,7 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) 
   // Register staging of the next tile in 16-byte pieces.  A row segment is CONTIGUOUS in memory (NHWC / NDHWC), so piece i of a
   // row is `row4[first + i]`: no per-piece index arithmetic beyond a bound check; its LDS slot (voxel i >> log2(C/4), channel
   // quad i & (C/4 - 1), padded voxel stride) does not depend on the tile and is computed once.
-  constexpr int NS = 4;                          // small: 64 * A/4 <= 1024 pieces
+  constexpr int NS = 4;                          // small: tv * A/4 <= 1024 pieces (host-checked)
   constexpr int NPR = MODE3D ? 4 : 5;            // big: pieces per staged row and thread (host checks WB * Bc/4 <= 256 * NPR)
   float4 st_small[NS], st_big[KH][NPR];
   const int c4a = p.A >> 2, c4b = p.Bc >> 2;
