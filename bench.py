@@ -214,10 +214,21 @@ def main():
     last = {}
     pipe = InFlight(dev, args.in_flight, done=lambda tag, o: last.__setitem__("out", o))
 
+    from mdfnet_hip import hostmirror
+    cams_cpu = tuple(t.cpu() for t in inputs[1:])
+
+    def fresh_cameras():
+        """The (tiny) camera / depth-range tensors are fresh objects every step, handed over the way eval.py:run_eval hands the
+        loader's batch over: host tensors copied to the device, the host copies registered as their mirrors.  The images stay
+        resident in HBM; the control-plane work (host prelude, small H2D copies) is part of every timed step."""
+        host = tuple(t.clone() for t in cams_cpu)
+        devs = tuple(t.to(dev, non_blocking=True) for t in host)
+        for d_, h_ in zip(devs, host):
+            hostmirror.put(d_, h_)
+        return devs
+
     def one_step():
-        # images stay resident; the (tiny) camera tensors are fresh objects every step, as in a real eval loop, so the
-        # control-plane work (host prelude, small H2D copies) is part of every timed step
-        cams = (inputs[1].clone(), inputs[2].clone(), inputs[3].clone())
+        cams = fresh_cameras()
         pipe.submit(lambda c=cams: model(inputs[0], *c), keep=cams)
 
     with torch.no_grad():
@@ -242,7 +253,7 @@ def main():
             torch.cuda.synchronize()
             ts = time.perf_counter()
             for _ in range(args.steps):
-                model(inputs[0], inputs[1].clone(), inputs[2].clone(), inputs[3].clone())
+                model(inputs[0], *fresh_cameras())
             torch.cuda.synchronize()
             dt_serial = time.perf_counter() - ts
     assert torch.isfinite(out["depth"]).all()
