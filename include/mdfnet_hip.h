@@ -222,6 +222,22 @@ int mdf_conv2d_wgrad(const float* small_, const float* big, float* dw, float* wo
 /* (input gradients of these layers are mdf_conv3d_fwd with re-packed weights: a stride-1 conv with flipped taps and
  *  swapped channels, the transposed conv for a stride-2 conv and vice versa.) */
 
+/* ---- batched weight packing: every packed weight set a training step reads (forward convs and their input-gradient
+ *      convs, train.py:36-45 after optimizer.step()), written by ONE launch.  A job is one weight set in the layout of
+ *      mdf_conv3d_pack_weights (is3d = 1) / mdf_conv_pack_weights (is3d = 0), read from the parameter `src` through `mode`:
+ *        0 the parameter itself [Cout][Cin][taps]          1 input gradient of a stride-1 conv: [Cin][Cout], taps mirrored
+ *        2 input gradient of Conv2d(k5,s2,p2) as a 3x3 conv over dy with the 4 output-parity classes as channels
+ *          (aux0 = the layer's in_channels, aux1 = first row of this part; Cin = the layer's out_channels, taps = 9)
+ *        3 the `prob` conv [1][Cin][3][3][3] as 2-D conv rows per depth tap (Cout = 4, taps = 9)
+ *        4 rows reordered for the PixelShuffle(2) epilogue    5 the parameter read as [Cin][Cout][taps]
+ *      mdf_pack_job_fill writes job `index` into a HOST table of mdf_pack_job_bytes() bytes per job and returns the number
+ *      of blocks the job takes (< 0: error code); first_block = sum of the earlier jobs' blocks.  The caller uploads the
+ *      table and an int32 per-block job index once; mdf_pack_batch then re-packs everything per call.               */
+int64_t mdf_pack_job_bytes(void);
+int64_t mdf_pack_job_fill(void* jobs_host, int index, const float* src, float* dst, int is3d, int transposed, int mode,
+                          int Cin, int Cout, int ntaps, int aux0, int aux1, int first_block);
+int mdf_pack_batch(const void* jobs_dev, const int* block_job_dev, int nblocks, void* stream);
+
 /* ---- adjoint of the FPN's bilinear x2 upsampling (backbone.py:60,62; F.interpolate(scale_factor=2, "bilinear",
  *      align_corners=False)), NHWC: dcoarse [B,h,w,C] (+)= up^T(dfine [B,2h,2w,C]); C % 4 == 0.                  */
 int mdf_upsample2_bilinear_bwd(const float* dfine, float* dcoarse, int B, int h, int w, int C, int accumulate, void* stream);

@@ -265,101 +265,181 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
   }
 }
 
-// torch weights -> fragment order  wpack[tap][chunk][nt][q][n][s] = W(cout = nt*16+n, cin = chunk*CK + KPL*q + s, tap)
-__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cin_mem, int Cout,
-                                    int ntaps, int transposed) {
-  const int KPL = (Cin >= 16) ? 4 : (Cin == 8 ? 2 : 1), CK = 4 * KPL, NCH = Cin / CK, NT = (Cout + 15) / 16;
-  const int total = ntaps * NCH * NT * 64 * KPL;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    int r = i;
-    const int s = r % KPL; r /= KPL;
-    const int n = r % 16; r /= 16;
-    const int qq = r % 4; r /= 4;
-    const int nt = r % NT; r /= NT;
-    const int ch = r % NCH; r /= NCH;
-    const int tap = r;
-    const int cout = nt * 16 + n, cin = ch * CK + KPL * qq + s;
-    float v = 0.f;
-    if (cout < Cout && cin < Cin_mem)
-      v = transposed ? w[((size_t)cin * Cout + cout) * ntaps + tap] : w[((size_t)cout * Cin_mem + cin) * ntaps + tap];
-    wp[i] = v;
+// ---- weight packing ------------------------------------------------------------------------------------------------
+// Every packing reads the LOGICAL conv weight W[o][i][t] (o < Co output rows, i < Ci input channels in memory, t < T taps)
+// through WSrc, which maps it onto the parameter tensor as it sits in the module.  Mode 0 is the parameter itself; the
+// other modes are the re-indexings the training step needs every time the optimizer has changed the weights (the input-
+// gradient convs of train_ops.py), done here instead of as flip / transpose / pad / index_select launches of their own.
+enum { kSrcDirect = 0, kSrcSwapFlip = 1, kSrcK5S2Dgrad = 2, kSrcProbSlices = 3, kSrcShuffle2 = 4, kSrcSwap = 5 };
+struct WSrc {
+  const float* w;
+  int mode, Co, Ci, T, a0, a1;
+  __device__ __forceinline__ float at(int o, int i, int t) const {
+    switch (mode) {
+      case kSrcSwapFlip:    // input gradient of a stride-1 conv: parameter [Ci][Co][T], taps mirrored
+        return w[((size_t)i * Co + o) * T + (T - 1 - t)];
+      case kSrcSwap:        // parameter laid out [Ci][Co][T] (ConvTranspose3d, or a conv weight read as one)
+        return w[((size_t)i * Co + o) * T + t];
+      case kSrcK5S2Dgrad: { // input gradient of Conv2d(k5,s2,p2) [Ci][a0][5][5] as a 3x3 conv over dy: row (py*2+px)*a0 + ci is dx[ci]
+        const int of = o + a1, cls = of / a0, ci = of - cls * a0;   // at the pixels of parity (py,px); dx[2j+p] = sum_t dy[j+t-1] w[k(p,t)]
+        const int ty = t / 3, tx = t - ty * 3;
+        const int ky = (cls >> 1) ? (ty == 0 ? -1 : 5 - 2 * ty) : 4 - 2 * ty;    // p=0: (4,2,0); p=1: (-,3,1)
+        const int kx = (cls & 1) ? (tx == 0 ? -1 : 5 - 2 * tx) : 4 - 2 * tx;
+        return (ky < 0 || kx < 0) ? 0.f : w[(((size_t)i * a0 + ci) * 5 + ky) * 5 + kx];
+      }
+      case kSrcProbSlices:  // `prob` conv [1][Ci][3][3][3] as a 2-D conv with one output row per depth tap (+ a zero row)
+        return o < 3 ? w[((size_t)i * 3 + o) * 9 + t] : 0.f;
+      case kSrcShuffle2: {  // conv feeding PixelShuffle(2): row sub*Cq + oc <- channel oc*4 + sub
+        const int cq = Co >> 2, sub = o / cq, oc = o - sub * cq;
+        return w[((size_t)(oc * 4 + sub) * Ci + i) * T + t];
+      }
+      default:
+        return w[((size_t)o * Ci + i) * T + t];
+    }
   }
+};
+
+// plain: wpack[tap][chunk][nt][q][n][s] = W(cout = nt*16+n, cin = chunk*CK + KPL*q + s, tap)
+__device__ __forceinline__ int pack_plain_total(int Cin, int Cout, int ntaps) {
+  const int KPL = (Cin >= 16) ? 4 : (Cin == 8 ? 2 : 1), CK = 4 * KPL, NCH = Cin / CK, NT = (Cout + 15) / 16;
+  return ntaps * NCH * NT * 64 * KPL;
+}
+__device__ __forceinline__ float pack_plain_elem(const WSrc& src, int i, int Cin, int Cin_mem, int Cout) {
+  const int KPL = (Cin >= 16) ? 4 : (Cin == 8 ? 2 : 1), CK = 4 * KPL, NCH = Cin / CK, NT = (Cout + 15) / 16;
+  int r = i;
+  const int s = r % KPL; r /= KPL;
+  const int n = r % 16; r /= 16;
+  const int qq = r % 4; r /= 4;
+  const int nt = r % NT; r /= NT;
+  const int ch = r % NCH; r /= NCH;
+  const int tap = r;
+  const int cout = nt * 16 + n, cin = ch * CK + KPL * qq + s;
+  return (cout < Cout && cin < Cin_mem) ? src.at(cout, cin, tap) : 0.f;
 }
 
 // w-phase packing for Cout < 16 (conv_lds.hip, Cfg::RW): the conv rewritten with GEMM row r*Cout + c = channel c of output
 // phase r (RW phases along w) and KW' = KHW + RW - 1 taps along w; tap kw' of phase r is the original tap kw' - r.
 // wp[tap' = kdh*KW' + kw'][chunk][q][n][s], one n-tile.
-__global__ void pack_weights_rw_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cin_mem, int Cout, int nkdh,
-                                       int KHW, int RW) {
+__device__ __forceinline__ int pack_rw_total(int Cin, int nkdh, int KHW, int RW) {
   const int KPL = (Cin >= 16) ? 4 : (Cin == 8 ? 2 : 1), CK = 4 * KPL, NCH = Cin / CK, KW = KHW + RW - 1;
-  const int total = nkdh * KW * NCH * 64 * KPL;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    int r = i;
-    const int s = r % KPL; r /= KPL;
-    const int n = r % 16; r /= 16;
-    const int qq = r % 4; r /= 4;
-    const int ch = r % NCH; r /= NCH;
-    const int kwp = r % KW, kdh = r / KW;
-    const int phase = n / Cout, cout = n % Cout, cin = ch * CK + KPL * qq + s;
-    const int kw = kwp - phase;
-    float v = 0.f;
-    if (phase < RW && cin < Cin_mem && kw >= 0 && kw < KHW) v = w[((size_t)cout * Cin_mem + cin) * (nkdh * KHW) + kdh * KHW + kw];
-    wp[i] = v;
-  }
+  return nkdh * KW * NCH * 64 * KPL;
+}
+__device__ __forceinline__ float pack_rw_elem(const WSrc& src, int i, int Cin, int Cin_mem, int Cout, int KHW, int RW) {
+  const int KPL = (Cin >= 16) ? 4 : (Cin == 8 ? 2 : 1), CK = 4 * KPL, NCH = Cin / CK, KW = KHW + RW - 1;
+  int r = i;
+  const int s = r % KPL; r /= KPL;
+  const int n = r % 16; r /= 16;
+  const int qq = r % 4; r /= 4;
+  const int ch = r % NCH; r /= NCH;
+  const int kwp = r % KW, kdh = r / KW;
+  const int phase = n / Cout, cout = n % Cout, cin = ch * CK + KPL * qq + s;
+  const int kw = kwp - phase;
+  return (phase < RW && cin < Cin_mem && kw >= 0 && kw < KHW) ? src.at(cout, cin, kdh * KHW + kw) : 0.f;
 }
 
 // Winograd F(2x2,3x3) weights for conv_lds.hip step_wino: U[kd][a][b] = G g[kd] G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1];
 // fragments in the order the kernel walks them: [kd][chunk][ab = a*4+b][nt][lane = q*16+m][s], cout = nt*16+m, cin = chunk*16+4q+s.
-__global__ void pack_weights_wino_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int nkd) {
+__device__ __forceinline__ int pack_wino_total(int Cin, int Cout, int nkd) { return nkd * (Cin / 16) * 16 * ((Cout + 15) / 16) * 64 * 4; }
+__device__ __forceinline__ float pack_wino_elem(const WSrc& src, int i, int Cin, int Cout, int nkd) {
   const int NCH = Cin / 16, NT = (Cout + 15) / 16;
-  const int total = nkd * NCH * 16 * NT * 64 * 4;
   const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    int r = i;
-    const int s = r % 4; r /= 4;
-    const int m = r % 16; r /= 16;
-    const int qq = r % 4; r /= 4;
-    const int nt = r % NT; r /= NT;
-    const int ab = r % 16; r /= 16;
-    const int ch = r % NCH; r /= NCH;
-    const int kd = r;
-    const int a = ab >> 2, b = ab & 3;
-    const int cout = nt * 16 + m, cin = ch * 16 + 4 * qq + s;
-    float v = 0.f;
-    if (cout < Cout) {
-      const float* g = w + (((size_t)cout * Cin + cin) * nkd + kd) * 9;
-      for (int y = 0; y < 3; ++y)
-        for (int x = 0; x < 3; ++x) v += G[a][y] * G[b][x] * g[y * 3 + x];
-    }
-    wp[i] = v;
+  int r = i;
+  const int s = r % 4; r /= 4;
+  const int m = r % 16; r /= 16;
+  const int qq = r % 4; r /= 4;
+  const int nt = r % NT; r /= NT;
+  const int ab = r % 16; r /= 16;
+  const int ch = r % NCH; r /= NCH;
+  const int kd = r;
+  const int a = ab >> 2, b = ab & 3;
+  const int cout = nt * 16 + m, cin = ch * 16 + 4 * qq + s;
+  float v = 0.f;
+  if (cout < Cout) {
+    for (int y = 0; y < 3; ++y)
+      for (int x = 0; x < 3; ++x) v += G[a][y] * G[b][x] * src.at(cout, cin, kd * 9 + y * 3 + x);
   }
+  return v;
 }
-static bool wino_built(int Cin, int Cout) { return ((Cout == 16 || Cout == 32) && (Cin == 16 || Cin == 32) && Cout <= Cin) || (Cin == 16 && Cout == 8); }   // 3-D
-static bool wino2d_built(int Cin, int Cout) { return (Cin == 16 && Cout == 16) || (Cin == 32 && Cout == 32) || (Cin == 64 && Cout == 64); }
 
 // ConvTranspose3d weights [Cin][Cout][3][3][3] -> wpack[tap' = (kd*3+kh)*2+ow][chunk][nt][q][n][s] with GEMM row
 // r = nt*16+n = pw*Cout + cout and kernel tap kw(pw, ow): (0,0)->1, (1,0)->2, (1,1)->0, (0,1)-> structurally zero.
-__global__ void pack_weights_tr_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout) {
+__device__ __forceinline__ int pack_tr_total(int Cin, int Cout) {
   const int KPL = (Cin >= 16) ? 4 : 2, CK = 4 * KPL, NCH = Cin / CK, NT = (2 * Cout + 15) / 16;
-  const int total = 18 * NCH * NT * 64 * KPL;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    int r = i;
-    const int s = r % KPL; r /= KPL;
-    const int n = r % 16; r /= 16;
-    const int qq = r % 4; r /= 4;
-    const int nt = r % NT; r /= NT;
-    const int ch = r % NCH; r /= NCH;
-    const int tap = r;
-    const int kd = tap / 6, kh = (tap / 2) % 3, ow = tap & 1;
-    const int row = nt * 16 + n, cin = ch * CK + KPL * qq + s;
-    float v = 0.f;
-    if (row < 2 * Cout) {
-      const int pw = row / Cout, cout = row % Cout;
-      const int kw = (pw == 0) ? (ow == 0 ? 1 : -1) : (ow == 0 ? 2 : 0);
-      if (kw >= 0) v = w[((size_t)cin * Cout + cout) * 27 + (kd * 3 + kh) * 3 + kw];
-    }
-    wp[i] = v;
+  return 18 * NCH * NT * 64 * KPL;
+}
+__device__ __forceinline__ float pack_tr_elem(const WSrc& src, int i, int Cin, int Cout) {
+  const int KPL = (Cin >= 16) ? 4 : 2, CK = 4 * KPL, NCH = Cin / CK, NT = (2 * Cout + 15) / 16;
+  int r = i;
+  const int s = r % KPL; r /= KPL;
+  const int n = r % 16; r /= 16;
+  const int qq = r % 4; r /= 4;
+  const int nt = r % NT; r /= NT;
+  const int ch = r % NCH; r /= NCH;
+  const int tap = r;
+  const int kd = tap / 6, kh = (tap / 2) % 3, ow = tap & 1;
+  const int row = nt * 16 + n, cin = ch * CK + KPL * qq + s;
+  if (row >= 2 * Cout) return 0.f;
+  const int pw = row / Cout, cout = row % Cout;
+  const int kw = (pw == 0) ? (ow == 0 ? 1 : -1) : (ow == 0 ? 2 : 0);
+  return kw >= 0 ? src.at(cout, cin, (kd * 3 + kh) * 3 + kw) : 0.f;
+}
+
+__host__ __device__ inline int rw_of(int Cout) { return Cout == 8 ? 2 : (Cout == 4 ? 4 : 0); }   // w-phase factor of a stride-1 k3 layer (0 = none)
+__host__ __device__ inline bool wino_built(int Cin, int Cout) { return ((Cout == 16 || Cout == 32) && (Cin == 16 || Cin == 32) && Cout <= Cin) || (Cin == 16 && Cout == 8); }   // 3-D
+__host__ __device__ inline bool wino2d_built(int Cin, int Cout) { return (Cin == 16 && Cout == 16) || (Cin == 32 && Cout == 32) || (Cin == 64 && Cout == 64); }
+__host__ __device__ inline int padded_cin(int c) { return c <= 4 ? 4 : c; }
+
+// One complete packed weight set, as mdf_conv3d_pack_weights / mdf_conv_pack_weights lay it out: the plain fragments, then
+// (Cout 8 / 4, 3x3 taps) the w-phase fragments, then (where a Winograd kernel exists) the transform-domain fragments; or the
+// transposed-conv fragments alone.
+struct PackJob {
+  const float* src;
+  float* dst;
+  int mode, transposed, is3d, Cin_mem, Cout, ntaps, a0, a1;
+  int blk0, nblk;
+};
+__host__ __device__ inline void pack_segments(int is3d, int transposed, int Cin_mem, int Cout, int ntaps, long long* plain, long long* rw, long long* wino) {
+  const int Cin = padded_cin(Cin_mem);
+  const int KPL = (Cin >= 16) ? 4 : (Cin == 8 ? 2 : 1), NCH = Cin / (4 * KPL);
+  *rw = 0; *wino = 0;
+  if (transposed) {
+    const int K2 = (Cin >= 16) ? 4 : 2;
+    *plain = 18ll * (Cin / (4 * K2)) * ((2 * Cout + 15) / 16) * 64 * K2;
+    return;
   }
+  *plain = (long long)ntaps * NCH * ((Cout + 15) / 16) * 64 * KPL;
+  const bool k3 = is3d ? (ntaps == 27) : (ntaps == 9);
+  if (k3 && rw_of(Cout)) *rw = (long long)(is3d ? 9 : 3) * (3 + rw_of(Cout) - 1) * NCH * 64 * KPL;
+  if (k3 && (is3d ? wino_built(Cin_mem, Cout) : wino2d_built(Cin_mem, Cout))) *wino = (long long)(is3d ? 3 : 1) * (Cin / 16) * 16 * ((Cout + 15) / 16) * 64 * 4;
+}
+__device__ __forceinline__ void pack_job_elem(const PackJob& j, long long i) {
+  const int Cin = padded_cin(j.Cin_mem);
+  WSrc src{j.src, j.transposed ? kSrcSwap : j.mode, j.Cout, j.Cin_mem, j.ntaps, j.a0, j.a1};
+  long long plain, rw, wino;
+  pack_segments(j.is3d, j.transposed, j.Cin_mem, j.Cout, j.ntaps, &plain, &rw, &wino);
+  if (i >= plain + rw + wino) return;
+  float v;
+  if (j.transposed) v = pack_tr_elem(src, (int)i, Cin, j.Cout);
+  else if (i < plain) v = pack_plain_elem(src, (int)i, Cin, j.Cin_mem, j.Cout);
+  else if (i < plain + rw) v = pack_rw_elem(src, (int)(i - plain), Cin, j.Cin_mem, j.Cout, 3, rw_of(j.Cout));
+  else v = pack_wino_elem(src, (int)(i - plain - rw), Cin, j.Cout, j.is3d ? 3 : 1);
+  j.dst[i] = v;
+}
+
+__global__ void pack_weights_kernel(PackJob j) {
+  long long plain, rw, wino;
+  pack_segments(j.is3d, j.transposed, j.Cin_mem, j.Cout, j.ntaps, &plain, &rw, &wino);
+  const long long total = plain + rw + wino;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) pack_job_elem(j, i);
+}
+
+// every weight set of a training step in ONE launch: block -> job through a per-block table (built once, mdf_pack_plan_*)
+constexpr int kPackPerBlock = 1024;
+__global__ void pack_batch_kernel(const PackJob* __restrict__ jobs, const int* __restrict__ block_job) {
+  const PackJob j = jobs[block_job[blockIdx.x]];
+  const long long base = (long long)(blockIdx.x - j.blk0) * kPackPerBlock;
+#pragma unroll
+  for (int k = 0; k < kPackPerBlock / 256; ++k) pack_job_elem(j, base + k * 256 + threadIdx.x);
 }
 
 template <int CIN, int COUT, int MODE, int MT, int SPLITK>
@@ -386,44 +466,33 @@ int launch_conv_mt(ConvParams& p, hipStream_t st) {
 
 }  // namespace
 
-// w-phase factor of a stride-1 k3 layer (0 = none): Cout 8 -> 2 outputs per MFMA column, Cout 4 -> 4
-static int rw_of(int Cout) { return Cout == 8 ? 2 : (Cout == 4 ? 4 : 0); }
+static int64_t pack_total(int is3d, int transposed, int Cin_mem, int Cout, int ntaps) {
+  long long plain, rw, wino;
+  pack_segments(is3d, transposed, Cin_mem, Cout, ntaps, &plain, &rw, &wino);
+  return plain + rw + wino;
+}
 
 extern "C" int64_t mdf_conv3d_packed_size(int Cin, int Cout) {
   if (Cin < 8 || Cout < 1) return 0;
-  int64_t plain = (int64_t)27 * Cin * (((Cout + 15) / 16) * 16);
-  if (rw_of(Cout)) plain += (int64_t)9 * (3 + rw_of(Cout) - 1) * Cin * 16;   // + the w-phase packing behind the plain one
-  if (wino_built(Cin, Cout)) plain += (int64_t)48 * Cin * (((Cout + 15) / 16) * 16);   // + the Winograd-domain weights
-  const int64_t transposed = (int64_t)18 * Cin * (((2 * Cout + 15) / 16) * 16);
+  const int64_t plain = pack_total(1, 0, Cin, Cout, 27), transposed = pack_total(1, 1, Cin, Cout, 27);
   return plain > transposed ? plain : transposed;   // one size serves both packings
+}
+
+static int launch_pack(const PackJob& j, void* stream) {
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, j);
+  return mdf::check_launch("pack_weights_kernel");
 }
 
 extern "C" int mdf_conv3d_pack_weights(const float* w, float* wpack, int Cin, int Cout, int transposed, void* stream) {
   MDF_REQUIRE(w && wpack, "null pointer argument");
   MDF_REQUIRE(Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64, "Cin=%d not in {8,16,32,64}", Cin);
   MDF_REQUIRE(Cout >= 1 && Cout <= 64, "Cout=%d out of range", Cout);
-  if (transposed) {
-    hipLaunchKernelGGL(pack_weights_tr_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, wpack, Cin, Cout);
-  } else {
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, wpack, Cin, Cin, Cout, 27, 0);
-    if (rw_of(Cout))
-      hipLaunchKernelGGL(pack_weights_rw_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, wpack + (size_t)27 * Cin * 16, Cin, Cin, Cout, 9, 3,
-                         rw_of(Cout));
-    if (wino_built(Cin, Cout))
-      hipLaunchKernelGGL(pack_weights_wino_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w,
-                         wpack + (size_t)27 * Cin * (((Cout + 15) / 16) * 16) + (rw_of(Cout) ? (size_t)36 * Cin * 16 : 0), Cin, Cout, 3);
-  }
-  return mdf::check_launch("pack_weights_kernel");
+  return launch_pack(PackJob{w, wpack, kSrcDirect, transposed ? 1 : 0, 1, Cin, Cout, 27, 0, 0, 0, 0}, stream);
 }
-
-static int padded_cin(int c) { return c <= 4 ? 4 : c; }
 
 extern "C" int64_t mdf_conv_packed_size(int Cin_mem, int Cout, int ntaps) {
   if (Cin_mem < 1 || Cout < 1 || ntaps < 1) return 0;
-  int64_t n = (int64_t)ntaps * padded_cin(Cin_mem) * (((Cout + 15) / 16) * 16);
-  if (ntaps == 9 && rw_of(Cout)) n += (int64_t)3 * (3 + rw_of(Cout) - 1) * padded_cin(Cin_mem) * 16;   // + w-phase packing (3x3 layers)
-  if (ntaps == 9 && wino2d_built(Cin_mem, Cout)) n += (int64_t)16 * Cin_mem * (((Cout + 15) / 16) * 16);   // + Winograd-domain weights
-  return n;
+  return pack_total(0, 0, Cin_mem, Cout, ntaps);
 }
 
 extern "C" int mdf_conv_pack_weights(const float* w, float* wpack, int Cin_mem, int Cout, int ntaps, void* stream) {
@@ -431,14 +500,34 @@ extern "C" int mdf_conv_pack_weights(const float* w, float* wpack, int Cin_mem, 
   const int Cin = padded_cin(Cin_mem);
   MDF_REQUIRE(Cin == 4 || Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64, "Cin=%d not supported", Cin_mem);
   MDF_REQUIRE(Cout >= 1 && Cout <= 64 && ntaps >= 1 && ntaps <= 27, "Cout=%d ntaps=%d out of range", Cout, ntaps);
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, wpack, Cin, Cin_mem, Cout, ntaps, 0);
-  if (ntaps == 9 && rw_of(Cout))
-    hipLaunchKernelGGL(pack_weights_rw_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, wpack + (size_t)9 * Cin * 16, Cin, Cin_mem, Cout, 3, 3,
-                       rw_of(Cout));
-  if (ntaps == 9 && wino2d_built(Cin_mem, Cout))
-    hipLaunchKernelGGL(pack_weights_wino_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, wpack + (size_t)9 * Cin * (((Cout + 15) / 16) * 16),
-                       Cin, Cout, 1);
-  return mdf::check_launch("pack_weights_kernel");
+  return launch_pack(PackJob{w, wpack, kSrcDirect, 0, 0, Cin_mem, Cout, ntaps, 0, 0, 0, 0}, stream);
+}
+
+// ---- batched packing (training: every weight set the step's kernels read, re-packed after each optimizer update) ------
+extern "C" int64_t mdf_pack_job_bytes(void) { return (int64_t)sizeof(PackJob); }
+
+extern "C" int64_t mdf_pack_job_fill(void* jobs_host, int index, const float* src, float* dst, int is3d, int transposed, int mode,
+                                     int Cin_mem, int Cout, int ntaps, int aux0, int aux1, int first_block) {
+  if (!jobs_host || index < 0 || !src || !dst) { mdf::set_error("mdf_pack_job_fill: null pointer or negative index"); return MDF_EARG; }
+  const int Cin = padded_cin(Cin_mem);
+  if (!(Cin == 4 || Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64) || Cout < 1 || Cout > 64 || ntaps < 1 || ntaps > 27 ||
+      (is3d && (ntaps != 27 || Cin_mem < 8)) || (transposed && !is3d) || mode < kSrcDirect || mode > kSrcSwap ||
+      (mode == kSrcK5S2Dgrad && (ntaps != 9 || aux0 < 1 || aux1 < 0)) || (mode == kSrcProbSlices && (ntaps != 9 || Cout != 4)) ||
+      (mode == kSrcShuffle2 && Cout % 4 != 0)) {
+    mdf::set_error("mdf_pack_job_fill: unsupported job (3d=%d tr=%d mode=%d Cin=%d Cout=%d taps=%d)", is3d, transposed, mode, Cin_mem, Cout, ntaps);
+    return MDF_EARG;
+  }
+  const int64_t total = pack_total(is3d, transposed, Cin_mem, Cout, ntaps);
+  const int nblk = (int)((total + kPackPerBlock - 1) / kPackPerBlock);
+  static_cast<PackJob*>(jobs_host)[index] = PackJob{src, dst, mode, transposed ? 1 : 0, is3d ? 1 : 0, Cin_mem, Cout, ntaps, aux0, aux1, first_block, nblk};
+  return nblk;
+}
+
+extern "C" int mdf_pack_batch(const void* jobs_dev, const int* block_job_dev, int nblocks, void* stream) {
+  MDF_REQUIRE(jobs_dev && block_job_dev, "null pointer argument");
+  MDF_REQUIRE(nblocks > 0, "no blocks");
+  hipLaunchKernelGGL(pack_batch_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, static_cast<const PackJob*>(jobs_dev), block_job_dev);
+  return mdf::check_launch("pack_batch_kernel");
 }
 
 int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,

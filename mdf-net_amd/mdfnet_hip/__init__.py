@@ -57,6 +57,9 @@ SIGNATURES = {
     "mdf_conv3d_wgrad": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp]),
     "mdf_conv2d_wgrad_workspace": (c_i64, [c_int] * 6),
     "mdf_conv2d_wgrad": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp]),
+    "mdf_pack_job_bytes": (c_i64, []),
+    "mdf_pack_job_fill": (c_i64, [c_fp, c_int, c_fp, c_fp] + [c_int] * 9),
+    "mdf_pack_batch": (c_int, [c_fp, c_fp, c_int, c_fp]),
     "mdf_upsample2_bilinear_bwd": (c_int, [c_fp, c_fp] + [c_int] * 5 + [c_fp]),
     "mdf_prob_softmax_regress_bwd": (c_int, [c_fp, c_fp, c_int, c_fp, c_fp, c_fp] + [c_int] * 4 + [c_fp]),
     "mdf_prob_conv_dgrad": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 5 + [c_fp]),

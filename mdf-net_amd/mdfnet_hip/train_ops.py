@@ -214,7 +214,8 @@ class RegulariserTrainFn(torch.autograd.Function):
         tape = Tape()
         x0 = ops.to_ndhwc(cost.detach())
         feat = module.features(x0, tape=tape)
-        wpack = ops.pack_prob_weight(module.prob.weight)
+        from .layers import cache_of_key
+        wpack = cache_of_key(module.prob, "probpack").get((module.prob.weight,), lambda: ops.pack_prob_weight(module.prob.weight))
         prob, depth = ops.prob_head(feat, module.prob.weight, hypos.detach(), wpack=wpack)
         ctx.module, ctx.tape, ctx.x0, ctx.feat, ctx.params = module, tape, x0, feat, params
         ctx.hypos = hypos.detach()
@@ -375,8 +376,7 @@ def _dgrad2d_pack(conv):
     if k == 3 and stride == 1:
         return cache_of_key(conv, "dgrad").get((w,), lambda: ops.pack_conv2d_weight(w.detach().flip(2, 3).transpose(0, 1).contiguous()))
     if k == 5 and stride == 2:
-        nout = 4 * cin
-        parts = [(0, nout)] if nout <= 64 else [(0, nout // 2), (nout // 2, nout)]
+        parts = _k5s2_parts(cin)
 
         def build():
             w4 = _k5s2_dgrad_weight(w)
@@ -471,31 +471,127 @@ def trunk_train(module, imgs, groups):
     return TrunkTrainFn.apply(module, groups, imgs, *params)
 
 
-# --------------------------------------------------------------------------- weight packing off the critical path
+# --------------------------------------------------------------------------- weight packing: one launch per step
+_SRC_DIRECT, _SRC_SWAPFLIP, _SRC_K5S2, _SRC_PROB, _SRC_SHUFFLE2, _SRC_SWAP = range(6)
+
+
+class PackPlan:
+    """Every packed weight set the training kernels read (forward convs and their input-gradient convs: ~100 sets), re-packed
+    after each optimizer update by ONE launch of mdf_pack_batch instead of ~250 flip / transpose / pad / pack launches.  The
+    job table is built once per model (parameter storage does not move during training: the optimizer and load_state_dict
+    write in place); `run` re-packs when a parameter's version moved and hands the buffers to the per-layer caches
+    (layers._Folded) the layer code looks them up in."""
+
+    def __init__(self, model):
+        import torch.nn as nn
+        from .layers import cache_of_key
+        L = lib()
+        self.jobs, self.entries = [], []          # jobs: ctypes arguments; entries: (cache, parameter, value)
+        self.device = next(model.parameters()).device
+
+        def buf(is3d, cin, cout, ntaps):
+            n = L.mdf_conv3d_packed_size(cin, cout) if is3d else L.mdf_conv_packed_size(cin, cout, ntaps)
+            return torch.empty(n, device=self.device, dtype=torch.float32)
+
+        def job(param, is3d, tr, mode, cin, cout, ntaps, a0=0, a1=0):
+            dst = buf(is3d, cin, cout, ntaps)
+            self.jobs.append((param, dst, int(is3d), int(tr), mode, cin, cout, ntaps, a0, a1))
+            return dst
+
+        def entry(mod, name, param, value):
+            self.entries.append((cache_of_key(mod, name), param, value))
+
+        for reg in model.Regular:
+            for m in reg.modules():
+                w = getattr(m, "weight", None)
+                if isinstance(m, nn.ConvTranspose3d):
+                    entry(m, "fwd", w, job(w, 1, 1, _SRC_DIRECT, m.in_channels, m.out_channels, 27))
+                    entry(m, "dgrad", w, job(w, 1, 0, _SRC_DIRECT, m.out_channels, m.in_channels, 27))     # stride-2 conv [out=Cin][in=Cout]
+                elif isinstance(m, nn.Conv3d) and tuple(m.kernel_size) == (3, 3, 3):
+                    if m.out_channels == 1:
+                        entry(m, "probpack", w, job(w, 0, 0, _SRC_PROB, m.in_channels, 4, 9))
+                        continue
+                    entry(m, "fwd", w, job(w, 1, 0, _SRC_DIRECT, m.in_channels, m.out_channels, 27))
+                    if m.stride[0] == 2:
+                        entry(m, "dgrad", w, job(w, 1, 1, _SRC_DIRECT, m.out_channels, m.in_channels, 27))  # transposed conv [in=Cout][out=Cin]
+                    else:
+                        entry(m, "dgrad", w, job(w, 1, 0, _SRC_SWAPFLIP, m.out_channels, m.in_channels, 27))
+        bb = model.Backbone
+        if hasattr(bb, "conv34"):
+            first = True
+            for seq in (bb.conv01, bb.conv12, bb.conv23, bb.conv34):
+                for blk in seq:
+                    c = blk.conv
+                    k, w = c.kernel_size[0], c.weight
+                    entry(c, "fwd", w, job(w, 0, 0, _SRC_DIRECT, c.in_channels, c.out_channels, k * k))
+                    if not first:
+                        if k == 3 and c.stride[0] == 1:
+                            entry(c, "dgrad", w, job(w, 0, 0, _SRC_SWAPFLIP, c.out_channels, c.in_channels, 9))
+                        else:
+                            entry(c, "dgrad", w, [(job(w, 0, 0, _SRC_K5S2, c.out_channels, hi - lo, 9, c.in_channels, lo), hi - lo)
+                                                  for lo, hi in _k5s2_parts(c.in_channels)])
+                    first = False
+            for c in (bb.lat2, bb.lat3, bb.out2, bb.out3, bb.out4):
+                entry(c, "fwd", c.weight, job(c.weight, 0, 0, _SRC_DIRECT, c.in_channels, c.out_channels, 1))
+                entry(c, "dgrad", c.weight, job(c.weight, 0, 0, _SRC_SWAP, c.out_channels, c.in_channels, 1))
+        rf = getattr(model, "Refine", None)
+        if rf is not None and hasattr(rf, "ress"):
+            shuffled = rf.conv2[0]
+            convs = [rf.conv0] + [blk.conv[i] for blk in rf.ress for i in (0, 2)] + [rf.conv1, rf.conv2[0], rf.conv2[2]]
+            for c in convs:
+                entry(c, "fwd", c.weight, job(c.weight, 0, 0, _SRC_SHUFFLE2 if c is shuffled else _SRC_DIRECT, c.in_channels, c.out_channels, 9))
+                if c is not rf.conv0:
+                    entry(c, "dgrad", c.weight, job(c.weight, 0, 0, _SRC_SWAPFLIP, c.out_channels, c.in_channels, 9))
+        # job table (host) -> device, with the per-block job index
+        nb = int(L.mdf_pack_job_bytes())
+        table = (ctypes.c_char * (nb * len(self.jobs)))()
+        block_job, first = [], 0
+        for i, (param, dst, is3d, tr, mode, cin, cout, ntaps, a0, a1) in enumerate(self.jobs):
+            nblk = int(L.mdf_pack_job_fill(ctypes.addressof(table), i, param.data_ptr(), dst.data_ptr(), is3d, tr, mode, cin, cout, ntaps,
+                                           a0, a1, first))
+            if nblk < 0:
+                from . import MdfHipError
+                raise MdfHipError(f"mdf_pack_job_fill: {L.mdf_last_error().decode()}")
+            block_job += [i] * nblk
+            first += nblk
+        self.nblocks = first
+        self.table = torch.frombuffer(bytearray(table), dtype=torch.uint8).to(self.device)
+        self.block_job = torch.tensor(block_job, dtype=torch.int32).to(self.device)
+        self.params = []
+        seen = set()
+        for _, p_, _ in self.entries:
+            if id(p_) not in seen:
+                seen.add(id(p_))
+                self.params.append(p_)
+        self.ptrs = tuple(p_.data_ptr() for p_ in self.params)
+        self.versions = None
+
+    def valid(self):
+        return tuple(p_.data_ptr() for p_ in self.params) == self.ptrs
+
+    def run(self):
+        versions = tuple(p_._version for p_ in self.params)
+        if versions != self.versions:
+            _abi("mdf_pack_batch", (self.table.data_ptr(), self.block_job.data_ptr(), self.nblocks, _stream(self.table)),
+                 tag=f"{len(self.jobs)} weight sets")
+            self.versions = versions
+        idx = self.device.index
+        for cache, p_, value in self.entries:
+            cache.key, cache.val, cache.ev, cache.seen = ((p_.data_ptr(), p_._version, idx),), value, None, ()
+
+
+def _k5s2_parts(cin):
+    nout = 4 * cin
+    return [(0, nout)] if nout <= 64 else [(0, nout // 2), (nout // 2, nout)]
+
+
 def prepack(model):
-    """Pack the forward and input-gradient weights of every conv layer the training kernels will use in this step (the
-    optimizer has just changed them: ~85 tiny launches).  Called on a side stream at the top of CoreNet.forward; the cache
-    entries carry an event, the consuming stream waits for it (mdfnet_hip/layers.py:_Folded)."""
-    import torch.nn as nn
-    from .layers import cache_of_key
-    for reg in model.Regular:
-        for m in reg.modules():
-            if isinstance(m, nn.ConvTranspose3d):
-                ops_pack_fwd(m, True)
-                dgrad_pack(m, True)
-            elif isinstance(m, nn.Conv3d) and m.out_channels > 1 and tuple(m.kernel_size) == (3, 3, 3):
-                ops_pack_fwd(m, False)
-                dgrad_pack(m, False)
-    bb = model.Backbone
-    if hasattr(bb, "conv34"):
-        first = True
-        for seq in (bb.conv01, bb.conv12, bb.conv23, bb.conv34):
-            for blk in seq:
-                conv = blk.conv
-                cache_of_key(conv, "fwd").get((conv.weight,), lambda c=conv: ops.pack_conv2d_weight(c.weight))
-                if not first:
-                    _dgrad2d_pack(conv)
-                first = False
+    """Pack the forward and input-gradient weights of every conv layer the training kernels use in this step (the optimizer
+    has just changed them).  Called at the top of CoreNet.forward in training mode, on the step's own stream."""
+    plan = model.__dict__.get("_mdf_pack_plan")
+    if plan is None or not plan.valid():
+        plan = model.__dict__["_mdf_pack_plan"] = PackPlan(model)
+    plan.run()
 
 
 # --------------------------------------------------------------------------- FPN heads (1x1 convs + top-down adds) in training mode

@@ -62,14 +62,9 @@ class CoreNet(torch.nn.Module):
             # mirrors and never synchronise again
             hostmirror.ensure((extrinsics, intrinsics, depth_range))
         if self.training and origin_imgs.is_cuda and layers.hip_train(self, origin_imgs):
-            # this step's weight packs (the optimizer has just changed every weight) on a side stream, off the critical path
+            # this step's weight packs (the optimizer has just changed every weight): one batched launch
             from mdfnet_hip import train_ops
-            cur = torch.cuda.current_stream(origin_imgs.device)
-            side = self.__dict__.get("_mdf_side_stream")
-            if side is None or side.device != origin_imgs.device:
-                side = self.__dict__["_mdf_side_stream"] = torch.cuda.Stream(origin_imgs.device)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side), torch.no_grad():
+            with torch.no_grad():
                 train_ops.prepack(self)
         pyramids = self._pyramids(origin_imgs.float(), feature_cache, view_keys)
         depth = hypos = prob = None

@@ -404,3 +404,51 @@ def test_refine_net_training_forward_backward():
         assert pa.grad is not None, k
         e_hip, e_cpu = _l2(pa.grad, p64.grad), _l2(pr.grad, p64.grad)
         assert e_hip <= max(3 * e_cpu, 2e-5), (k, e_hip, e_cpu)
+
+
+def test_batched_weight_packing_equals_the_per_layer_packs(seeded_sd):
+    """train_ops.PackPlan (one mdf_pack_batch launch for every weight set of a training step) writes bit-for-bit what the
+    per-layer route builds with torch re-indexing (flip / transpose / pad / index_select) + mdf_conv*_pack_weights."""
+    model = build_model()
+    model.load_state_dict(seeded_sd)
+    model = model.to(DEV).train()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    plan = train_ops.PackPlan(model)
+    for job in plan.jobs:
+        job[1].fill_(float("nan"))        # (the 3-D buffers are sized for the larger of the plain and transposed layouts)
+    plan.run()
+    torch.cuda.synchronize()
+    assert len(plan.jobs) > 90 and plan.nblocks > 0
+    S = train_ops
+    for param, dst, is3d, tr, mode, cin, cout, ntaps, a0, a1 in plan.jobs:
+        w = param.detach()
+        if is3d:
+            if tr:
+                ref = ops.pack_conv3d_weight(w, transposed=True)
+            elif mode == S._SRC_SWAPFLIP:
+                ref = ops.pack_conv3d_weight(w.flip(2, 3, 4).transpose(0, 1).contiguous())
+            else:                                 # direct: Conv3d weight, or a ConvTranspose3d weight read as [out=Cin][in=Cout]
+                ref = ops.pack_conv3d_weight(w)
+        elif mode == S._SRC_PROB:
+            ref = ops.pack_prob_weight(w)
+        elif mode == S._SRC_K5S2:
+            ref = ops.pack_conv2d_weight(S._k5s2_dgrad_weight(w)[a1:a1 + cout].contiguous())
+        elif mode == S._SRC_SHUFFLE2:
+            ref = ops.pack_conv2d_weight(ops.shuffle2_rows(w))
+        elif mode == S._SRC_SWAPFLIP:
+            ref = ops.pack_conv2d_weight(w.flip(2, 3).transpose(0, 1).contiguous())
+        elif mode == S._SRC_SWAP:
+            ref = ops.pack_conv2d_weight(w.transpose(0, 1).contiguous())
+        else:
+            ref = ops.pack_conv2d_weight(w)
+        assert ref.numel() == dst.numel()
+        written = ~torch.isnan(dst)
+        assert int(written.sum()) >= param.numel() and bool(written[:param.numel()].all())
+        assert torch.equal(dst[written], ref[written]), (tuple(param.shape), is3d, tr, mode, cin, cout, ntaps)
+    # and the caches hand the buffers out without re-packing
+    from mdfnet_hip.layers import cache_of_key
+    conv = next(m for m in model.Regular[0].modules() if isinstance(m, nn.Conv3d))
+    got = cache_of_key(conv, "fwd").get((conv.weight,), lambda: pytest.fail("cache missed after PackPlan.run"))
+    assert got.data_ptr() in {j[1].data_ptr() for j in plan.jobs}
