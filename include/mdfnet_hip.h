@@ -264,6 +264,20 @@ int mdf_warp_aggregate_vec_train(int pass, const float* ref_fea, const float* co
                                  const float* dcost, float* cost, float* wsum, double* red_out, float* dref,
                                  float* const* dsrc, float* dcw, int B, int C, int G, int D, int h, int w, int n_src,
                                  void* stream);
+/* Control plane of the passes above, on the device (homoaggregate.py:16-20: the BatchNorm3d(1) of depth_weight, called
+ * once per source view, :35-40):
+ *   prepare       par[0,G+4) = (conv weight, w2, b2, gamma, 1/n), par[G+4, G+4+4 n_src) = 0, red[0,nred) = 0
+ *   finalize      after pass 0: par[G+4+4v..] = (alpha_v, beta_v, mean_v, invstd_v) from red; running_mean / running_var /
+ *                 num_batches_tracked (any may be NULL) advanced as by n_src successive calls with `momentum`
+ *   bwd_finalize  after pass 3: dsrc [n_src][B,h,w,C] from the even-channel gradients dhalf [n_src][B,h,w,G] (n_half = their
+ *                 total element count), and dpar = (d gamma, d beta, d w2, d b2) from pass 2's red                      */
+int mdf_aggregate_train_prepare(const float* cw, const float* w2, const float* b2, const float* gamma, long long n, int G,
+                                int n_src, float* par, double* red, int nred, void* stream);
+int mdf_aggregate_train_finalize(const double* red, const float* gamma, const float* beta, float eps, float momentum, long long n,
+                                 int G, int n_src, float* par, float* running_mean, float* running_var,
+                                 long long* num_batches_tracked, void* stream);
+int mdf_aggregate_train_bwd_finalize(const float* dhalf, const double* red, int n_src, long long n_half, float* dsrc,
+                                     float* dpar, void* stream);
 
 #ifdef __cplusplus
 }

@@ -429,6 +429,55 @@ int launch_train(TrainParams& p, int C, hipStream_t st) {
   return mdf::check_launch("warp_train_kernel");
 }
 
+// ---- control plane of the training aggregate: the handful of scalars between the passes, computed where they live (as
+// torch expressions they were ~35 tiny launches per stage and direction, on a step that is bound by its host's issue rate)
+__global__ void agg_prepare_kernel(const float* cw, const float* w2, const float* b2, const float* gamma, float inv_n, int G, int n_src,
+                                   float* par, double* red, int nred) {
+  const int i = threadIdx.x;
+  if (i < G) par[i] = cw[i];
+  if (i == 0) { par[G] = w2[0]; par[G + 1] = b2[0]; par[G + 2] = gamma[0]; par[G + 3] = inv_n; }
+  if (i < 4 * n_src) par[G + 4 + i] = 0.f;
+  if (i < nred) red[i] = 0.0;
+}
+
+// batch statistics of the 1-channel BatchNorm per source view -> (alpha, shift, mean, invstd), and the running statistics
+// advanced as by n_src successive module calls (homoaggregate.py:35-40 calls depth_weight once per source view)
+__global__ void agg_finalize_kernel(const double* red, const float* gamma, const float* beta, double eps, double momentum, double n, int G,
+                                    int n_src, float* par, float* rmean, float* rvar, long long* nbt) {
+  if (threadIdx.x != 0) return;
+  double rm = rmean ? (double)rmean[0] : 0.0, rv = rvar ? (double)rvar[0] : 0.0;
+  for (int v = 0; v < n_src; ++v) {
+    const double mean = red[2 * v] / n;
+    double var = red[2 * v + 1] / n - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const double invstd = 1.0 / sqrt(var + eps);
+    const double alpha = (double)gamma[0] * invstd;
+    float* o = par + G + 4 + 4 * v;
+    o[0] = (float)alpha; o[1] = (float)((double)beta[0] - mean * alpha); o[2] = (float)mean; o[3] = (float)invstd;
+    rm = (1.0 - momentum) * rm + momentum * mean;
+    rv = (1.0 - momentum) * rv + momentum * var * (n / (n > 1.0 ? n - 1.0 : 1.0));
+  }
+  if (rmean) rmean[0] = (float)rm;
+  if (rvar) rvar[0] = (float)rv;
+  if (nbt) nbt[0] += n_src;
+}
+
+// backward epilogue: the scatter accumulated the gradient of the EVEN channel of every softmax pair; the odd channel gets
+// its negative (d softmax pair: dv1 = -dv0).  dpar = (d gamma, d beta, d w2, d b2) from the fp64 reductions.
+__global__ void agg_bwd_finalize_kernel(const float* __restrict__ dhalf, const double* __restrict__ red, int n_src, long long n_half,
+                                        float* __restrict__ dfull, float* __restrict__ dpar) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_half) {
+    const float v = dhalf[i];
+    reinterpret_cast<float2*>(dfull)[i] = make_float2(v, -v);
+  }
+  if (i == 0) {
+    double dg = 0.0, db = 0.0;
+    for (int v = 0; v < n_src; ++v) { db += red[2 * v]; dg += red[2 * v + 1]; }
+    dpar[0] = (float)dg; dpar[1] = (float)db; dpar[2] = (float)red[2 * n_src]; dpar[3] = (float)red[2 * n_src + 1];
+  }
+}
+
 }  // namespace
 
 extern "C" int mdf_warp_aggregate_vec_train(int pass, const float* ref_fea, const float* const* src_feas, const float* proj,
@@ -471,4 +520,33 @@ extern "C" int mdf_warp_aggregate_vec_train(int pass, const float* ref_fea, cons
       }
       return launch_bwd(p, C, st);
   }
+}
+
+extern "C" int mdf_aggregate_train_prepare(const float* cw, const float* w2, const float* b2, const float* gamma, long long n, int G,
+                                           int n_src, float* par, double* red, int nred, void* stream) {
+  MDF_REQUIRE(cw && w2 && b2 && gamma && par && red, "null pointer argument");
+  MDF_REQUIRE(n > 0 && G >= 1 && G <= 32 && n_src >= 1 && n_src <= MDF_MAX_SRC_VIEWS && nred >= 0 && nred <= 64, "bad sizes");
+  hipLaunchKernelGGL(agg_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cw, w2, b2, gamma, (float)(1.0 / (double)n), G, n_src, par,
+                     red, nred);
+  return mdf::check_launch("agg_prepare_kernel");
+}
+
+extern "C" int mdf_aggregate_train_finalize(const double* red, const float* gamma, const float* beta, float eps, float momentum, long long n,
+                                            int G, int n_src, float* par, float* running_mean, float* running_var,
+                                            long long* num_batches_tracked, void* stream) {
+  MDF_REQUIRE(red && gamma && beta && par, "null pointer argument");
+  MDF_REQUIRE(n > 0 && G >= 1 && n_src >= 1 && n_src <= MDF_MAX_SRC_VIEWS, "bad sizes");
+  hipLaunchKernelGGL(agg_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, red, gamma, beta, (double)eps, (double)momentum, (double)n,
+                     G, n_src, par, running_mean, running_var, num_batches_tracked);
+  return mdf::check_launch("agg_finalize_kernel");
+}
+
+extern "C" int mdf_aggregate_train_bwd_finalize(const float* dhalf, const double* red, int n_src, long long n_half, float* dsrc,
+                                                float* dpar, void* stream) {
+  MDF_REQUIRE(dhalf && red && dsrc && dpar, "null pointer argument");
+  MDF_REQUIRE(n_half > 0 && n_src >= 1 && n_src <= MDF_MAX_SRC_VIEWS, "bad sizes");
+  const long long blocks = (n_half + 255) / 256;
+  MDF_REQUIRE(blocks < (1ll << 31), "too many elements");
+  hipLaunchKernelGGL(agg_bwd_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dhalf, red, n_src, n_half, dsrc, dpar);
+  return mdf::check_launch("agg_bwd_finalize_kernel");
 }

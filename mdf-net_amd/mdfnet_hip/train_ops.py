@@ -248,7 +248,6 @@ def regulariser_train(module, cost, hypos):
 
 # --------------------------------------------------------------------------- VectorAggregate in training mode
 _PASS_STATS, _PASS_FWD, _PASS_BWD_REDUCE, _PASS_BWD = 0, 1, 2, 3
-_COEF = {}
 
 
 def _agg_call(pass_, ref, srcs, proj, hyp, pp, par, red_in, dcost, cost, wsum, red_out, dref, dsrcs, dcw, b, c, g, d, h, w):
@@ -274,29 +273,20 @@ class AggregateTrainFn(torch.autograd.Function):
         nsrc = len(feas) - 1
         dev = feas[0].device
         n = b * d * h * w
-        head = torch.cat([cw.detach().reshape(-1).float(), w2.detach().reshape(1).float(), b2.detach().reshape(1).float(),
-                          gamma.detach().reshape(1).float(), torch.full((1,), 1.0 / n, device=dev)])
-        par0 = torch.cat([head, torch.zeros(4 * nsrc, device=dev)])
-        red = torch.zeros(2 * nsrc, device=dev, dtype=torch.float64)
-        _agg_call(_PASS_STATS, feas[0], feas[1:], proj, hyp, pp, par0, None, None, None, None, red, None, None, None, b, c, g, d, h, w)
-        mean = red[0::2] / n
-        var = (red[1::2] / n - mean * mean).clamp_(min=0.0)
-        invstd = torch.rsqrt(var + bn.eps)
-        alpha = gamma.detach().double() * invstd
-        shift = beta.detach().double() - mean * alpha
-        par = torch.cat([head, torch.stack([alpha, shift, mean, invstd], dim=1).reshape(-1).float()])
-        if bn.track_running_stats and bn.running_mean is not None:
-            # the module is called once per source view (homoaggregate.py:35-40): n_src sequential momentum updates
-            mom = BN_MOMENTUM if bn.momentum is None else bn.momentum
-            ck = (dev, nsrc, mom)
-            coef = _COEF.get(ck)
-            if coef is None:
-                coef = _COEF[ck] = torch.tensor([mom * (1.0 - mom) ** (nsrc - 1 - v) for v in range(nsrc)], dtype=torch.float64).to(dev)
-            keep = (1.0 - mom) ** nsrc
-            unb = var * (n / max(n - 1, 1))
-            bn.running_mean.mul_(keep).add_((coef * mean).sum().float())
-            bn.running_var.mul_(keep).add_((coef * unb).sum().float())
-            bn.num_batches_tracked.add_(nsrc)
+        st = _stream(feas[0])
+        # the scalars between the passes stay on the device (prepare / finalize kernels): no host arithmetic, no tiny ATen launches
+        par = torch.empty(g + 4 + 4 * nsrc, device=dev, dtype=torch.float32)
+        red = torch.empty(2 * nsrc, device=dev, dtype=torch.float64)
+        cwd, gmd, btd, w2d, b2d = (_f32c(t.detach()) for t in (cw, gamma, beta, w2, b2))
+        _abi("mdf_aggregate_train_prepare", (cwd.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), gmd.data_ptr(), n, g, nsrc, par.data_ptr(),
+                                             red.data_ptr(), 2 * nsrc, st))
+        _agg_call(_PASS_STATS, feas[0], feas[1:], proj, hyp, pp, par, None, None, None, None, red, None, None, None, b, c, g, d, h, w)
+        track = bn.track_running_stats and bn.running_mean is not None
+        mom = BN_MOMENTUM if bn.momentum is None else bn.momentum
+        _abi("mdf_aggregate_train_finalize", (red.data_ptr(), gmd.data_ptr(), btd.data_ptr(), ctypes.c_float(bn.eps), ctypes.c_float(mom), n, g,
+                                              nsrc, par.data_ptr(), bn.running_mean.data_ptr() if track else None,
+                                              bn.running_var.data_ptr() if track else None,
+                                              bn.num_batches_tracked.data_ptr() if track else None, st))
         cost = torch.empty((b, d, h, w, g), device=dev, dtype=torch.float32)
         wsum = torch.empty((b, d, h, w), device=dev, dtype=torch.float32)
         _agg_call(_PASS_FWD, feas[0], feas[1:], proj, hyp, pp, par, None, None, cost, wsum, None, None, None, None, b, c, g, d, h, w)
@@ -311,23 +301,29 @@ class AggregateTrainFn(torch.autograd.Function):
         feas, nsrc = ctx.feas, len(ctx.feas) - 1
         dev = feas[0].device
         dc = ops.to_ndhwc(dcost)
-        red = torch.zeros(2 * nsrc + 2, device=dev, dtype=torch.float64)
+        nhalf = b * h * w * g
+        # one zero fill for everything the two passes accumulate into: fp64 reductions | even-channel gradients per view | d conv weight
+        nred = 2 * nsrc + 2
+        zero = torch.zeros(8 * nred + 4 * (nsrc * nhalf + g), device=dev, dtype=torch.uint8)
+        red = zero[:8 * nred].view(torch.float64)
+        acc = zero[8 * nred:].view(torch.float32)
+        dhalf = [acc[v * nhalf:(v + 1) * nhalf] for v in range(nsrc)]
+        dcw = acc[nsrc * nhalf:]
         _agg_call(_PASS_BWD_REDUCE, feas[0], feas[1:], ctx.proj, ctx.hyp, ctx.pp, ctx.par, None, dc, ctx.cost, ctx.wsum, red, None, None,
                   None, b, c, g, d, h, w)
         dref = torch.empty_like(feas[0])
-        dhalf = [torch.zeros((b, h, w, g), device=dev, dtype=torch.float32) for _ in feas[1:]]   # even channel of every pair
-        dcw = torch.zeros(g, device=dev, dtype=torch.float32)
         _agg_call(_PASS_BWD, feas[0], feas[1:], ctx.proj, ctx.hyp, ctx.pp, ctx.par, red, dc, ctx.cost, ctx.wsum, None, dref, dhalf, dcw,
                   b, c, g, d, h, w)
-        dsrcs = [torch.stack((t, -t), dim=-1).reshape(b, h, w, c) for t in dhalf]      # softmax pair: d v1 = -d v0
+        dfull = torch.empty((nsrc, b, h, w, c), device=dev, dtype=torch.float32)
+        dpar = torch.empty(4, device=dev, dtype=torch.float32)
+        _abi("mdf_aggregate_train_bwd_finalize", (acc.data_ptr(), red.data_ptr(), nsrc, nsrc * nhalf, dfull.data_ptr(), dpar.data_ptr(),
+                                                  _stream(dfull)), tag=f"pairs {nsrc}x{h}x{w}x{c}",
+             work={"bytes": 12.0 * nsrc * nhalf, "bound": "hbm"})
         s_cw, s_gamma, s_beta, s_w2, s_b2 = ctx.wshapes
-        dgamma = red[1:2 * nsrc:2].sum().float().reshape(s_gamma)
-        dbeta = red[0:2 * nsrc:2].sum().float().reshape(s_beta)
-        dw2 = red[2 * nsrc].float().reshape(s_w2)
-        db2 = red[2 * nsrc + 1].float().reshape(s_b2)
-        dfeas = [t.permute(0, 3, 1, 2) for t in [dref] + dsrcs]
+        dfeas = [dref.permute(0, 3, 1, 2)] + [dfull[v].permute(0, 3, 1, 2) for v in range(nsrc)]
         ctx.cost = ctx.wsum = None
-        return (None, None, None, dcw.reshape(s_cw), dgamma, dbeta, dw2, db2) + tuple(dfeas)
+        return (None, None, None, dcw.reshape(s_cw), dpar[0].reshape(s_gamma), dpar[1].reshape(s_beta), dpar[2].reshape(s_w2),
+                dpar[3].reshape(s_b2)) + tuple(dfeas)
 
 
 def aggregate_train(module, features, proj, hypos):
