@@ -186,8 +186,9 @@ int mdf_consistency_fuse_fwd(const float* depth_ref, const float* conf, const fl
  *   bwd_reduce: red[0..C) += sum dr, red[C..2C) += sum dr*xhat,  dr = dz*[y*a+b > 0], xhat = (y-mean)*invstd
  *   bwd:      dy = gamma*invstd*(dr - red0/N - xhat*red1/N);  dgamma[c] = red1, dbeta[c] = red0
  *   ngroups: the tensor is [ngroups][N][C] and every group is one call of the module with its own batch statistics
- *   (the feature pyramid runs once per view, net/core.py:42): sums/red [ngroups][2C], aux [ngroups][4C], dgamma/dbeta
- *   [ngroups][C]; finalize walks the groups in order for the running statistics and adds ngroups to *nbt.            */
+ *   (the feature pyramid runs once per view, net/core.py:42): sums/red [ngroups][2C], aux [ngroups][4C]; dgamma/dbeta [C]
+ *   are summed over the groups (one module, its calls' gradients add); finalize walks the groups in order for the running
+ *   statistics and adds ngroups to *nbt.                                                                             */
 int mdf_bn_stats_fwd(const float* y, long long N, int C, int ngroups, double* sums, void* stream);
 int mdf_bn_finalize_fwd(const double* sums, const float* gamma, const float* beta, float eps, float momentum, long long N,
                         int C, int ngroups, float* aux, float* running_mean, float* running_var,

@@ -185,9 +185,13 @@ __global__ __launch_bounds__(kT) void bn_relu_bwd_kernel(const float* __restrict
   y += (long long)blockIdx.y * n4 * 4;
   dy += (long long)blockIdx.y * n4 * 4;
   aux += (long long)blockIdx.y * 4 * C;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid < C) {   // parameter gradients: the groups are calls of ONE module, their gradients add
+    double sb = 0.0, sg = 0.0;
+    for (int g = 0; g < (int)gridDim.y; ++g) { sb += red[(long long)g * 2 * C + tid]; sg += red[(long long)g * 2 * C + C + tid]; }
+    dbeta[tid] = (float)sb;
+    dgamma[tid] = (float)sg;
+  }
   red += (long long)blockIdx.y * 2 * C;
-  dgamma += (long long)blockIdx.y * C;
-  dbeta += (long long)blockIdx.y * C;
   float a[4], b[4], mu[4], is[4], m1[4], m2[4], gi[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -195,10 +199,6 @@ __global__ __launch_bounds__(kT) void bn_relu_bwd_kernel(const float* __restrict
     m1[k] = (float)(red[c0 + k] * inv_n);
     m2[k] = (float)(red[C + c0 + k] * inv_n);
     gi[k] = gamma[c0 + k] * is[k];
-  }
-  if (blockIdx.x == 0 && tid < C) {
-    dbeta[tid] = (float)red[tid];
-    dgamma[tid] = (float)red[C + tid];
   }
   const long long stride = (long long)gridDim.x * kT;
   for (long long i = (long long)blockIdx.x * kT + tid; i < n4; i += stride) {

@@ -50,9 +50,22 @@ struct WgradParams {
   long long n_items;     // B*Ds*Hs*chunks_per_row
   int NB;                // b-tiles
   int split;             // waves of a block that share one pair and split the chunks (1, 2 or 4)
+  float* zero_out;       // when set: zero_n floats cleared by this launch (the dw the slab is summed into next)
+  int zero_n;
 };
 
+// the launch also clears the gradient tensor its partial tiles are summed into afterwards (slab_sum_kernel adds with
+// atomics): no separate memset launch per layer
+__device__ __forceinline__ void zero_slice(float* out, int n) {
+  if (!out) return;
+  const int nb = gridDim.x * gridDim.y * gridDim.z;
+  const int bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  for (int i = bid * 256 + threadIdx.x; i < n; i += nb * 256) out[i] = 0.f;
+}
+
+
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+  zero_slice(p.zero_out, p.zero_n);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: the item bookkeeping below runs on the scalar unit
   const int q = lane >> 4, c16 = lane & 15;
@@ -189,6 +202,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 // nine (kh,kw) shifts of `small` in the ROWS of the tile: one MFMA step yields all nine taps of a depth tap (27 -> 3 MFMA
 // steps per chunk, `big` read once per kd instead of nine times).  blockIdx.z = kd; the 4 waves of a block split the chunks.
 __global__ __launch_bounds__(256) void wgrad_a1_kernel(const WgradParams p) {
+  zero_slice(p.zero_out, p.zero_n);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, c16 = lane & 15;
   const int kd = blockIdx.z;
@@ -244,10 +258,13 @@ struct Wgrad2dParams {
   int chunks_per_row;
   long long n_items;     // B*Hs*chunks_per_row
   int NB, split;
+  float* zero_out;
+  int zero_n;
 };
 
 template <int KS>
 __global__ __launch_bounds__(256) void wgrad2d_kernel(const Wgrad2dParams p) {
+  zero_slice(p.zero_out, p.zero_n);
   constexpr int PAD = (KS - 1) / 2;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -372,7 +389,7 @@ __global__ void slab_sum_kernel(const float* __restrict__ slab, int nslab, int n
 }  // namespace
 
 int mdf_wgrad_lds_dispatch(const float* small_, const float* big, float* workspace, int* gx_io, int B, int Ds, int Hs, int Ws, int A, int Bc,
-                           int stride, int ksize, int is3d, void* stream);
+                           int stride, int ksize, int is3d, float* zero_out, int zero_n, void* stream);
 // blocks per launch: every block writes one partial tile set to the slab (PMC: 2 GB written + 2 GB re-read per cfg3 step at
 // 2048 blocks), so no more blocks than it takes to fill the chip a few times over
 static int wgrad_target_blocks() {
@@ -418,6 +435,9 @@ extern "C" int mdf_conv3d_wgrad(const float* small_, const float* big, float* dw
   p.split = pairs >= 4 ? 1 : (pairs == 2 ? 2 : 4);
   const int gy = (pairs * p.split + 3) / 4;
   const int gx = (int)(mdf_conv3d_wgrad_workspace(B, Ds, Hs, Ws, A, Bc) / ((long long)A * Bc * 27));
+  const int n = A * Bc * 27;
+  p.zero_out = accumulate ? nullptr : dw;
+  p.zero_n = n;
   int gx_used = gx;
   int rc_lds = MDF_EUNSUPPORTED;
   if (A == 1 && Bc <= 16 && stride == 1) {
@@ -425,7 +445,7 @@ extern "C" int mdf_conv3d_wgrad(const float* small_, const float* big, float* dw
   } else {
     if (wgrad_use_lds()) {
       gx_used = gx;
-      rc_lds = mdf_wgrad_lds_dispatch(small_, big, workspace, &gx_used, B, Ds, Hs, Ws, A, Bc, stride, 3, 1, stream);
+      rc_lds = mdf_wgrad_lds_dispatch(small_, big, workspace, &gx_used, B, Ds, Hs, Ws, A, Bc, stride, 3, 1, p.zero_out, n, stream);
       if (rc_lds != MDF_OK && rc_lds != MDF_EUNSUPPORTED) return rc_lds;
     }
     if (rc_lds == MDF_EUNSUPPORTED) {
@@ -434,8 +454,6 @@ extern "C" int mdf_conv3d_wgrad(const float* small_, const float* big, float* dw
     }
   }
   if (int rc = mdf::check_launch("wgrad_kernel")) return rc;
-  const int n = A * Bc * 27;
-  if (!accumulate) (void)hipMemsetAsync(dw, 0, (size_t)n * sizeof(float), (hipStream_t)stream);
   int gys = gx_used / 8;                  // >= 8 slabs per partial sum
   if (gys < 1) gys = 1;
   if (gys > 32) gys = 32;
@@ -482,10 +500,13 @@ extern "C" int mdf_conv2d_wgrad(const float* small_, const float* big, float* dw
   const int gx = (int)wgrad2d_grid(B, Hs, Ws, A, Bc, ksize, &p.split, &gy);
   const dim3 grid(gx, gy, ksize);
   hipStream_t st = (hipStream_t)stream;
+  const int n = A * Bc * ksize * ksize;
+  p.zero_out = accumulate ? nullptr : dw;
+  p.zero_n = n;
   int gx_used = gx, rc_lds = MDF_EUNSUPPORTED;
   if (wgrad_use_lds()) {
     gx_used = gx;
-    rc_lds = mdf_wgrad_lds_dispatch(small_, big, workspace, &gx_used, B, 1, Hs, Ws, A, Bc, stride, ksize, 0, stream);
+    rc_lds = mdf_wgrad_lds_dispatch(small_, big, workspace, &gx_used, B, 1, Hs, Ws, A, Bc, stride, ksize, 0, p.zero_out, n, stream);
     if (rc_lds != MDF_OK && rc_lds != MDF_EUNSUPPORTED) return rc_lds;
   }
   if (rc_lds == MDF_EUNSUPPORTED) {
@@ -495,8 +516,6 @@ extern "C" int mdf_conv2d_wgrad(const float* small_, const float* big, float* dw
     else hipLaunchKernelGGL(wgrad2d_kernel<5>, grid, dim3(256), 0, st, p);
     if (int rc = mdf::check_launch("wgrad2d_kernel")) return rc;
   }
-  const int n = A * Bc * ksize * ksize;
-  if (!accumulate) (void)hipMemsetAsync(dw, 0, (size_t)n * sizeof(float), st);
   int gys = gx_used / 8;
   if (gys < 1) gys = 1;
   if (gys > 32) gys = 32;

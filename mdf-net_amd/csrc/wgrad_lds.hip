@@ -27,6 +27,8 @@ struct WgradLdsParams {
   int ntaps_total;       // 27 (3-D) or KS*KS (2-D)
   int pad;               // spatial padding of the taps inside a row (and of the z tap)
   int tv;                // voxels of `small` per tile along w: 64, or 256 for few-channel layers (more MFMAs per barrier)
+  float* zero_out;       // when set: zero_n floats cleared by this launch (the dw the slab is summed into next)
+  int zero_n;
 };
 
 // KH kernel rows x KW taps per block; MODE3D: z = kd and the rows are the 3 kh rows of depth plane od*s+kd-1;
@@ -34,6 +36,11 @@ struct WgradLdsParams {
 template <int KH, int KW, bool MODE3D>
 __global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (p.zero_out) {
+    const int nblk = gridDim.x * gridDim.y * gridDim.z;
+    const int bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    for (int i = bid * 256 + threadIdx.x; i < p.zero_n; i += nblk * 256) p.zero_out[i] = 0.f;
+  }
   const int s = p.stride;
   const int WB = p.tv * s + KW - 1;              // voxels of `big` per staged row
   float* sm_small = lds;                         // [tv][AS]
@@ -191,10 +198,10 @@ int padded_stride(int C, int step) {
 
 // returns MDF_EUNSUPPORTED when the shape has no LDS instantiation (the caller falls back to the direct kernels)
 int mdf_wgrad_lds_dispatch(const float* small_, const float* big, float* workspace, int* gx_io, int B, int Ds, int Hs, int Ws, int A, int Bc,
-                           int stride, int ksize, int is3d, void* stream) {
+                           int stride, int ksize, int is3d, float* zero_out, int zero_n, void* stream) {
   if ((A & 3) || (Bc & 3)) return MDF_EUNSUPPORTED;
   WgradLdsParams p{};
-  p.small_ = small_; p.big = big; p.slab = workspace;
+  p.small_ = small_; p.big = big; p.slab = workspace; p.zero_out = zero_out; p.zero_n = zero_n;
   p.B = B; p.Ds = Ds; p.Hs = Hs; p.Ws = Ws; p.Db = Ds * stride; p.Hb = Hs * stride; p.Wb = Ws * stride; p.A = A; p.Bc = Bc; p.stride = stride;
   if (!is3d) { p.Ds = 1; p.Db = 1; }
   p.pad = (ksize - 1) / 2;

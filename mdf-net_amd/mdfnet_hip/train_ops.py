@@ -38,6 +38,23 @@ class ZeroPool:
         self.off += k
         return v
 
+    def reset(self):
+        """Start of a training step: every slice handed out so far has been consumed (same stream), one fill re-arms them all."""
+        self.buf.zero_()
+        self.off = 0
+
+
+_STEP_POOLS = {}
+
+
+def step_pool(device):
+    """The reduction scratch of the whole step (forward and backward sweeps of every slot): zeroed ONCE per step by prepack();
+    without that reset (a slot called on its own) it simply keeps handing out fresh zeroed slices."""
+    p = _STEP_POOLS.get(device)
+    if p is None:
+        p = _STEP_POOLS[device] = ZeroPool(device, 1 << 16)
+    return p
+
 
 def bn_stats(y, n, c, groups=1, pool=None):
     sums = torch.zeros(groups * 2 * c, device=y.device, dtype=torch.float64) if pool is None else pool.take(groups * 2 * c)
@@ -87,13 +104,11 @@ def bn_relu_backward(dz, y, aux, gamma, n, c, groups=1, pool=None):
     _abi("mdf_bn_relu_bwd_reduce", (dz.data_ptr(), y.data_ptr(), aux.data_ptr(), n, c, groups, red.data_ptr(), _stream(y)),
          tag=f"bwd-reduce C{c} N{n}x{groups}", work={"bytes": 8.0 * n * c * groups, "bound": "hbm"})
     dy = torch.empty_like(y)
-    dgamma = torch.empty(groups * c, device=y.device, dtype=torch.float32)
-    dbeta = torch.empty(groups * c, device=y.device, dtype=torch.float32)
+    dgamma = torch.empty(c, device=y.device, dtype=torch.float32)
+    dbeta = torch.empty(c, device=y.device, dtype=torch.float32)
     _abi("mdf_bn_relu_bwd", (dz.data_ptr(), y.data_ptr(), aux.data_ptr(), red.data_ptr(), gamma.data_ptr(), n, c, groups, dy.data_ptr(),
                              dgamma.data_ptr(), dbeta.data_ptr(), _stream(y)),
          tag=f"bwd C{c} N{n}x{groups}", work={"bytes": 12.0 * n * c * groups, "bound": "hbm"})
-    if groups > 1:
-        dgamma, dbeta = dgamma.view(groups, c).sum(0), dbeta.view(groups, c).sum(0)
     return dy, dgamma, dbeta
 
 
@@ -170,7 +185,7 @@ class Tape:
 
     def layer(self, conv, bn, x, res):
         if self.pool is None:
-            self.pool = ZeroPool(x.device)
+            self.pool = step_pool(x.device)
         tr = isinstance(conv, torch.nn.ConvTranspose3d)
         stride = conv.stride[0]
         wp = ops_pack_fwd(conv, tr)
@@ -185,7 +200,7 @@ class Tape:
         """grads: {id(tensor): gradient} holding the gradient of the last layer's output; returns parameter grads
         {param: grad} and leaves the input gradients in `grads`."""
         pg = {}
-        pool = ZeroPool(self.layers[0][4].device)
+        pool = step_pool(self.layers[0][4].device)
         for conv, bn, tr, stride, x, y, aux, res, z in reversed(self.layers):
             dz = grads.pop(id(z))
             if res is not None:
@@ -263,9 +278,18 @@ def _agg_call(pass_, ref, srcs, proj, hyp, pp, par, red_in, dcost, cost, wsum, r
 
 class AggregateTrainFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, module, proj, hypos, cw, gamma, beta, w2, b2, *features):
+    def forward(ctx, module, proj, hypos, cw, gamma, beta, w2, b2, nviews, *features):
+        """features: one [B,C,h,w] tensor per view -- or (nviews > 0) ONE view-major tensor [nviews*B,C,h,w] holding them all
+        (FPN_4Scales.forward_views), whose gradient is then returned as one tensor too: no slice / zero-fill / add launches
+        of the autograd engine around the slot."""
         bn = module.depth_weight[0].bn
-        feas = [ops.nhwc(f.detach()).permute(0, 2, 3, 1).contiguous() for f in features]      # [B,h,w,C] memory
+        ctx.batched = nviews > 0
+        if ctx.batched:
+            allv = ops.nhwc(features[0].detach()).permute(0, 2, 3, 1).contiguous()              # [V*B,h,w,C] memory
+            bb = allv.shape[0] // nviews
+            feas = [allv[v * bb:(v + 1) * bb] for v in range(nviews)]
+        else:
+            feas = [ops.nhwc(f.detach()).permute(0, 2, 3, 1).contiguous() for f in features]  # [B,h,w,C] memory
         b, h, w, c = feas[0].shape
         g = module.ngroups
         d = hypos.shape[1]
@@ -311,25 +335,31 @@ class AggregateTrainFn(torch.autograd.Function):
         dcw = acc[nsrc * nhalf:]
         _agg_call(_PASS_BWD_REDUCE, feas[0], feas[1:], ctx.proj, ctx.hyp, ctx.pp, ctx.par, None, dc, ctx.cost, ctx.wsum, red, None, None,
                   None, b, c, g, d, h, w)
-        dref = torch.empty_like(feas[0])
+        dall = torch.empty((nsrc + 1, b, h, w, c), device=dev, dtype=torch.float32)                # reference view first
+        dref, dfull = dall[0], dall[1:]
         _agg_call(_PASS_BWD, feas[0], feas[1:], ctx.proj, ctx.hyp, ctx.pp, ctx.par, red, dc, ctx.cost, ctx.wsum, None, dref, dhalf, dcw,
                   b, c, g, d, h, w)
-        dfull = torch.empty((nsrc, b, h, w, c), device=dev, dtype=torch.float32)
         dpar = torch.empty(4, device=dev, dtype=torch.float32)
         _abi("mdf_aggregate_train_bwd_finalize", (acc.data_ptr(), red.data_ptr(), nsrc, nsrc * nhalf, dfull.data_ptr(), dpar.data_ptr(),
                                                   _stream(dfull)), tag=f"pairs {nsrc}x{h}x{w}x{c}",
              work={"bytes": 12.0 * nsrc * nhalf, "bound": "hbm"})
         s_cw, s_gamma, s_beta, s_w2, s_b2 = ctx.wshapes
-        dfeas = [dref.permute(0, 3, 1, 2)] + [dfull[v].permute(0, 3, 1, 2) for v in range(nsrc)]
+        if ctx.batched:
+            dfeas = [dall.view((nsrc + 1) * b, h, w, c).permute(0, 3, 1, 2)]
+        else:
+            dfeas = [dall[v].permute(0, 3, 1, 2) for v in range(nsrc + 1)]
         ctx.cost = ctx.wsum = None
         return (None, None, None, dcw.reshape(s_cw), dpar[0].reshape(s_gamma), dpar[1].reshape(s_beta), dpar[2].reshape(s_w2),
-                dpar[3].reshape(s_b2)) + tuple(dfeas)
+                dpar[3].reshape(s_b2), None) + tuple(dfeas)
 
 
 def aggregate_train(module, features, proj, hypos):
     head = module.depth_weight
-    return AggregateTrainFn.apply(module, proj, hypos, head[0].conv.weight, head[0].bn.weight, head[0].bn.bias, head[1].weight, head[1].bias,
-                                  *features)
+    args = (module, proj, hypos, head[0].conv.weight, head[0].bn.weight, head[0].bn.bias, head[1].weight, head[1].bias)
+    parents = [getattr(f, "_mdf_parent", None) for f in features]
+    if all(p is not None and p[0] is parents[0][0] and p[1] == i and p[2] == len(features) for i, p in enumerate(parents)):
+        return AggregateTrainFn.apply(*args, len(features), parents[0][0])      # the views are the slices of one view-major tensor
+    return AggregateTrainFn.apply(*args, 0, *features)
 
 
 # --------------------------------------------------------------------------- feature-pyramid trunk (2-D) in training mode
@@ -404,7 +434,7 @@ class Tape2D:
         k, stride = conv.kernel_size[0], conv.stride[0]
         from .layers import cache_of_key
         if self.pool is None:
-            self.pool = ZeroPool(x.device)
+            self.pool = step_pool(x.device)
         wp = cache_of_key(conv, "fwd").get((conv.weight,), lambda: ops.pack_conv2d_weight(conv.weight))
         y = ops.conv2d_nhwc(x, wp, conv.in_channels, conv.out_channels, k, stride, planar_in=planar_in)        # raw conv
         c = conv.out_channels
@@ -415,7 +445,7 @@ class Tape2D:
 
     def backward(self, grads):
         pg = {}
-        pool = ZeroPool(self.layers[0][3].device)
+        pool = step_pool(self.layers[0][3].device)
         for conv, bn, x, y, aux, z, is_input in reversed(self.layers):
             dz = grads.pop(id(z))
             c = conv.out_channels
@@ -588,6 +618,7 @@ def prepack(model):
     if plan is None or not plan.valid():
         plan = model.__dict__["_mdf_pack_plan"] = PackPlan(model)
     plan.run()
+    step_pool(plan.device).reset()
 
 
 # --------------------------------------------------------------------------- FPN heads (1x1 convs + top-down adds) in training mode
@@ -638,7 +669,7 @@ class FPNHeadsTrainFn(torch.autograd.Function):
             return torch.zeros_like(like) if g is None else ops.to_nhwc(g)
         dy4, dy3, dy2 = nh(dy4, t4n), ops.to_nhwc(dy3) if dy3 is not None else None, ops.to_nhwc(dy2) if dy2 is not None else None
         pg = {}
-        pool = ZeroPool(t2n.device, 1024)
+        pool = step_pool(t2n.device)
 
         def bias_grad(g):
             c = g.shape[-1]

@@ -92,8 +92,14 @@ class FPN_4Scales(nn.Module):
         from mdfnet_hip import train_ops
         b, v = imgs.shape[:2]
         x = imgs.transpose(0, 1).reshape(v * b, *imgs.shape[2:])           # view-major: group g = view g
-        y4, y3, y2 = self._heads(*train_ops.trunk_train(self, x, groups=v))
-        return [(y4[g * b:(g + 1) * b], y3[g * b:(g + 1) * b], y2[g * b:(g + 1) * b]) for g in range(v)]
+        ys = self._heads(*train_ops.trunk_train(self, x, groups=v))
+        out = []
+        for g in range(v):
+            trip = tuple(y[g * b:(g + 1) * b] for y in ys)
+            for t, y in zip(trip, ys):
+                t._mdf_parent = (y, g, v)        # lets the aggregation slot take (and return the gradient of) the whole tensor at once
+            out.append(trip)
+        return out
 
     def forward(self, x: torch.Tensor):
         """[B,3,H,W] -> (1/8: 64ch, 1/4: 32ch, 1/2: 16ch)   (backbone.py:50-66)."""

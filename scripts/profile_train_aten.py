@@ -24,8 +24,9 @@ def step():
     bucket.zero_grad(); loss.backward(); bucket.allreduce_gradients(); opt.step()
 
 
-VIEW_OPS = ("view", "permute", "transpose", "reshape", "slice", "select", "detach", "alias", "expand", "unsqueeze", "squeeze", "as_strided",
-            "t.default", "unbind", "split", "_unsafe_view", "empty", "is_", "sym_", "stride", "size", "_version", "numel", "dim", "unfold")
+VIEW_OPS = {"view", "permute", "transpose", "reshape", "slice", "select", "detach", "alias", "expand", "unsqueeze", "squeeze", "as_strided",
+            "t", "unbind", "split", "_unsafe_view", "empty", "empty_like", "empty_strided", "new_empty", "is_same_size", "sym_size", "sym_stride",
+            "sym_numel", "unfold", "_reshape_alias", "view_as", "split_with_sizes", "narrow", "lift_fresh", "_local_scalar_dense"}
 counts = collections.Counter()
 
 
@@ -36,7 +37,10 @@ class Rec(TorchDispatchMode):
         for a in args:
             if isinstance(a, (list, tuple)):
                 flat += [t for t in a if isinstance(t, torch.Tensor)]
-        if any(t.is_cuda for t in flat) and not any(v in name for v in VIEW_OPS):
+        base = name.replace("aten.", "").split(".")[0]
+        dev_kw = (kwargs or {}).get("device")
+        on_gpu = any(t.is_cuda for t in flat) or (dev_kw is not None and "cuda" in str(dev_kw))
+        if on_gpu and base not in VIEW_OPS:
             frame = "?"
             for fs in reversed(traceback.extract_stack()):
                 fn = fs.filename
