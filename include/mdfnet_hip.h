@@ -280,6 +280,18 @@ int mdf_aggregate_train_finalize(const double* red, const float* gamma, const fl
 int mdf_aggregate_train_bwd_finalize(const float* dhalf, const double* red, int n_src, long long n_half, float* dsrc,
                                      float* dpar, void* stream);
 
+/* ---- training loss (net/loss.py:10-27): sum over the output scales of smooth-L1 (beta 1, mean) over the pixels with
+ *      gt > depth_min[b].  est, gt [B][per_batch] float; depth_min element b at floor_[b*floor_stride], float64 when
+ *      floor_f64 (as the loader hands depth_range over) else float32.
+ *   reduce    acc[0] += sum of the per-pixel losses, acc[1] += number of valid pixels      (fp64, zeroed by the caller)
+ *   finalize  loss[0] = sum_s acc[2s]/acc[2s+1] over nscales scales; inv_count[s] = 1/acc[2s+1]
+ *   bwd       dest = dloss[0] * inv_count[0] * clamp(est - gt, -1, 1) on valid pixels, 0 elsewhere                    */
+int mdf_masked_smooth_l1_reduce(const float* est, const float* gt, const void* floor_, int floor_f64, int floor_stride, int B,
+                                long long per_batch, double* acc, void* stream);
+int mdf_masked_smooth_l1_finalize(const double* acc, int nscales, float* loss, float* inv_count, void* stream);
+int mdf_masked_smooth_l1_bwd(const float* est, const float* gt, const void* floor_, int floor_f64, int floor_stride, int B,
+                             long long per_batch, const float* dloss, const float* inv_count, float* dest, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

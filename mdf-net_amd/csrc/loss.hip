@@ -1,0 +1,108 @@
+// Training loss on the device (net/loss.py:10-27): sum over the output scales of smooth-L1 (beta = 1, mean) over the pixels
+// with gt > depth_min.  As torch expressions this is ~55 tiny launches per step (mask, boolean-free masked mean, the same
+// backwards) on a step that is bound by launch count; here: one reduction launch per scale, one finalize, one backward
+// launch per scale.
+#include "common.h"
+
+namespace {
+
+constexpr int kT = 256;
+
+// depth_min arrives as the loader made it (float64, load/dtutrain.py) or as float32; `gt > depth_min` promotes to the wider type
+__device__ __forceinline__ double load_floor(const void* p, int is_f64, long long i) {
+  return is_f64 ? static_cast<const double*>(p)[i] : (double)static_cast<const float*>(p)[i];
+}
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// acc[0] += sum of smooth_l1(e - gt) over valid pixels, acc[1] += number of valid pixels
+__global__ __launch_bounds__(kT) void masked_smooth_l1_reduce_kernel(const float* __restrict__ e, const float* __restrict__ gt,
+                                                                     const void* __restrict__ floor_, int floor_f64, int floor_stride,
+                                                                     long long per_batch, double* __restrict__ acc) {
+  __shared__ double sh[4];
+  const int b = blockIdx.y;
+  const double fl = load_floor(floor_, floor_f64, (long long)b * floor_stride);
+  const float* eb = e + (long long)b * per_batch;
+  const float* gb = gt + (long long)b * per_batch;
+  double s = 0.0, c = 0.0;
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < per_batch; i += (long long)gridDim.x * kT) {
+    const float g = gb[i];
+    if ((double)g > fl) {
+      const float d = eb[i] - g, a = fabsf(d);
+      s += (double)(a < 1.0f ? 0.5f * d * d : a - 0.5f);
+      c += 1.0;
+    }
+  }
+  s = block_sum(s, sh);
+  c = block_sum(c, sh);
+  if (threadIdx.x == 0) {
+    atomicAdd(&acc[0], s);
+    atomicAdd(&acc[1], c);
+  }
+}
+
+// loss = sum_s acc[2s] / acc[2s+1];  inv_count[s] = 1 / acc[2s+1] (for the backward launches)
+__global__ void masked_smooth_l1_finalize_kernel(const double* __restrict__ acc, int nscales, float* __restrict__ loss, float* __restrict__ inv_count) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float total = 0.f;
+  for (int s = 0; s < nscales; ++s) {
+    total += (float)(acc[2 * s] / acc[2 * s + 1]);      // each scale's mean rounded to fp32, then added: torch's order (loss.py:19-25)
+    inv_count[s] = (float)(1.0 / acc[2 * s + 1]);
+  }
+  loss[0] = total;
+}
+
+// de = dloss * inv_count * clamp(e - gt, -1, 1) on valid pixels, 0 elsewhere
+__global__ __launch_bounds__(kT) void masked_smooth_l1_bwd_kernel(const float* __restrict__ e, const float* __restrict__ gt,
+                                                                  const void* __restrict__ floor_, int floor_f64, int floor_stride,
+                                                                  long long per_batch, const float* __restrict__ dloss,
+                                                                  const float* __restrict__ inv_count, float* __restrict__ de) {
+  const int b = blockIdx.y;
+  const double fl = load_floor(floor_, floor_f64, (long long)b * floor_stride);
+  const float scale = dloss[0] * inv_count[0];
+  const long long off = (long long)b * per_batch;
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < per_batch; i += (long long)gridDim.x * kT) {
+    const float g = gt[off + i];
+    const float d = e[off + i] - g;
+    de[off + i] = ((double)g > fl) ? scale * fminf(fmaxf(d, -1.0f), 1.0f) : 0.0f;
+  }
+}
+
+int grid_x(long long per_batch) {
+  long long g = (per_batch + 4 * kT - 1) / (4 * kT);
+  return (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
+}
+
+}  // namespace
+
+extern "C" int mdf_masked_smooth_l1_reduce(const float* est, const float* gt, const void* floor_, int floor_f64, int floor_stride, int B,
+                                           long long per_batch, double* acc, void* stream) {
+  MDF_REQUIRE(est && gt && floor_ && acc, "null pointer argument");
+  MDF_REQUIRE(B > 0 && B <= 65535 && per_batch > 0 && floor_stride >= 0, "bad shape");
+  hipLaunchKernelGGL(masked_smooth_l1_reduce_kernel, dim3(grid_x(per_batch), B), dim3(kT), 0, (hipStream_t)stream, est, gt, floor_, floor_f64,
+                     floor_stride, per_batch, acc);
+  return mdf::check_launch("masked_smooth_l1_reduce_kernel");
+}
+
+extern "C" int mdf_masked_smooth_l1_finalize(const double* acc, int nscales, float* loss, float* inv_count, void* stream) {
+  MDF_REQUIRE(acc && loss && inv_count && nscales >= 1 && nscales <= 64, "bad argument");
+  hipLaunchKernelGGL(masked_smooth_l1_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc, nscales, loss, inv_count);
+  return mdf::check_launch("masked_smooth_l1_finalize_kernel");
+}
+
+extern "C" int mdf_masked_smooth_l1_bwd(const float* est, const float* gt, const void* floor_, int floor_f64, int floor_stride, int B,
+                                        long long per_batch, const float* dloss, const float* inv_count, float* dest, void* stream) {
+  MDF_REQUIRE(est && gt && floor_ && dloss && inv_count && dest, "null pointer argument");
+  MDF_REQUIRE(B > 0 && B <= 65535 && per_batch > 0 && floor_stride >= 0, "bad shape");
+  hipLaunchKernelGGL(masked_smooth_l1_bwd_kernel, dim3(grid_x(per_batch), B), dim3(kT), 0, (hipStream_t)stream, est, gt, floor_, floor_f64,
+                     floor_stride, per_batch, dloss, inv_count, dest);
+  return mdf::check_launch("masked_smooth_l1_bwd_kernel");
+}

@@ -770,3 +770,55 @@ class RefineTrainFn(torch.autograd.Function):
 
 def refine_train(module, depth, lo, span):
     return RefineTrainFn.apply(module, depth, lo, span, *tuple(module.parameters()))
+
+
+# --------------------------------------------------------------------------- training loss
+class LossTrainFn(torch.autograd.Function):
+    """net/loss.py:10-27 on the device: (depth_min [B], est_0, gt_0, est_1, gt_1, ...) -> scalar loss."""
+
+    @staticmethod
+    def forward(ctx, floor, *pairs):
+        ests = [_f32c(t.detach()) for t in pairs[0::2]]
+        gts = [_f32c(t.detach()) for t in pairs[1::2]]
+        ns = len(ests)
+        dev = ests[0].device
+        b = ests[0].shape[0]
+        fl = floor.detach()
+        if fl.dtype not in (torch.float32, torch.float64):
+            fl = fl.float()
+        f64, fstride = int(fl.dtype == torch.float64), fl.stride(0) if fl.dim() > 0 else 0
+        acc = step_pool(dev).take(2 * ns)
+        st = _stream(ests[0])
+        for s_, (e, g) in enumerate(zip(ests, gts)):
+            assert e.shape == g.shape and e.shape[0] == b, (e.shape, g.shape)
+            _abi("mdf_masked_smooth_l1_reduce", (e.data_ptr(), g.data_ptr(), fl.data_ptr(), f64, fstride, b, e.numel() // b,
+                                                 acc[2 * s_:].data_ptr(), st), tag=f"loss {tuple(e.shape)}",
+                 work={"bytes": 8.0 * e.numel(), "bound": "hbm"})
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        inv = torch.empty(ns, device=dev, dtype=torch.float32)
+        _abi("mdf_masked_smooth_l1_finalize", (acc.data_ptr(), ns, loss.data_ptr(), inv.data_ptr(), st))
+        ctx.saved = (ests, gts, fl, f64, fstride, inv)
+        ctx.needs = [pairs[2 * i].requires_grad for i in range(ns)]
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        ests, gts, fl, f64, fstride, inv = ctx.saved
+        dl = _f32c(dloss)
+        out = [None]
+        for s_, (e, g) in enumerate(zip(ests, gts)):
+            de = None
+            if ctx.needs[s_]:
+                de = torch.empty_like(e)
+                b = e.shape[0]
+                _abi("mdf_masked_smooth_l1_bwd", (e.data_ptr(), g.data_ptr(), fl.data_ptr(), f64, fstride, b, e.numel() // b, dl.data_ptr(),
+                                                  inv[s_:].data_ptr(), de.data_ptr(), _stream(de)), tag=f"loss bwd {tuple(e.shape)}",
+                     work={"bytes": 12.0 * e.numel(), "bound": "hbm"})
+            out += [de, None]
+        ctx.saved = None
+        return tuple(out)
+
+
+def loss_train(floor, pairs):
+    flat = [t for pr in pairs for t in pr]
+    return LossTrainFn.apply(floor, *flat)

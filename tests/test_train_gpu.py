@@ -452,3 +452,33 @@ def test_batched_weight_packing_equals_the_per_layer_packs(seeded_sd):
     conv = next(m for m in model.Regular[0].modules() if isinstance(m, nn.Conv3d))
     got = cache_of_key(conv, "fwd").get((conv.weight,), lambda: pytest.fail("cache missed after PackPlan.run"))
     assert got.data_ptr() in {j[1].data_ptr() for j in plan.jobs}
+
+
+@pytest.mark.parametrize("range_dtype", [torch.float64, torch.float32])
+def test_fused_loss_value_and_gradient(range_dtype):
+    """net/loss.py on the GPU (csrc/loss.hip: one reduction per scale, one finalize, one backward launch per scale) against
+    the reference formulation (boolean-indexed smooth-L1 means, loss.py:19-25) on the CPU."""
+    from net import loss as loss_mod
+    torch.manual_seed(7)
+    b = 2
+    ests, gts = [], {}
+    for k, (h, w) in zip(("3", "2", "1", "0"), ((9, 12), (18, 24), (36, 48), (72, 96))):
+        gt = torch.rand(b, h, w) * 500 + 300
+        gt[:, : h // 3] = 0.0                      # invalid region (gt <= depth_min)
+        est = gt + torch.randn(b, h, w) * 1.5      # both branches of smooth-L1
+        ests.append(est)
+        gts[k] = gt
+    dr = torch.tensor([[425.0, 935.0], [300.0 + 1e-7, 900.0]], dtype=range_dtype)
+    gts["3"][1, -1, -1] = float(dr[1, 0].float())  # a gt that sits exactly at depth_min rounded to fp32
+    crit = loss_mod.Loss()
+    e_cpu = [e.clone().requires_grad_(True) for e in ests]
+    ref = crit({"depth": e_cpu}, gts, dr)
+    ref.backward()
+    e_gpu = [e.to(DEV).requires_grad_(True) for e in ests]
+    got = crit({"depth": e_gpu}, {k: v.to(DEV) for k, v in gts.items()}, dr.to(DEV))
+    assert got.shape == () and got.dtype == torch.float32
+    got.backward()
+    assert abs(float(got) - float(ref)) <= 2e-6 * abs(float(ref))
+    for a, r in zip(e_gpu, e_cpu):
+        assert torch.equal(a.grad.cpu() != 0, r.grad != 0)                      # the same valid mask
+        assert _rel(a.grad, r.grad) <= 2e-6
