@@ -970,6 +970,7 @@ int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha
   // 3-D regulariser layers (stride 1)
   LDS_CASE(32, 32, 16, 3, 3, 1, 2) LDS_CASE(16, 16, 16, 3, 3, 1, 4) LDS_CASE(16, 16, 8, 3, 3, 1, 4) LDS_CASE(8, 8, 8, 3, 3, 1, 4)
   LDS_CASE(32, 32, 32, 3, 3, 1, 2)
+  LDS_CASE(16, 16, 32, 3, 3, 1, 2) LDS_CASE(8, 8, 16, 3, 3, 1, 4)      // input gradients of the regularisers' first layers (training)
   // 2-D layers of the feature pyramid / refinement (KD = 1)
   LDS_CASE(4, 3, 8, 1, 3, 1, 4) LDS_CASE(8, 8, 8, 1, 3, 1, 4) LDS_CASE(16, 16, 16, 1, 3, 1, 4) LDS_CASE(32, 32, 32, 1, 3, 1, 2)
   LDS_CASE(64, 64, 64, 1, 3, 1, 1)

@@ -44,7 +44,7 @@ def test_conv3d_layer(cin, cout, mode, shape):
     np.testing.assert_allclose(ops.from_ndhwc(y2).cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize("cin,cout", [(32, 16), (16, 16), (32, 32), (16, 8), (8, 8)])
+@pytest.mark.parametrize("cin,cout", [(32, 16), (16, 16), (32, 32), (16, 8), (8, 8), (16, 32), (8, 16)])
 @pytest.mark.parametrize("shape", [(1, 6, 130, 201), (2, 5, 125, 131), (1, 3, 260, 197), (1, 90, 5, 401), (1, 2, 3, 25001), (1, 1, 400, 400)])
 def test_conv3d_layer_lds_kernels(cin, cout, shape):
     """Volumes of >= 150 000 voxels take the LDS-staged kernels (conv_lds.hip; Cout = 8 in the w-phase form): ragged tiles
