@@ -256,7 +256,7 @@ int mdf_prob_conv_dgrad(const float* dlogit, const float* w, float* dx, int B, i
  *        0 stats       red_out[2v], [2v+1] += sum t_v, sum t_v^2  (t_v = Conv3d(G->1)(sim_v); fp64, zeroed by caller)
  *        1 forward     cost [B,D,h,w,G] and wsum [B,D,h,w] = sum_v w_v, with per-view (alpha_v, beta_v) from `par`
  *        2 bwd-reduce  red_out[2v], [2v+1] += sum dz_v, sum dz_v*xhat_v; red_out[2n], [2n+1] += d w2, d b2
- *        3 backward    dref [B,h,w,C] (stored), dsrc[v] [B,h,w,G] (+= by fp32 atomics; zeroed by caller; the gradient of
+ *        3 backward    dref [B,h,w,C] (+=; zeroed by caller), dsrc[v] [B,h,w,G] (+= by fp32 atomics; zeroed by caller; the gradient of
  *                      channel 2g of every softmax pair -- channel 2g+1 gets its negative), dcw[G] (+=)
  *      par (float): [0,G) conv weight | G: w2 | G+1: b2 | G+2: gamma | G+3: 1/N | G+4+4v: alpha_v, beta_v, mean_v,
  *      invstd_v.  Features NHWC, C in {16,32,64}, G = C/2.                                                        */
@@ -271,14 +271,15 @@ int mdf_warp_aggregate_vec_train(int pass, const float* ref_fea, const float* co
  *   finalize      after pass 0: par[G+4+4v..] = (alpha_v, beta_v, mean_v, invstd_v) from red; running_mean / running_var /
  *                 num_batches_tracked (any may be NULL) advanced as by n_src successive calls with `momentum`
  *   bwd_finalize  after pass 3: dsrc [n_src][B,h,w,C] from the even-channel gradients dhalf [n_src][B,h,w,G] (n_half = their
- *                 total element count), and dpar = (d gamma, d beta, d w2, d b2) from pass 2's red                      */
+ *                 total element count), and dpar = (d gamma, d beta, d w2, d b2) from pass 2's red; when dref_acc is given,
+ *                 its n_ref floats (the zero-initialised buffer pass 3 accumulated d ref into) are copied to dref           */
 int mdf_aggregate_train_prepare(const float* cw, const float* w2, const float* b2, const float* gamma, long long n, int G,
                                 int n_src, float* par, double* red, int nred, void* stream);
 int mdf_aggregate_train_finalize(const double* red, const float* gamma, const float* beta, float eps, float momentum, long long n,
                                  int G, int n_src, float* par, float* running_mean, float* running_var,
                                  long long* num_batches_tracked, void* stream);
 int mdf_aggregate_train_bwd_finalize(const float* dhalf, const double* red, int n_src, long long n_half, float* dsrc,
-                                     float* dpar, void* stream);
+                                     float* dpar, const float* dref_acc, float* dref, long long n_ref, void* stream);
 
 /* ---- training loss (net/loss.py:10-27): sum over the output scales of smooth-L1 (beta 1, mean) over the pixels with
  *      gt > depth_min[b].  est, gt [B][per_batch] float; depth_min element b at floor_[b*floor_stride], float64 when

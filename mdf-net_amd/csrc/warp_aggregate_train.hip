@@ -14,6 +14,7 @@
 // pixel reduce with DPP row operations, sample positions are computed once per (pixel, plane, view) into an LDS table.
 //
 // par (float):  [0,G) conv weight | G: w2, G+1: b2, G+2: gamma, G+3: 1/N | G+4+4v..: alpha_v, beta_v, mean_v, invstd_v
+#include <cstdlib>
 #include "warp_common.h"
 
 namespace {
@@ -36,6 +37,7 @@ struct TrainParams {
   float* dcw;             // [G], zero-initialised
   Geom g;
   int B, D, n_src, hypos_per_pixel, dchunk, nblk_x;
+  int dslice;             // planes per blockIdx.z (the depth range is cut into gridDim.z slices: more blocks for the small cfg3 maps)
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -81,8 +83,9 @@ __global__ __launch_bounds__(kThreads) void warp_train_kernel(const TrainParams 
   const int nred = (PASS == kStats) ? 2 * p.n_src : 2 * p.n_src + 2;
   double total = 0.0;                 // thread k < nred: block total of reduction slot k
 
-  for (int d0 = 0; d0 < p.D; d0 += p.dchunk) {
-    const int nd = min(p.dchunk, p.D - d0);
+  const int dlo = blockIdx.z * p.dslice, dhi = min(p.D, dlo + p.dslice);
+  for (int d0 = dlo; d0 < dhi; d0 += p.dchunk) {
+    const int nd = min(p.dchunk, dhi - d0);
     const int nent = nd * p.n_src * PPB;
     for (int e = tid; e < nent; e += kThreads) {
       const int epl = e % PPB;
@@ -201,6 +204,15 @@ __global__ __launch_bounds__(kThreads) void warp_train_kernel(const TrainParams 
 // tap; a block whose footprint does not fit (strong rotation, very wide depth range) scatters to memory directly.
 constexpr int kWinFloats = 8192;   // 32 KiB
 
+// LDS float add through an address-space-3 pointer: `ds_add_f32` (with a generic pointer next to the global fallback the
+// compiler merges both branches into one `flat_atomic_add_f32` on a selected 64-bit address).  Measured by ablation at cfg3:
+// these adds are 0.69 of the kernel's 1.27 ms per step -- an LDS float atomic retires about one LANE per clock per CU (450 M
+// lane-adds per step), whatever the bank layout (padding the texel stride changed nothing); the same updates as plain
+// read-add-write cost 0.11 ms.  Making them plain needs per-wave windows plus a per-instruction duplicate-texel check.
+__device__ __forceinline__ void lds_add(float* p, float v) {
+  (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <int C>
 __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p) {
   constexpr int LPP = C / 4;
@@ -238,8 +250,9 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
   float gref0 = 0.f, gref1 = 0.f;     // d sim/d p0 accumulated over planes and views
   float dcw0 = 0.f, dcw1 = 0.f;       // d conv weight of this lane's two groups
 
-  for (int d0 = 0; d0 < p.D; d0 += p.dchunk) {
-    const int nd = min(p.dchunk, p.D - d0);
+  const int dlo = blockIdx.z * p.dslice, dhi = min(p.D, dlo + p.dslice);
+  for (int d0 = dlo; d0 < dhi; d0 += p.dchunk) {
+    const int nd = min(p.dchunk, dhi - d0);
     if (tid < 4 * p.n_src) bb[tid >> 2][tid & 3] = (tid & 1) ? INT32_MIN : INT32_MAX;
     __syncthreads();
     const int nent = nd * p.n_src * PPB;
@@ -294,8 +307,8 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
             const int tx = (k & 1) ? xb : xa, ty = (k & 2) ? yb : ya;
             if (use_win) {
               float* o = win + ((ty - ymin) * ww + (tx - xmin)) * G + 2 * sub;
-              atomicAdd(o, a0);
-              atomicAdd(o + 1, a1);
+              lds_add(o, a0);
+              lds_add(o + 1, a1);
             } else {
               float* o = gp + (size_t)(ty * W + tx) * G;
               unsafeAtomicAdd(o, a0);
@@ -378,7 +391,12 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
   if (live) {
     const float p1a = r[1], p0a = 1.0f - r[1], p1b = r[3], p0b = 1.0f - r[3];
     const float ga = gref0 * p0a * p1a, gb = gref1 * p0b * p1b;
-    *reinterpret_cast<float4*>(p.dref + ((size_t)b * hw + pix) * C + 4 * sub) = make_float4(ga, -ga, gb, -gb);
+    float* o = p.dref + ((size_t)b * hw + pix) * C + 4 * sub;      // zero-initialised: the depth slices of a pixel meet here
+    if (gridDim.z == 1) {
+      *reinterpret_cast<float4*>(o) = make_float4(ga, -ga, gb, -gb);
+    } else {
+      unsafeAtomicAdd(o, ga); unsafeAtomicAdd(o + 1, -ga); unsafeAtomicAdd(o + 2, gb); unsafeAtomicAdd(o + 3, -gb);
+    }
   }
   dcw_sm[tid][0] = dcw0;
   dcw_sm[tid][1] = dcw1;
@@ -390,16 +408,33 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
   }
 }
 
+// A block walks its pixels over the planes one (plane, view) at a time, each step a dependent gather: with the few blocks of a
+// cfg3-sized map (432 at 72x96x64ch) the chip holds < 2 waves per SIMD and the kernel is latency-bound.  Cut the depth range
+// into slices (gridDim.z) until there are a few thousand blocks; per-pixel results that span the planes (d ref) meet through atomics.
+int depth_slices(TrainParams& p, int& dch) {
+  static const int target = [] { const char* e = getenv("MDF_WARP_TRAIN_BLOCKS"); return (e && atoi(e) > 0) ? atoi(e) : 2048; }();   // dev A/B
+  const long long blocks = (long long)p.nblk_x * p.B;
+  int nz = (int)((target + blocks - 1) / blocks);
+  if (nz > p.D / 4) nz = p.D / 4;          // >= 4 planes per slice: a slice re-reads the reference features and the tap setup
+  if (nz < 1) nz = 1;
+  p.dslice = (p.D + nz - 1) / nz;
+  nz = (p.D + p.dslice - 1) / p.dslice;
+  if (dch > p.dslice) dch = p.dslice;
+  const int nch = (p.dslice + dch - 1) / dch;   // equal chunks inside a slice
+  dch = (p.dslice + nch - 1) / nch;
+  return nz;
+}
+
 int launch_bwd(TrainParams& p, int C, hipStream_t st) {
   const int lpp = C / 4, ppb = kThreads / lpp;
   const int hw = p.g.h * p.g.w;
   p.nblk_x = (hw + ppb - 1) / ppb;
   int dch = 512 / (p.n_src * ppb);
   if (dch < 1) dch = 1;
-  if (dch > p.D) dch = p.D;
+  const int nz = depth_slices(p, dch);
   p.dchunk = dch;
   const size_t lds = (size_t)dch * p.n_src * ppb * sizeof(TapXY) + (size_t)kWinFloats * sizeof(float);
-  dim3 grid(p.nblk_x, p.B), block(kThreads);
+  dim3 grid(p.nblk_x, p.B, nz), block(kThreads);
   switch (C) {
     case 64: hipLaunchKernelGGL((warp_bwd_kernel<64>), grid, block, lds, st, p); break;
     case 32: hipLaunchKernelGGL((warp_bwd_kernel<32>), grid, block, lds, st, p); break;
@@ -416,10 +451,10 @@ int launch_train(TrainParams& p, int C, hipStream_t st) {
   p.nblk_x = (hw + ppb - 1) / ppb;
   int dch = 512 / (p.n_src * ppb);
   if (dch < 1) dch = 1;
-  if (dch > p.D) dch = p.D;
+  const int nz = depth_slices(p, dch);
   p.dchunk = dch;
   const size_t lds = (size_t)dch * p.n_src * ppb * sizeof(TapEntry);
-  dim3 grid(p.nblk_x, p.B), block(kThreads);
+  dim3 grid(p.nblk_x, p.B, nz), block(kThreads);
   switch (C) {
     case 64: hipLaunchKernelGGL((warp_train_kernel<64, PASS>), grid, block, lds, st, p); break;
     case 32: hipLaunchKernelGGL((warp_train_kernel<32, PASS>), grid, block, lds, st, p); break;
@@ -465,12 +500,14 @@ __global__ void agg_finalize_kernel(const double* red, const float* gamma, const
 // backward epilogue: the scatter accumulated the gradient of the EVEN channel of every softmax pair; the odd channel gets
 // its negative (d softmax pair: dv1 = -dv0).  dpar = (d gamma, d beta, d w2, d b2) from the fp64 reductions.
 __global__ void agg_bwd_finalize_kernel(const float* __restrict__ dhalf, const double* __restrict__ red, int n_src, long long n_half,
-                                        float* __restrict__ dfull, float* __restrict__ dpar) {
+                                        float* __restrict__ dfull, float* __restrict__ dpar, const float* __restrict__ dref_acc,
+                                        float* __restrict__ dref_out, long long n_ref4) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_half) {
     const float v = dhalf[i];
     reinterpret_cast<float2*>(dfull)[i] = make_float2(v, -v);
   }
+  if (dref_acc && i < n_ref4) reinterpret_cast<float4*>(dref_out)[i] = reinterpret_cast<const float4*>(dref_acc)[i];
   if (i == 0) {
     double dg = 0.0, db = 0.0;
     for (int v = 0; v < n_src; ++v) { db += red[2 * v]; dg += red[2 * v + 1]; }
@@ -542,11 +579,14 @@ extern "C" int mdf_aggregate_train_finalize(const double* red, const float* gamm
 }
 
 extern "C" int mdf_aggregate_train_bwd_finalize(const float* dhalf, const double* red, int n_src, long long n_half, float* dsrc,
-                                                float* dpar, void* stream) {
+                                                float* dpar, const float* dref_acc, float* dref, long long n_ref, void* stream) {
   MDF_REQUIRE(dhalf && red && dsrc && dpar, "null pointer argument");
   MDF_REQUIRE(n_half > 0 && n_src >= 1 && n_src <= MDF_MAX_SRC_VIEWS, "bad sizes");
-  const long long blocks = (n_half + 255) / 256;
+  MDF_REQUIRE((dref_acc == nullptr) == (dref == nullptr) && (dref_acc == nullptr || (n_ref > 0 && n_ref % 4 == 0)), "dref_acc / dref / n_ref mismatch");
+  const long long n_ref4 = dref_acc ? n_ref / 4 : 0;
+  const long long blocks = ((n_half > n_ref4 ? n_half : n_ref4) + 255) / 256;
   MDF_REQUIRE(blocks < (1ll << 31), "too many elements");
-  hipLaunchKernelGGL(agg_bwd_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dhalf, red, n_src, n_half, dsrc, dpar);
+  hipLaunchKernelGGL(agg_bwd_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dhalf, red, n_src, n_half, dsrc, dpar,
+                     dref_acc, dref, n_ref4);
   return mdf::check_launch("agg_bwd_finalize_kernel");
 }

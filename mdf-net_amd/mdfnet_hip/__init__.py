@@ -67,7 +67,7 @@ SIGNATURES = {
                                              c_fp, ctypes.POINTER(c_fp), c_fp] + [c_int] * 7 + [c_fp]),
     "mdf_aggregate_train_prepare": (c_int, [c_fp] * 4 + [c_i64, c_int, c_int, c_fp, c_fp, c_int, c_fp]),
     "mdf_aggregate_train_finalize": (c_int, [c_fp] * 3 + [ctypes.c_float, ctypes.c_float, c_i64, c_int, c_int] + [c_fp] * 5),
-    "mdf_aggregate_train_bwd_finalize": (c_int, [c_fp, c_fp, c_int, c_i64, c_fp, c_fp, c_fp]),
+    "mdf_aggregate_train_bwd_finalize": (c_int, [c_fp, c_fp, c_int, c_i64, c_fp, c_fp, c_fp, c_fp, c_i64, c_fp]),
     "mdf_masked_smooth_l1_reduce": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_i64, c_fp, c_fp]),
     "mdf_masked_smooth_l1_finalize": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp]),
     "mdf_masked_smooth_l1_bwd": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_i64, c_fp, c_fp, c_fp, c_fp]),

@@ -328,21 +328,23 @@ class AggregateTrainFn(torch.autograd.Function):
         nhalf = b * h * w * g
         # one zero fill for everything the two passes accumulate into: fp64 reductions | even-channel gradients per view | d conv weight
         nred = 2 * nsrc + 2
-        zero = torch.zeros(8 * nred + 4 * (nsrc * nhalf + g), device=dev, dtype=torch.uint8)
+        nref = b * h * w * c
+        zero = torch.zeros(8 * nred + 4 * (nsrc * nhalf + nref + g), device=dev, dtype=torch.uint8)
         red = zero[:8 * nred].view(torch.float64)
         acc = zero[8 * nred:].view(torch.float32)
         dhalf = [acc[v * nhalf:(v + 1) * nhalf] for v in range(nsrc)]
-        dcw = acc[nsrc * nhalf:]
+        dref_acc = acc[nsrc * nhalf:nsrc * nhalf + nref]            # the depth slices of a pixel add their d ref here
+        dcw = acc[nsrc * nhalf + nref:]
         _agg_call(_PASS_BWD_REDUCE, feas[0], feas[1:], ctx.proj, ctx.hyp, ctx.pp, ctx.par, None, dc, ctx.cost, ctx.wsum, red, None, None,
                   None, b, c, g, d, h, w)
         dall = torch.empty((nsrc + 1, b, h, w, c), device=dev, dtype=torch.float32)                # reference view first
         dref, dfull = dall[0], dall[1:]
-        _agg_call(_PASS_BWD, feas[0], feas[1:], ctx.proj, ctx.hyp, ctx.pp, ctx.par, red, dc, ctx.cost, ctx.wsum, None, dref, dhalf, dcw,
-                  b, c, g, d, h, w)
+        _agg_call(_PASS_BWD, feas[0], feas[1:], ctx.proj, ctx.hyp, ctx.pp, ctx.par, red, dc, ctx.cost, ctx.wsum, None, dref_acc, dhalf,
+                  dcw, b, c, g, d, h, w)
         dpar = torch.empty(4, device=dev, dtype=torch.float32)
         _abi("mdf_aggregate_train_bwd_finalize", (acc.data_ptr(), red.data_ptr(), nsrc, nsrc * nhalf, dfull.data_ptr(), dpar.data_ptr(),
-                                                  _stream(dfull)), tag=f"pairs {nsrc}x{h}x{w}x{c}",
-             work={"bytes": 12.0 * nsrc * nhalf, "bound": "hbm"})
+                                                  dref_acc.data_ptr(), dref.data_ptr(), nref, _stream(dfull)),
+             tag=f"pairs {nsrc}x{h}x{w}x{c}", work={"bytes": 12.0 * nsrc * nhalf + 8.0 * nref, "bound": "hbm"})
         s_cw, s_gamma, s_beta, s_w2, s_b2 = ctx.wshapes
         if ctx.batched:
             dfeas = [dall.view((nsrc + 1) * b, h, w, c).permute(0, 3, 1, 2)]
