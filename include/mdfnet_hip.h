@@ -255,7 +255,8 @@ int mdf_prob_conv_dgrad(const float* dlogit, const float* w, float* dx, int B, i
  *      base.py:97: no gradient through the sampling grid).  pass:
  *        0 stats       red_out[2v], [2v+1] += sum t_v, sum t_v^2  (t_v = Conv3d(G->1)(sim_v); fp64, zeroed by caller)
  *        1 forward     cost [B,D,h,w,G] and wsum [B,D,h,w] = sum_v w_v, with per-view (alpha_v, beta_v) from `par`
- *        2 bwd-reduce  red_out[2v], [2v+1] += sum dz_v, sum dz_v*xhat_v; red_out[2n], [2n+1] += d w2, d b2
+ *        2 bwd-reduce  red_out[2v], [2v+1] += sum dz_v, sum dz_v*xhat_v; red_out[2n], [2n+1] += d w2, d b2; aux [n_src][B*D*h*w][4]
+ *                      = (w_v, dz_v, t_v, -) per sample, which pass 3 reads instead of re-deriving them from all channels
  *        3 backward    dref [B,h,w,C] (+=; zeroed by caller), dsrc[v] [B,h,w,G] (+= by fp32 atomics; zeroed by caller; the gradient of
  *                      channel 2g of every softmax pair -- channel 2g+1 gets its negative), dcw[G] (+=)
  *      par (float): [0,G) conv weight | G: w2 | G+1: b2 | G+2: gamma | G+3: 1/N | G+4+4v: alpha_v, beta_v, mean_v,
@@ -263,8 +264,8 @@ int mdf_prob_conv_dgrad(const float* dlogit, const float* w, float* dx, int B, i
 int mdf_warp_aggregate_vec_train(int pass, const float* ref_fea, const float* const* src_feas, const float* proj,
                                  const float* hypos, int hypos_per_pixel, const float* par, const double* red_in,
                                  const float* dcost, float* cost, float* wsum, double* red_out, float* dref,
-                                 float* const* dsrc, float* dcw, int B, int C, int G, int D, int h, int w, int n_src,
-                                 void* stream);
+                                 float* const* dsrc, float* dcw, float* aux, int B, int C, int G, int D, int h, int w,
+                                 int n_src, void* stream);
 /* Control plane of the passes above, on the device (homoaggregate.py:16-20: the BatchNorm3d(1) of depth_weight, called
  * once per source view, :35-40):
  *   prepare       par[0,G+4) = (conv weight, w2, b2, gamma, 1/n), par[G+4, G+4+4 n_src) = 0, red[0,nred) = 0

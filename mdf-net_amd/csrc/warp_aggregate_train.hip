@@ -35,6 +35,7 @@ struct TrainParams {
   float* dref;            // [B,h,w,C]
   float* dsrc[MDF_MAX_SRC_VIEWS];   // [B,h,w,G]: gradient of the EVEN channel of every group (odd = -even); zero-initialised by the caller
   float* dcw;             // [G], zero-initialised
+  float4* aux;            // [n_src][B*D*h*w] (w_v, dz_v, t_v, -): written by kBwdReduce, read by kBwd
   Geom g;
   int B, D, n_src, hypos_per_pixel, dchunk, nblk_x;
   int dslice;             // planes per blockIdx.z (the depth range is cut into gridDim.z slices: more blocks for the small cfg3 maps)
@@ -139,7 +140,11 @@ __global__ __launch_bounds__(kThreads) void warp_train_kernel(const TrainParams 
             const float du = dwv * wv * (1.0f - wv);
             const float dz = (z > 0.0f) ? du * w2 : 0.0f;
             const float xh = (tt - vpar[4 * v + 2]) * vpar[4 * v + 3];
-            if (owner) { s1 += dz; s2 = fmaf(dz, xh, s2); a3 = fmaf(du, rl, a3); a4 += du; }
+            if (owner) {
+              s1 += dz; s2 = fmaf(dz, xh, s2); a3 = fmaf(du, rl, a3); a4 += du;
+              // the per-sample scalars the scatter pass needs: with them it has no reduction over a pixel's channels left
+              p.aux[(size_t)v * ((size_t)p.B * p.D * hw) + vox] = make_float4(wv, dz, tt, 0.f);
+            }
           }
         }
         s1 = wave_sum(s1);
@@ -205,23 +210,33 @@ __global__ __launch_bounds__(kThreads) void warp_train_kernel(const TrainParams 
 constexpr int kWinFloats = 8192;   // 32 KiB
 
 // LDS float add through an address-space-3 pointer: `ds_add_f32` (with a generic pointer next to the global fallback the
-// compiler merges both branches into one `flat_atomic_add_f32` on a selected 64-bit address).  Measured by ablation at cfg3:
-// these adds are 0.69 of the kernel's 1.27 ms per step -- an LDS float atomic retires about one LANE per clock per CU (450 M
-// lane-adds per step), whatever the bank layout (padding the texel stride changed nothing); the same updates as plain
-// read-add-write cost 0.11 ms.  Making them plain needs per-wave windows plus a per-instruction duplicate-texel check.
+// compiler merges both branches into one `flat_atomic_add_f32` on a selected 64-bit address).
 __device__ __forceinline__ void lds_add(float* p, float v) {
   (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// Thread mapping of the scatter: the four waves of a block split the CHANNELS of the tile's pixels (wave w owns channels
+// [w*C/4, (w+1)*C/4) of all PPB pixels), so two waves never touch the same (texel, channel) of the window, and a lane needs
+// nothing from the other channels of its pixel: the per-sample scalars (view weight, dz, t) come from pass 2 (`aux`).
+// That leaves one hazard for updating the window with plain read-add-write instead of LDS float atomics -- which retire about
+// one LANE per clock per CU (ablation at cfg3: 0.69 of this kernel's 1.27 ms per step were those adds; the same updates as plain
+// ds_read/ds_write cost 0.11 ms): two pixels of ONE wave instruction on the same texel.  For unclamped corners (xb = xa+1,
+// yb = ya+1) the texel of tap k is (xa,ya) + offset_k, so two pixels collide on some tap iff their (xa,ya) agree.  Every
+// flushing pixel writes its id to the per-wave claim byte of its (xa,ya) window texel and reads it back (LDS executes a wave's
+// instructions in order): the pixel whose id survived adds non-atomically; the others on that texel and every pixel with
+// clamped corners use atomic adds, in a separate basic block.
 template <int C>
 __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p) {
-  constexpr int LPP = C / 4;
-  constexpr int PPB = kThreads / LPP;
+  constexpr int LPP = C / 4;            // lanes per pixel over the whole block
+  constexpr int PPB = kThreads / LPP;   // pixels per tile = pixels per wave (every wave sees all of them)
+  constexpr int LW = LPP / 4;           // lanes per pixel inside one wave (4 channels each)
   constexpr int G = C / 2;
+  static_assert(PPB * LW == 64, "a wave holds every pixel of the tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   TapXY* tab = reinterpret_cast<TapXY*>(smem);
   float* win = reinterpret_cast<float*>(smem + (size_t)p.dchunk * p.n_src * PPB * sizeof(TapXY));
   __shared__ int bb[MDF_MAX_SRC_VIEWS][4];   // xmin, xmax, ymin, ymax of the live taps of one view in this chunk
+  __shared__ unsigned char claim[4][kWinFloats / 8];    // one id byte per window texel (G >= 8) and wave
   __shared__ float dcw_sm[kThreads][2];
 
   const int hw = p.g.h * p.g.w;
@@ -230,9 +245,11 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
   const int tile = (int)mdf::xcd_remap(blockIdx.x, p.nblk_x);
   const int pix0 = tile * PPB;
   const int tid = threadIdx.x;
-  const int pl = tid / LPP, sub = tid % LPP;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int pl = lane / LW, sub = wave * LW + lane % LW;    // pixel of the tile, 4-channel slot of the pixel
   const int pix = min(pix0 + pl, hw - 1);
   const bool live = (pix0 + pl) < hw;
+  volatile unsigned char* my_claim = claim[wave];
 
   float r[4];
   {
@@ -243,10 +260,11 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
     r[2] -= r[3];
   }
   const float cw0 = p.par[2 * sub], cw1 = p.par[2 * sub + 1];
-  const float w2 = p.par[G], b2 = p.par[G + 1], gamma = p.par[G + 2], inv_n = p.par[G + 3];
+  const float gamma = p.par[G + 2], inv_n = p.par[G + 3];
   const float* vpar = p.par + G + 4;
   const size_t map_stride = (size_t)hw * C;
   const size_t gmap_stride = (size_t)hw * G;
+  const size_t nvox = (size_t)p.B * p.D * hw;
   float gref0 = 0.f, gref1 = 0.f;     // d sim/d p0 accumulated over planes and views
   float dcw0 = 0.f, dcw1 = 0.f;       // d conv weight of this lane's two groups
 
@@ -294,25 +312,47 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
       }
       const float* sp = p.src[v] + (size_t)b * map_stride + 4 * sub;
       float* gp = p.dsrc[v] + (size_t)b * gmap_stride + 2 * sub;
-      const float s1 = (float)p.red_in[2 * v], s2 = (float)p.red_in[2 * v + 1];
-      const float al = vpar[4 * v], be = vpar[4 * v + 1], mu = vpar[4 * v + 2], is = vpar[4 * v + 3];
+      const float4* ax = p.aux + (size_t)v * nvox;
+      const float s1n = (float)p.red_in[2 * v] * inv_n, s2n = (float)p.red_in[2 * v + 1] * inv_n;
+      const float mu = vpar[4 * v + 2], is = vpar[4 * v + 3];
       float pend0[4] = {0.f, 0.f, 0.f, 0.f}, pend1[4] = {0.f, 0.f, 0.f, 0.f};   // pending tap sums of the current corner set
       int cxa = -1, cxb = -1, cya = -1, cyb = -1;
       auto flush_taps = [&](int xa, int xb, int ya, int yb) {
+        bool plain = false;
+        if (use_win) {
+          const int slot = min(max((ya - ymin) * ww + (xa - xmin), 0), kWinFloats / 8 - 1);   // the window texel of (xa,ya): no false sharing
+          my_claim[slot] = (unsigned char)pl;
+          plain = (my_claim[slot] == (unsigned char)pl) && (xb == xa + 1) && (yb == ya + 1);
+        }
+        float a0[4], a1[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float a0 = pend0[k], a1 = pend1[k];
-          pend0[k] = 0.f; pend1[k] = 0.f;
-          if (a0 != 0.0f || a1 != 0.0f) {      // zero-weight (out-of-bounds) taps never leave the registers
-            const int tx = (k & 1) ? xb : xa, ty = (k & 2) ? yb : ya;
-            if (use_win) {
-              float* o = win + ((ty - ymin) * ww + (tx - xmin)) * G + 2 * sub;
-              lds_add(o, a0);
-              lds_add(o + 1, a1);
-            } else {
-              float* o = gp + (size_t)(ty * W + tx) * G;
-              unsafeAtomicAdd(o, a0);
-              unsafeAtomicAdd(o + 1, a1);
+        for (int k = 0; k < 4; ++k) { a0[k] = pend0[k]; a1[k] = pend1[k]; pend0[k] = 0.f; pend1[k] = 0.f; }
+        if (plain) {          // this pixel owns its texels among the pixels flushing in this instruction
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (a0[k] != 0.0f || a1[k] != 0.0f) {      // zero-weight (out-of-bounds) taps never leave the registers
+              const int tx = (k & 1) ? xb : xa, ty = (k & 2) ? yb : ya;
+              float2* o = reinterpret_cast<float2*>(win + ((ty - ymin) * ww + (tx - xmin)) * G + 2 * sub);
+              float2 cur = *o;
+              cur.x += a0[k]; cur.y += a1[k];
+              *o = cur;
+            }
+            asm volatile("" ::: "memory");   // tap k's write stays ahead of tap k+1's read (a neighbour's tap k+1 may be this texel)
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (a0[k] != 0.0f || a1[k] != 0.0f) {
+              const int tx = (k & 1) ? xb : xa, ty = (k & 2) ? yb : ya;
+              if (use_win) {
+                float* o = win + ((ty - ymin) * ww + (tx - xmin)) * G + 2 * sub;
+                lds_add(o, a0[k]);
+                lds_add(o + 1, a1[k]);
+              } else {
+                float* o = gp + (size_t)(ty * W + tx) * G;
+                unsafeAtomicAdd(o, a0[k]);
+                unsafeAtomicAdd(o + 1, a1[k]);
+              }
             }
           }
         }
@@ -324,6 +364,10 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
         const float4 ne = *reinterpret_cast<const float4*>(sp + (size_t)o1 * C);
         const float4 sw = *reinterpret_cast<const float4*>(sp + (size_t)o2 * C);
         const float4 se = *reinterpret_cast<const float4*>(sp + (size_t)o3 * C);
+        const size_t vox = ((size_t)b * p.D + d0 + dd) * hw + pix;
+        const float4 sc = ax[vox];                                   // (w_v, dz_v, t_v, -)
+        const float2 dc = *reinterpret_cast<const float2*>(p.dcost + vox * G + 2 * sub);
+        const float dn = p.wsum[vox];
         const float v0 = __fmaf_rn(se.x, t.wt[3], __fmaf_rn(sw.x, t.wt[2], __fmaf_rn(ne.x, t.wt[1], __fmul_rn(nw.x, t.wt[0]))));
         const float v1 = __fmaf_rn(se.y, t.wt[3], __fmaf_rn(sw.y, t.wt[2], __fmaf_rn(ne.y, t.wt[1], __fmul_rn(nw.y, t.wt[0]))));
         const float v2 = __fmaf_rn(se.z, t.wt[3], __fmaf_rn(sw.z, t.wt[2], __fmaf_rn(ne.z, t.wt[1], __fmul_rn(nw.z, t.wt[0]))));
@@ -331,22 +375,10 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
         const float q0 = softmax2_p0(v0, v1), q1 = softmax2_p0(v2, v3);
         const float sim0 = __fmaf_rn(q0, r[0], r[1]);
         const float sim1 = __fmaf_rn(q1, r[2], r[3]);
-        const float tt = pixel_sum<LPP>(__fmaf_rn(cw0, sim0, cw1 * sim1));
-        const float z = __fmaf_rn(tt, al, be);
-        const float rl = fmaxf(z, 0.0f);
-        const float u = __fmaf_rn(rl, w2, b2);
-        const float wv = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-u * kLog2e));
-        const size_t vox = ((size_t)b * p.D + d0 + dd) * hw + pix;
-        const float2 dc = *reinterpret_cast<const float2*>(p.dcost + vox * G + 2 * sub);
-        const float2 co = *reinterpret_cast<const float2*>(p.cost + vox * G + 2 * sub);
-        const float dn = p.wsum[vox];
+        const float wv = sc.x, dz = sc.y, tt = sc.z;
         const float dN0 = dc.x / dn, dN1 = dc.y / dn;
-        const float dDn = -pixel_sum<LPP>(__fmaf_rn(dc.x, co.x, dc.y * co.y)) / dn;
-        const float dwv = pixel_sum<LPP>(__fmaf_rn(dN0, sim0, dN1 * sim1)) + dDn;
-        const float du = dwv * wv * (1.0f - wv);
-        const float dz = (z > 0.0f) ? du * w2 : 0.0f;
         const float xh = (tt - mu) * is;
-        const float dt = gamma * is * (dz - s1 * inv_n - xh * (s2 * inv_n));
+        const float dt = gamma * is * (dz - s1n - xh * s2n);
         const float ds0 = __fmaf_rn(dN0, wv, dt * cw0);
         const float ds1 = __fmaf_rn(dN1, wv, dt * cw1);
         if (live) {
@@ -401,9 +433,10 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
   dcw_sm[tid][0] = dcw0;
   dcw_sm[tid][1] = dcw1;
   __syncthreads();
-  if (tid < G) {   // group tid lives in lane sub = tid/2 of every pixel, slot tid&1
+  if (tid < G) {   // group tid lives in 4-channel slot tid/2, i.e. wave (tid/2)/LW, lanes pl*LW + (tid/2)%LW
+    const int sl = tid >> 1, wv_ = sl / LW, ln = sl % LW;
     float sacc = 0.f;
-    for (int qd = 0; qd < PPB; ++qd) sacc += dcw_sm[qd * LPP + (tid >> 1)][tid & 1];
+    for (int qd = 0; qd < PPB; ++qd) sacc += dcw_sm[wv_ * 64 + qd * LW + ln][tid & 1];
     unsafeAtomicAdd(&p.dcw[tid], sacc);
   }
 }
@@ -520,8 +553,8 @@ __global__ void agg_bwd_finalize_kernel(const float* __restrict__ dhalf, const d
 extern "C" int mdf_warp_aggregate_vec_train(int pass, const float* ref_fea, const float* const* src_feas, const float* proj,
                                             const float* hypos, int hypos_per_pixel, const float* par, const double* red_in,
                                             const float* dcost, float* cost, float* wsum, double* red_out, float* dref,
-                                            float* const* dsrc, float* dcw, int B, int C, int G, int D, int h, int w, int n_src,
-                                            void* stream) {
+                                            float* const* dsrc, float* dcw, float* aux, int B, int C, int G, int D, int h, int w,
+                                            int n_src, void* stream) {
   MDF_REQUIRE(ref_fea && src_feas && proj && hypos && par, "null pointer argument");
   MDF_REQUIRE(pass >= 0 && pass <= 3, "pass=%d not in 0..3", pass);
   MDF_REQUIRE(B > 0 && D > 0 && h > 1 && w > 1, "bad shape B=%d D=%d h=%d w=%d", B, D, h, w);
@@ -535,7 +568,7 @@ extern "C" int mdf_warp_aggregate_vec_train(int pass, const float* ref_fea, cons
     p.src[v] = src_feas[v];
   }
   p.proj = proj; p.hypos = hypos; p.par = par; p.red_in = red_in; p.dcost = dcost; p.cost = cost; p.wsum = wsum;
-  p.red_out = red_out; p.dref = dref; p.dcw = dcw;
+  p.red_out = red_out; p.dref = dref; p.dcw = dcw; p.aux = reinterpret_cast<float4*>(aux);
   p.g = make_geom(h, w);
   p.B = B; p.D = D; p.n_src = n_src; p.hypos_per_pixel = hypos_per_pixel;
   hipStream_t st = (hipStream_t)stream;
@@ -547,10 +580,10 @@ extern "C" int mdf_warp_aggregate_vec_train(int pass, const float* ref_fea, cons
       MDF_REQUIRE(cost && wsum, "forward pass needs cost and wsum");
       return launch_train<kFwd>(p, C, st);
     case kBwdReduce:
-      MDF_REQUIRE(dcost && cost && wsum && red_out, "backward-reduce pass needs dcost, cost, wsum, red_out");
+      MDF_REQUIRE(dcost && cost && wsum && red_out && aux, "backward-reduce pass needs dcost, cost, wsum, red_out, aux");
       return launch_train<kBwdReduce>(p, C, st);
     default:
-      MDF_REQUIRE(dcost && cost && wsum && red_in && dref && dsrc && dcw, "backward pass needs dcost, cost, wsum, red_in, dref, dsrc, dcw");
+      MDF_REQUIRE(dcost && wsum && red_in && dref && dsrc && dcw && aux, "backward pass needs dcost, wsum, red_in, dref, dsrc, dcw, aux");
       for (int v = 0; v < n_src; ++v) {
         MDF_REQUIRE(dsrc[v], "dsrc[%d] is null", v);
         p.dsrc[v] = dsrc[v];

@@ -64,7 +64,7 @@ SIGNATURES = {
     "mdf_prob_softmax_regress_bwd": (c_int, [c_fp, c_fp, c_int, c_fp, c_fp, c_fp] + [c_int] * 4 + [c_fp]),
     "mdf_prob_conv_dgrad": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 5 + [c_fp]),
     "mdf_warp_aggregate_vec_train": (c_int, [c_int, c_fp, ctypes.POINTER(c_fp), c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
-                                             c_fp, ctypes.POINTER(c_fp), c_fp] + [c_int] * 7 + [c_fp]),
+                                             c_fp, ctypes.POINTER(c_fp), c_fp, c_fp] + [c_int] * 7 + [c_fp]),
     "mdf_aggregate_train_prepare": (c_int, [c_fp] * 4 + [c_i64, c_int, c_int, c_fp, c_fp, c_int, c_fp]),
     "mdf_aggregate_train_finalize": (c_int, [c_fp] * 3 + [ctypes.c_float, ctypes.c_float, c_i64, c_int, c_int] + [c_fp] * 5),
     "mdf_aggregate_train_bwd_finalize": (c_int, [c_fp, c_fp, c_int, c_i64, c_fp, c_fp, c_fp, c_fp, c_i64, c_fp]),

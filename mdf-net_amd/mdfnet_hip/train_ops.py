@@ -265,13 +265,13 @@ def regulariser_train(module, cost, hypos):
 _PASS_STATS, _PASS_FWD, _PASS_BWD_REDUCE, _PASS_BWD = 0, 1, 2, 3
 
 
-def _agg_call(pass_, ref, srcs, proj, hyp, pp, par, red_in, dcost, cost, wsum, red_out, dref, dsrcs, dcw, b, c, g, d, h, w):
+def _agg_call(pass_, ref, srcs, proj, hyp, pp, par, red_in, dcost, cost, wsum, red_out, dref, dsrcs, dcw, b, c, g, d, h, w, aux=None):
     def ptr(t):
         return None if t is None else t.data_ptr()
     algo = 4.0 * b * ((len(srcs) + 1) * c * h * w + g * d * h * w)
     _abi("mdf_warp_aggregate_vec_train", (pass_, ref.data_ptr(), _src_array(srcs), proj.data_ptr(), hyp.data_ptr(), pp, par.data_ptr(),
                                           ptr(red_in), ptr(dcost), ptr(cost), ptr(wsum), ptr(red_out), ptr(dref),
-                                          None if dsrcs is None else _src_array(dsrcs), ptr(dcw), b, c, g, d, h, w, len(srcs),
+                                          None if dsrcs is None else _src_array(dsrcs), ptr(dcw), ptr(aux), b, c, g, d, h, w, len(srcs),
                                           _stream(ref)), tag=f"train pass{pass_} C{c}G{g}D{d} {w}x{h} V{len(srcs) + 1}",
          work={"bytes": algo * (2 if pass_ == _PASS_BWD else 1), "bound": "hbm"})
 
@@ -335,12 +335,13 @@ class AggregateTrainFn(torch.autograd.Function):
         dhalf = [acc[v * nhalf:(v + 1) * nhalf] for v in range(nsrc)]
         dref_acc = acc[nsrc * nhalf:nsrc * nhalf + nref]            # the depth slices of a pixel add their d ref here
         dcw = acc[nsrc * nhalf + nref:]
+        aux = torch.empty((nsrc, b * d * h * w, 4), device=dev, dtype=torch.float32)     # per sample (w_v, dz_v, t_v, -): pass 2 -> pass 3
         _agg_call(_PASS_BWD_REDUCE, feas[0], feas[1:], ctx.proj, ctx.hyp, ctx.pp, ctx.par, None, dc, ctx.cost, ctx.wsum, red, None, None,
-                  None, b, c, g, d, h, w)
+                  None, b, c, g, d, h, w, aux=aux)
         dall = torch.empty((nsrc + 1, b, h, w, c), device=dev, dtype=torch.float32)                # reference view first
         dref, dfull = dall[0], dall[1:]
         _agg_call(_PASS_BWD, feas[0], feas[1:], ctx.proj, ctx.hyp, ctx.pp, ctx.par, red, dc, ctx.cost, ctx.wsum, None, dref_acc, dhalf,
-                  dcw, b, c, g, d, h, w)
+                  dcw, b, c, g, d, h, w, aux=aux)
         dpar = torch.empty(4, device=dev, dtype=torch.float32)
         _abi("mdf_aggregate_train_bwd_finalize", (acc.data_ptr(), red.data_ptr(), nsrc, nsrc * nhalf, dfull.data_ptr(), dpar.data_ptr(),
                                                   dref_acc.data_ptr(), dref.data_ptr(), nref, _stream(dfull)),
