@@ -294,6 +294,18 @@ int mdf_masked_smooth_l1_finalize(const double* acc, int nscales, float* loss, f
 int mdf_masked_smooth_l1_bwd(const float* est, const float* gt, const void* floor_, int floor_f64, int floor_stride, int B,
                              long long per_batch, const float* dloss, const float* inv_count, float* dest, void* stream);
 
+/* ---- optimizer step (train.py:14,43: torch.optim.Adam(lr) -> optimizer.step()) over all parameters in one launch.  The
+ *      parameters stay the module's tensors; grads, exp_avg, exp_avg_sq are flat float buffers in parameter order.  A job
+ *      is one parameter tensor (param, its offset in the flat buffers, n elements); mdf_adam_job_fill writes job `index`
+ *      into a HOST table of mdf_adam_job_bytes() bytes per job and returns its block count (< 0: error code); the caller
+ *      uploads the table and an int32 per-block job index once.  `step` = 1-based step count (bias corrections
+ *      1 - beta^step); torch's defaults otherwise (no amsgrad; weight_decay is added to the gradient as torch does).  */
+int64_t mdf_adam_job_bytes(void);
+int64_t mdf_adam_job_fill(void* jobs_host, int index, float* param, long long offset, long long n, int first_block);
+int mdf_adam_step(const void* jobs_dev, const int* block_job_dev, int nblocks, const float* grads, float* exp_avg,
+                  float* exp_avg_sq, float lr, float beta1, float beta2, float eps, float weight_decay, long long step,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,7 +9,6 @@ import os
 import time
 
 import torch
-import torch.optim as optim
 from torch.utils.data import DataLoader
 from torch.utils.data.distributed import DistributedSampler
 
@@ -65,7 +64,9 @@ def main():
     model.to(device)
     bucket = ddp.FlatBucket(model)
     bucket.broadcast_parameters(0)
-    optimizer = optim.Adam([{"params": model.parameters(), "initial_lr": train_args.lr}], lr=train_args.lr)
+    # train.py:14 -- Adam(lr); the same update as ONE launch over the flat bucket (mdfnet_hip/optim.py)
+    from mdfnet_hip.optim import FlatAdam
+    optimizer = FlatAdam(bucket, lr=train_args.lr)
     criterion = loss_mod.Loss().to(device)
     per_rank = max(train_args.batch_size // world, 1)       # the reference's batch is the GLOBAL batch (DataParallel scatter)
     sampler = DistributedSampler(dataset, world, rank, shuffle=True, drop_last=True) if world > 1 else None

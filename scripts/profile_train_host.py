@@ -11,7 +11,11 @@ dev = torch.device('cuda', 0)
 W, H, V = 768, 576, 5
 model = bench.build(dev).train()
 bucket = ddp.FlatBucket(model)
-opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+if os.environ.get("MDF_TRAIN_STOCK") == "1":
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+else:
+    from mdfnet_hip.optim import FlatAdam
+    opt = FlatAdam(bucket, lr=1e-3)
 crit = loss_mod.Loss().to(dev)
 imgs, extr, intr, dr = (t.to(dev) for t in synth.make_scene(W, H, V, batch=1, rot_deg=2.0, seed=3))
 gt = {str(k): (torch.rand(1, H >> k, W >> k, device=dev) * 400 + 480) for k in (3, 2, 1, 0)}

@@ -149,3 +149,24 @@ def test_three_rank_gloo_direct_gradient_exchange_equals_allreduce(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert rec == {"world": 3, "ok": True, "views": True, "n": 454}
+
+
+def test_flat_adam_cpu_rehearsal_matches_torch_adam():
+    """The CPU leg of mdfnet_hip.optim.FlatAdam (used by the gloo rehearsals of train.py) applies torch.optim.Adam's update."""
+    import torch
+    from mdfnet_hip import ddp, optim as moptim
+    torch.manual_seed(0)
+    a = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    b = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    b.load_state_dict(a.state_dict())
+    oa = torch.optim.Adam(a.parameters(), lr=1e-2)
+    bucket = ddp.FlatBucket(b)
+    ob = moptim.FlatAdam(bucket, lr=1e-2)
+    x = torch.randn(16, 5)
+    for _ in range(5):
+        oa.zero_grad(); bucket.zero_grad()
+        a(x).square().mean().backward(); b(x).square().mean().backward()
+        bucket.allreduce_gradients()
+        oa.step(); ob.step()
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-6, atol=1e-8)
