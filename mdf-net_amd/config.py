@@ -38,7 +38,8 @@ class Args:
         """One process per GPU: the device is this rank's (LOCAL_RANK), never a device list."""
         if torch.cuda.is_available():
             torch.cuda.manual_seed(seed_id)
-            return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+            # (MDF_SHARE_GPU: rehearsal knob for a 1-GPU box -- every rank on card 0; never set in production)
+            return torch.device("cuda", 0 if os.environ.get("MDF_SHARE_GPU") else int(os.environ.get("LOCAL_RANK", "0")))
         return torch.device("cpu")
 
 

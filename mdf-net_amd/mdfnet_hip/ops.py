@@ -31,8 +31,24 @@ def profile_end():
     return [(n, tag, e0.elapsed_time(e1), work) for n, tag, e0, e1, work in recs]
 
 
+_counts = None      # optional census of the C-ABI entries called (tests: "which kernels actually ran in this process")
+
+
+def count_begin():
+    global _counts
+    _counts = {}
+
+
+def count_end():
+    global _counts
+    c, _counts = _counts, None
+    return c
+
+
 def _abi(name, args, tag="", work=None):
     fn = getattr(lib(), name)
+    if _counts is not None:
+        _counts[name] = _counts.get(name, 0) + 1
     if _prof is None:
         check(fn(*args), name)
         return

@@ -17,7 +17,10 @@ def init(backend=None):
     rank, world, local = world_info()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # (MDF_DIST_BACKEND / MDF_SHARE_GPU: rehearsal knobs for a 1-GPU box -- gloo instead of RCCL, every rank on card 0)
+        backend = backend or os.environ.get("MDF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if os.environ.get("MDF_SHARE_GPU"):
+            local = 0
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, device_id=torch.device("cuda", local))

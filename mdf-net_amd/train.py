@@ -62,11 +62,16 @@ def main():
         start_epoch = ckpt["epoch"] + 1
         model.load_state_dict(ckpt["model"])
     model.to(device)
+    dump_dir = os.environ.get("MDF_DUMP_RANK_STATE")       # test hook (tests/test_train_ddp_gpu.py): every rank's final parameters
+    if dump_dir:
+        from mdfnet_hip import ops as _ops
+        _ops.count_begin()
     bucket = ddp.FlatBucket(model)
     bucket.broadcast_parameters(0)
     # train.py:14 -- Adam(lr); the same update as ONE launch over the flat bucket (mdfnet_hip/optim.py)
     from mdfnet_hip.optim import FlatAdam
     optimizer = FlatAdam(bucket, lr=train_args.lr)
+    initial = {k: v.detach().cpu().clone() for k, v in model.named_parameters()} if dump_dir else None
     criterion = loss_mod.Loss().to(device)
     per_rank = max(train_args.batch_size // world, 1)       # the reference's batch is the GLOBAL batch (DataParallel scatter)
     sampler = DistributedSampler(dataset, world, rank, shuffle=True, drop_last=True) if world > 1 else None
@@ -85,6 +90,11 @@ def main():
                 f.write(str(mean_loss) + "\n")
             torch.save({"epoch": epoch, "model": model.state_dict()},
                        os.path.join(train_args.pth_path, args.dataset + "_" + str(epoch) + ".pth"))
+    if dump_dir:
+        calls = _ops.count_end()
+        trained = sum(n for k, n in calls.items() if k.endswith("_bwd") or "wgrad" in k or "train" in k)
+        torch.save({"device": str(device), "params": {k: v.detach().cpu() for k, v in model.named_parameters()}, "initial": initial,
+                    "hip_training_calls": trained}, os.path.join(dump_dir, f"rank{rank}_state.pt"))
 
 
 if __name__ == "__main__":
