@@ -68,6 +68,31 @@ def test_conv3d_layer_lds_kernels(cin, cout, shape):
     np.testing.assert_allclose(ops.from_ndhwc(y2).cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("cin,cout", [(8, 16), (16, 32)])
+@pytest.mark.parametrize("shape", [(1, 25, 203, 261), (2, 11, 190, 301), (1, 6, 401, 799), (1, 2, 700, 900), (1, 3, 640, 1000)])
+def test_conv3d_stride2_layer_large_volumes(cin, cout, shape):
+    """Stride-2 down-sampling layers at the sizes the regularisers run them (>= 150 000 output voxels): odd and even extents in
+    d, h and w (the last output plane / row / column reads the zero halo or not), batch 2, a single output plane, two."""
+    b, d, h, w = shape
+    do, ho, wo = (d - 1) // 2 + 1, (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    assert b * do * ho * wo >= 150000
+    g = torch.Generator().manual_seed(cin * 100 + cout + w)
+    x = torch.randn(b, cin, d, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, 3, generator=g) / np.sqrt(27 * cin)
+    alpha = torch.rand(cout, generator=g) + 0.5
+    beta = torch.rand(cout, generator=g) * 0.4 - 0.2
+    ref = F.conv3d(x, wt, None, 2, 1)
+    assert tuple(ref.shape) == (b, cout, do, ho, wo)
+    res = torch.randn(ref.shape, generator=g)
+    exp = F.relu(ref * alpha.view(1, -1, 1, 1, 1) + beta.view(1, -1, 1, 1, 1)) + res
+    wp = ops.pack_conv3d_weight(wt.to(DEV), False)
+    xd = ops.to_ndhwc(x.to(DEV))
+    y = ops.conv3d_ndhwc(xd, wp, cin, cout, 2, False, alpha.to(DEV), beta.to(DEV), True, ops.to_ndhwc(res.to(DEV)))
+    np.testing.assert_allclose(ops.from_ndhwc(y).cpu().numpy(), exp.numpy(), rtol=1e-4, atol=2e-5)
+    y2 = ops.conv3d_ndhwc(xd, wp, cin, cout, 2, False)
+    np.testing.assert_allclose(ops.from_ndhwc(y2).cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
+
+
 @pytest.mark.parametrize("cin,cout", [(32, 16), (16, 8), (64, 32)])
 @pytest.mark.parametrize("shape", [(1, 6, 130, 201), (2, 4, 101, 187)])
 def test_conv_transpose3d_layer_large_volumes(cin, cout, shape):
