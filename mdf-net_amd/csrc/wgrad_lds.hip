@@ -9,6 +9,7 @@
 // 64-lane read).  Voxel strides in LDS are padded so that the two 16-lane groups of a 32-lane half hit disjoint banks.
 //
 //     dw[a][b][z][kh][kw] (+)= sum_o small[o][a] * big[s*o + tap - pad][b]       z = blockIdx.z (kd in 3-D, kh in 2-D)
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -29,12 +30,22 @@ struct WgradLdsParams {
   int tv;                // voxels of `small` per tile along w: 64, or 256 for few-channel layers (more MFMAs per barrier)
   float* zero_out;       // when set: zero_n floats cleared by this launch (the dw the slab is summed into next)
   int zero_n;
+  int pa, pb;            // tap packing (R > 0): `small` shifts in the tile rows (A <= 8), `big` shifts in the tile columns (Bc <= 8)
 };
 
 // KH kernel rows x KW taps per block; MODE3D: z = kd and the rows are the 3 kh rows of depth plane od*s+kd-1;
 // otherwise (2-D): z = kh, one row.
-template <int KH, int KW, bool MODE3D>
+//
+// R > 0 (stride 1, KW = 3, A <= 8 and/or Bc <= 8): TAP PACKING.  An 8 x 8 channel pair fills a quarter of a 16 x 16 MFMA tile.
+// Tile row (sa, a) instead holds `small` shifted by sa voxels and tile column (sb, b) holds `big` shifted by sb:
+//     D[(sa,a)][(sb,b)] = sum_v small[v - sa][a] * big[v + t + sb][b] = dw[a][b][kw = t + sa + sb]
+// so ONE chain of MFMAs yields the taps t .. t + R, R = (pa-1) + (pb-1): all three kw taps for 8 x 8 (R = 2; the (1,0) block
+// duplicates (0,1) and is not stored), two steps t = 0, 2 for 8 x 16 / 16 x 8 (R = 1).  The row sum of a shifted block runs over
+// v - sa, so `small` is staged with pa-1 voxels of left halo and the tiles cover Ws + pa - 1 voxels (zero beyond the row).
+template <int KH, int KW, bool MODE3D, int R>
 __global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) {
+  constexpr int NT = (R == 0) ? KW : (R == 1 ? 2 : 1);     // MFMA chains (accumulators) per kernel row
+  constexpr int TSTEP = (R == 0) ? 1 : R + 1;              // first tap of chain ts: ts * TSTEP
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if (p.zero_out) {
     const int nblk = gridDim.x * gridDim.y * gridDim.z;
@@ -43,8 +54,9 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) 
   }
   const int s = p.stride;
   const int WB = p.tv * s + KW - 1;              // voxels of `big` per staged row
-  float* sm_small = lds;                         // [tv][AS]
-  float* sm_big = lds + p.tv * p.AS;             // [KH][WB][BS]
+  const int hal = (R > 0) ? p.pa - 1 : 0;        // left halo of the staged `small` segment
+  float* sm_small = lds;                         // [hal + tv][AS]
+  float* sm_big = lds + (p.tv + hal) * p.AS;     // [KH][WB][BS] (+ one voxel of slack: the discarded tap t + sa + sb = 3 reads it)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, c16 = lane & 15;
@@ -53,13 +65,15 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) 
   const int part = wave % p.split;
   const int na = pair / p.NB, nb = pair % p.NB;
   const int a = na * 16 + c16, bcol = nb * 16 + c16;
-  const bool b_ok = bcol < p.Bc;
-  const int ac = min(a, p.A - 1), bc = min(bcol, p.Bc - 1);   // clamped lanes feed tile rows / columns that are never stored
+  const bool b_ok = (R > 0 && p.pb > 1) ? (c16 < p.Bc * p.pb) : (bcol < p.Bc);
+  // operand lanes: (shift, channel) when packed; clamped lanes feed tile rows / columns that are never stored
+  const int sa = (R > 0 && p.pa > 1) ? min(c16 / p.A, p.pa - 1) : 0, sb = (R > 0 && p.pb > 1) ? min(c16 / p.Bc, p.pb - 1) : 0;
+  const int ac = (R > 0 && p.pa > 1) ? c16 % p.A : min(a, p.A - 1), bc = (R > 0 && p.pb > 1) ? c16 % p.Bc : min(bcol, p.Bc - 1);
   const int z = blockIdx.z;
 
-  f32x4 acc[KH * KW];
+  f32x4 acc[KH * NT];
 #pragma unroll
-  for (int t = 0; t < KH * KW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < KH * NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // Register staging of the next tile in 16-byte pieces.  A row segment is CONTIGUOUS in memory (NHWC / NDHWC), so piece i of a
   // row is `row4[first + i]`: no per-piece index arithmetic beyond a bound check; its LDS slot (voxel i >> log2(C/4), channel
@@ -69,7 +83,7 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) 
   float4 st_small[NS], st_big[KH][NPR];
   const int c4a = p.A >> 2, c4b = p.Bc >> 2;
   const int la2 = 31 - __clz(c4a), lb2 = 31 - __clz(c4b);
-  const int small_pieces = p.tv * c4a, row_pieces = WB * c4b;
+  const int small_pieces = (p.tv + hal) * c4a, row_pieces = WB * c4b;
   int lds_small[NS], lds_big[NPR];
 #pragma unroll
   for (int k = 0; k < NS; ++k) { const int i = threadIdx.x + 256 * k; lds_small[k] = (i >> la2) * p.AS + 4 * (i & (c4a - 1)); }
@@ -87,12 +101,12 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) 
   auto stage = [&](long long tile) {          // global -> registers (zero for out-of-range voxels / rows)
     int n, od, oh, ow0;
     decode(tile, n, od, oh, ow0);             // wave-uniform (scalar unit)
-    const float4* srow = reinterpret_cast<const float4*>(p.small_) + ((((long long)n * p.Ds + od) * p.Hs + oh) * p.Ws + ow0) * c4a;
-    const int s_hi = min(p.tv, p.Ws - ow0) * c4a;
+    const float4* srow = reinterpret_cast<const float4*>(p.small_) + ((((long long)n * p.Ds + od) * p.Hs + oh) * p.Ws + (ow0 - hal)) * c4a;
+    const int s_lo = max(0, hal - ow0) * c4a, s_hi = min(p.tv + hal, p.Ws - ow0 + hal) * c4a;     // staged slot 0 = voxel ow0 - hal
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       const int i = threadIdx.x + 256 * k;
-      st_small[k] = (i < s_hi) ? srow[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      st_small[k] = (i >= s_lo && i < s_hi) ? srow[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int id = MODE3D ? od * s + z - p.pad : 0;
     const int v_first = ow0 * s - p.pad;                                  // big voxel of staged slot 0
@@ -122,9 +136,9 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) 
   };
 
   // chunks of the tile this wave multiplies: the `split` waves that share a pair take every split-th chunk
-  const int nchunk = (p.tv / 16) / p.split;
-  const float* la = sm_small + q * p.AS + ac;
-  const float* lb = sm_big + q * s * p.BS + bc;
+  const int nchunk = (p.tv / 16 - part + p.split - 1) / p.split;     // tv is any multiple of 16: the first waves may take one chunk more
+  const float* la = sm_small + (q + hal - sa) * p.AS + ac;
+  const float* lb = sm_big + (q * s + sb) * p.BS + bc;
 
   long long tile = blockIdx.x;
   if (tile < p.n_tiles) stage(tile);
@@ -141,12 +155,12 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) 
 #pragma unroll
       for (int kh = 0; kh < KH; ++kh) {
 #pragma unroll
-        for (int kw = 0; kw < KW; ++kw) {
+        for (int ts = 0; ts < NT; ++ts) {
           float bf[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) bf[j] = lb[(kh * WB + (v0 + 4 * j) * s + kw) * p.BS];
+          for (int j = 0; j < 4; ++j) bf[j] = lb[(kh * WB + (v0 + 4 * j) * s + ts * TSTEP) * p.BS];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[kh * KW + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[j], acc[kh * KW + kw], 0, 0, 0);
+          for (int j = 0; j < 4; ++j) acc[kh * NT + ts] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[j], acc[kh * NT + ts], 0, 0, 0);
         }
       }
     }
@@ -155,18 +169,18 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) 
   }
 
   // partial tiles of the `split` waves that share a pair: summed through LDS (the staging area is free now)
-  float* mine = lds + (wave / p.split) * (KH * KW * 4 * 64);
+  float* mine = lds + (wave / p.split) * (KH * NT * 4 * 64);
   for (int turn = 1; turn < p.split; ++turn) {
     if (part == turn) {
 #pragma unroll
-      for (int t = 0; t < KH * KW; ++t)
+      for (int t = 0; t < KH * NT; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) mine[(t * 4 + i) * 64 + lane] = acc[t][i];
     }
     __syncthreads();
     if (part == 0) {
 #pragma unroll
-      for (int t = 0; t < KH * KW; ++t)
+      for (int t = 0; t < KH * NT; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[t][i] += mine[(t * 4 + i) * 64 + lane];
     }
@@ -174,13 +188,35 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) 
   }
   if (part == 0 && b_ok) {
     float* out = p.slab + (long long)blockIdx.x * p.A * p.Bc * p.ntaps_total;
+    if constexpr (R == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = na * 16 + 4 * q + i;
-      if (row < p.A) {
-        float* o = out + ((long long)row * p.Bc + bcol) * p.ntaps_total + z * (KH * KW);
+      for (int i = 0; i < 4; ++i) {
+        const int row = na * 16 + 4 * q + i;
+        if (row < p.A) {
+          float* o = out + ((long long)row * p.Bc + bcol) * p.ntaps_total + z * (KH * KW);
 #pragma unroll
-        for (int t = 0; t < KH * KW; ++t) o[t] = acc[t][i];
+          for (int t = 0; t < KH * KW; ++t) o[t] = acc[t][i];
+        }
+      }
+    } else {
+      // tile (row, column) = ((sa, a), (sb, b)); chain ts holds tap kw = ts*TSTEP + sa + sb.  Every (a, b, kw) is stored once: by the
+      // block with the largest row shift that reaches it (sa = min(m, pa-1), m = kw - ts*TSTEP).
+      const int sbc = (p.pb > 1) ? c16 / p.Bc : 0, bch = (p.pb > 1) ? c16 % p.Bc : bcol;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = na * 16 + 4 * q + i;
+        const int sar = (p.pa > 1) ? row / p.A : 0, ach = (p.pa > 1) ? row % p.A : row;
+        if ((p.pa > 1) ? (row >= p.A * p.pa) : (row >= p.A)) continue;
+        const int m = sar + sbc;
+        if (sar != min(m, p.pa - 1)) continue;
+        float* o = out + ((long long)ach * p.Bc + bch) * p.ntaps_total + z * (KH * KW);
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+          for (int ts = 0; ts < NT; ++ts) {
+            const int kw = ts * TSTEP + m;
+            if (kw < KW) o[kh * KW + kw] = acc[kh * NT + ts][i];
+          }
       }
     }
   }
@@ -214,23 +250,34 @@ int mdf_wgrad_lds_dispatch(const float* small_, const float* big, float* workspa
   const int gy = (pairs * p.split + 3) / 4;
   const int KH = is3d ? 3 : 1, KW = ksize;
   p.ntaps_total = is3d ? 27 : ksize * ksize;
+  // tap packing for the few-channel layers (see the kernel): shifts of `small` in the rows, of `big` in the columns
+  static const bool pack_on = [] { const char* e = getenv("MDF_WGRAD_PACK"); return e ? atoi(e) != 0 : true; }();   // dev A/B
+  p.pa = p.pb = 1;
+  if (pack_on && stride == 1 && ksize == 3) {
+    if (A <= 8) p.pa = 2;
+    if (Bc <= 8) p.pb = 2;
+  }
+  const int R = (p.pa - 1) + (p.pb - 1), hal = p.pa - 1;
   // tile width along w: a multiple of 16*split voxels, as wide as the register staging and ~64 KiB of LDS allow (more MFMAs per
   // barrier pair), chosen to waste the fewest voxels of the row's last tile
   const int npr = is3d ? 4 : 5;
   int best_tv = 0;
   long long best_cost = 0;
   size_t best_lds = 0;
-  for (int tv = 16 * p.split; tv <= 256; tv += 16 * p.split) {
+  // (unpacked layers: multiples of 16*split up to 256, every wave the same number of chunks -- the A/B-tuned choice; packed layers
+  // need Ws + 1 voxels covered, which would cost a whole extra tile at those widths: any multiple of 16 up to 512)
+  for (int tv = 16 * p.split; tv <= (R > 0 ? 512 : 256); tv += (R > 0 ? 16 : 16 * p.split)) {
     const int WB = tv * stride + KW - 1;
-    if (tv * (A / 4) > 4 * 256 || WB * (Bc / 4) > npr * 256) break;            // register staging capacity
-    const size_t lds = (size_t)(tv * p.AS + KH * WB * p.BS) * sizeof(float);
+    if ((tv + hal) * (A / 4) > 4 * 256 || WB * (Bc / 4) > npr * 256) break;    // register staging capacity
+    const size_t lds = (size_t)((tv + hal) * p.AS + (KH * WB + 1) * p.BS) * sizeof(float);
     if (lds > 72 * 1024) break;
-    const long long cost = (long long)((Ws + tv - 1) / tv) * (tv + 24);          // + ~24 voxel-times of fixed cost per tile
+    const int rounds = (tv / 16 + p.split - 1) / p.split;                       // chunks of the busiest wave
+    const long long cost = (long long)((Ws + hal + tv - 1) / tv) * (rounds * p.split * 16 + 24);    // + ~24 voxel-times of fixed cost per tile
     if (best_tv == 0 || cost <= best_cost) { best_tv = tv; best_cost = cost; best_lds = lds; }
   }
   if (best_tv == 0) return MDF_EUNSUPPORTED;
   p.tv = best_tv;
-  p.wtiles = (Ws + p.tv - 1) / p.tv;
+  p.wtiles = (Ws + hal + p.tv - 1) / p.tv;      // (packed rows sum over v - sa: the tiles reach pa-1 voxels past the row)
   p.n_tiles = (long long)B * p.Ds * Hs * p.wtiles;
   size_t lds = best_lds;
   const size_t red = (size_t)2 * KH * KW * 4 * 64 * sizeof(float);
@@ -242,24 +289,28 @@ int mdf_wgrad_lds_dispatch(const float* small_, const float* big, float* workspa
   *gx_io = gx;
   const dim3 grid(gx, gy, is3d ? 3 : ksize);
   hipStream_t st = (hipStream_t)stream;
-#define WG_LAUNCH(KHv, KWv, M3)                                                                                            \
+#define WG_LAUNCH(KHv, KWv, M3, Rv)                                                                                        \
   {                                                                                                                        \
     static bool attr_done[64] = {};                                                                                        \
     int dev_id = 0;                                                                                                        \
     (void)hipGetDevice(&dev_id);                                                                                           \
     if (dev_id < 0 || dev_id >= 64 || !attr_done[dev_id]) {                                                                \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lds_kernel<KHv, KWv, M3>),                   \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lds_kernel<KHv, KWv, M3, Rv>),               \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);                          \
       if (e != hipSuccess) return mdf::fail(MDF_EHIP, "hipFuncSetAttribute(dynamic LDS): %s", hipGetErrorString(e));       \
       if (dev_id >= 0 && dev_id < 64) attr_done[dev_id] = true;                                                            \
     }                                                                                                                      \
-    hipLaunchKernelGGL((wgrad_lds_kernel<KHv, KWv, M3>), grid, dim3(256), lds, st, p);                                      \
+    hipLaunchKernelGGL((wgrad_lds_kernel<KHv, KWv, M3, Rv>), grid, dim3(256), lds, st, p);                                  \
     return mdf::check_launch("wgrad_lds_kernel");                                                                          \
   }
-  if (is3d && ksize == 3) WG_LAUNCH(3, 3, true)
-  if (!is3d && ksize == 3) WG_LAUNCH(1, 3, false)
-  if (!is3d && ksize == 5) WG_LAUNCH(1, 5, false)
-  if (!is3d && ksize == 1) WG_LAUNCH(1, 1, false)
+  if (is3d && ksize == 3 && R == 2) WG_LAUNCH(3, 3, true, 2)
+  if (is3d && ksize == 3 && R == 1) WG_LAUNCH(3, 3, true, 1)
+  if (is3d && ksize == 3) WG_LAUNCH(3, 3, true, 0)
+  if (!is3d && ksize == 3 && R == 2) WG_LAUNCH(1, 3, false, 2)
+  if (!is3d && ksize == 3 && R == 1) WG_LAUNCH(1, 3, false, 1)
+  if (!is3d && ksize == 3) WG_LAUNCH(1, 3, false, 0)
+  if (!is3d && ksize == 5) WG_LAUNCH(1, 5, false, 0)
+  if (!is3d && ksize == 1) WG_LAUNCH(1, 1, false, 0)
 #undef WG_LAUNCH
   return MDF_EUNSUPPORTED;
 }

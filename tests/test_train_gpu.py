@@ -515,3 +515,27 @@ def test_flat_adam_matches_torch_adam(seeded_sd):
         worst = max(worst, err)
         assert err <= 2e-6, (k, err)
     print(f"FlatAdam vs torch.optim.Adam after 4 steps: max relative parameter difference {worst:.2e}")
+
+
+@pytest.mark.parametrize("a,bc", [(8, 8), (8, 16), (16, 8), (8, 4)])
+@pytest.mark.parametrize("w", [16, 17, 63, 64, 65, 256, 257, 384, 511, 512, 513])
+def test_wgrad_tap_packing_row_lengths(a, bc, w):
+    """Few-channel weight gradients pack taps into the MFMA tile (shifts of dy in the rows, of x in the columns: wgrad_lds.hip, R > 0);
+    the shifted row blocks sum over v - 1, so the tiles must reach one voxel past the row -- exercised at row lengths around every
+    tile-width boundary, 2-D and 3-D, against torch's weight gradient on the CPU."""
+    torch.manual_seed(a * 1000 + bc * 10 + w)
+    for three_d in (False, True):
+        if three_d:
+            conv = nn.Conv3d(bc, a, 3, padding=1, bias=False)
+            x = torch.randn(1, bc, 3, 4, w, requires_grad=True)
+        else:
+            conv = nn.Conv2d(bc, a, 3, padding=1, bias=False)
+            x = torch.randn(2, bc, 5, w, requires_grad=True)
+        y = conv(x)
+        dy = torch.randn_like(y)
+        y.backward(dy)
+        if three_d:
+            dw = train_ops.conv3d_wgrad(ops.to_ndhwc(dy.to(DEV)), ops.to_ndhwc(x.detach().to(DEV)), 1, tuple(conv.weight.shape))
+        else:
+            dw = train_ops.conv2d_wgrad(ops.to_nhwc(dy.to(DEV)), ops.to_nhwc(x.detach().to(DEV)), 3, 1, tuple(conv.weight.shape))
+        assert _rel(dw, conv.weight.grad) < 3e-5, (three_d, _rel(dw, conv.weight.grad))
