@@ -51,3 +51,10 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(mdfnet_hip, "LIB_PATH", "/nonexistent/libmdfnet_hip.so")
     with pytest.raises(mdfnet_hip.MdfHipError, match="no fallback"):
         mdfnet_hip.lib()
+
+
+def test_integration_notes_name_every_abi_entry():
+    """INTEGRATION.md maps every entry of the C ABI to the reference code it replaces."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [name for name in _declared_symbols() if name not in text]
+    assert not missing, missing
