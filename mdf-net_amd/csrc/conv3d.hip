@@ -171,7 +171,14 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
   // split-K stride hands every wave real work.  Along w: offset 0 feeds pw=0 (kw=1) and pw=1 (kw=2); offset +1 feeds pw=1 (kw=0).
   const int nkh = 1 + ph;
   const int ntaps = (MODE == kTr) ? (1 + pd) * nkh * 2 : 27;
-  for (int j = (SPLITK > 1 ? wave : 0); j < ntaps; j += (SPLITK > 1 ? SPLITK : 1)) {
+  // Software pipeline over the taps: the operands of tap j+1 (all cin chunks: NCH*(MT+NT) 16-byte fragments) are requested before
+  // the MFMAs of tap j.  A block lives for ONE wave tile, so without it every tap exposes an L2 round trip: the small layers
+  // (1/8-resolution volumes, the transposed up-sampling layers) were pure latency -- 64->32 T at 1x74x100: 46 us for 0.8 GFLOP.
+  struct TapRegs {
+    Frag<KPL> bf[NCH][MT], af[NCH][NT];
+    int ow;
+  };
+  auto load_tap = [&](int j, TapRegs& r) {
     int kd, kh, kw, od, oh, ow, tap;
     if (MODE == kTr) {
       ow = j & 1;
@@ -186,24 +193,28 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
       kd = tap / 9; kh = (tap / 3) % 3; kw = tap % 3;
       od = kd - 1; oh = kh - 1; ow = kw - 1;
     }
+    r.ow = ow;
     const int tapoff = ((od * p.Hi + oh) * p.Wi + ow) * CIN;
     const unsigned need = (1u << kd) | (8u << kh) | (64u << kw);
     const float* wt = wl + (size_t)tap * (NCH * NT * 64 * KPL);
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-      Frag<KPL> bf[MT];
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         // branch-free: an out-of-range tap reads the voxel's own (valid) position and is zeroed by a multiply.  A predicated
         // load compiles to a branch and a wait per load (s_and_saveexec / s_cbranch_execz), which serialises the fetches of
         // a tap step; a select instead of the multiply lets the compiler sink the load back under the condition.
         const bool ok = (vmask[t] & need) == need;
-        bf[t].load(xq + in_off[t] + (ok ? tapoff : 0) + ch * CK);
-        bf[t].scale(ok ? 1.0f : 0.0f);
+        r.bf[ch][t].load(xq + in_off[t] + (ok ? tapoff : 0) + ch * CK);
+        r.bf[ch][t].scale(ok ? 1.0f : 0.0f);
       }
-      Frag<KPL> af[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) af[nt].load(wt + (size_t)(ch * NT + nt) * (64 * KPL));
+      for (int nt = 0; nt < NT; ++nt) r.af[ch][nt].load(wt + (size_t)(ch * NT + nt) * (64 * KPL));
+    }
+  };
+  auto mul_tap = [&](const TapRegs& r) {
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
       for (int s = 0; s < KPL; ++s)
 #pragma unroll
@@ -211,9 +222,37 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             // transposed, offset +1: rows of parity pw = 0 are structurally zero -> skip n-tiles made only of such rows
-            if (MODE == kTr && ow == 1 && (nt + 1) * 16 <= COUT) continue;
-            acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[nt].v[s], bf[t].v[s], acc[t][nt], 0, 0, 0);
+            if (MODE == kTr && r.ow == 1 && (nt + 1) * 16 <= COUT) continue;
+            acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.af[ch][nt].v[s], r.bf[ch][t].v[s], acc[t][nt], 0, 0, 0);
           }
+  };
+  // (measured per variant: the single-tile transposed kernels gain 1.1-1.9x -- 64->32 T 77 / 44 / 46 -> 53 / 23 / 25 us; the big-tile
+  // variants lose the occupancy their HBM-bound layers live on -- 32->16 T 92 -> 125 us, 16->8 T 88 -> 104 --, and the split-K stride-1
+  // kernels lose too -- 64->64 65 -> 85: those keep one tap in flight)
+  constexpr bool kPipeTaps = (MODE == kTr && MT == 1);
+  {
+    const int js = (SPLITK > 1) ? SPLITK : 1;
+    int j = (SPLITK > 1) ? wave : 0;
+    if constexpr (kPipeTaps) {
+      TapRegs ra, rb;
+      if (j < ntaps) load_tap(j, ra);
+      while (j < ntaps) {
+        if (j + js < ntaps) load_tap(j + js, rb);
+        __builtin_amdgcn_sched_barrier(0);       // (the requests stay ahead of the MFMAs; hipcc otherwise sinks them to their first use)
+        mul_tap(ra);
+        j += js;
+        if (j >= ntaps) break;
+        if (j + js < ntaps) load_tap(j + js, ra);
+        __builtin_amdgcn_sched_barrier(0);
+        mul_tap(rb);
+        j += js;
+      }
+    } else {
+      for (; j < ntaps; j += js) {
+        TapRegs r;
+        load_tap(j, r);
+        mul_tap(r);
+      }
     }
   }
 
