@@ -269,15 +269,22 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
   float dcw0 = 0.f, dcw1 = 0.f;       // d conv weight of this lane's two groups
 
   const int dlo = blockIdx.z * p.dslice, dhi = min(p.D, dlo + p.dslice);
-  for (int d0 = dlo; d0 < dhi; d0 += p.dchunk) {
-    const int nd = min(p.dchunk, dhi - d0);
+  // Per-pixel hypotheses (stages 1, 2) keep a pixel's planes within a fraction of a source texel of each other: there the tap table
+  // is built per VIEW over all the planes it can hold (the same LDS: dchunk * n_src planes), so a pixel's tap sums stay in registers
+  // across them and the window is zeroed and flushed once per view instead of once per (chunk, view).  Uniform hypotheses (stage 0)
+  // sweep the whole depth range -- a long epipolar segment -- and keep the short chunks whose footprint fits the window.
+  const int nv = p.hypos_per_pixel ? 1 : p.n_src;                 // views per tap table
+  const int dstep = p.hypos_per_pixel ? p.dchunk * p.n_src : p.dchunk;
+  for (int v_lo = 0; v_lo < p.n_src; v_lo += nv)
+  for (int d0 = dlo; d0 < dhi; d0 += dstep) {
+    const int nd = min(dstep, dhi - d0);
     if (tid < 4 * p.n_src) bb[tid >> 2][tid & 3] = (tid & 1) ? INT32_MIN : INT32_MAX;
     __syncthreads();
-    const int nent = nd * p.n_src * PPB;
+    const int nent = nd * nv * PPB;
     for (int e = tid; e < nent; e += kThreads) {
       const int epl = e % PPB;
-      const int ev = (e / PPB) % p.n_src;
-      const int ed = e / (PPB * p.n_src);
+      const int ev = v_lo + (e / PPB) % nv;
+      const int ed = e / (PPB * nv);
       const int epix = min(pix0 + epl, hw - 1);
       const int yy = epix / W, xx = epix - yy * W;
       const float* m = p.proj + ((size_t)ev * p.B + b) * 12;
@@ -301,7 +308,7 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
     }
     __syncthreads();
 
-    for (int v = 0; v < p.n_src; ++v) {
+    for (int v = v_lo; v < v_lo + nv; ++v) {
       const int xmin = bb[v][0], xmax = bb[v][1], ymin = bb[v][2], ymax = bb[v][3];
       const int ww = xmax - xmin + 1, wh = ymax - ymin + 1;
       const bool any = (xmax >= xmin) && (ymax >= ymin);
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
         }
       };
       for (int dd = 0; dd < nd; ++dd) {
-        const TapXY t = tab[(dd * p.n_src + v) * PPB + pl];
+        const TapXY t = tab[(dd * nv + (v - v_lo)) * PPB + pl];
         const int o0 = (t.ya * W + t.xa), o1 = (t.ya * W + t.xb), o2 = (t.yb * W + t.xa), o3 = (t.yb * W + t.xb);
         const float4 nw = *reinterpret_cast<const float4*>(sp + (size_t)o0 * C);
         const float4 ne = *reinterpret_cast<const float4*>(sp + (size_t)o1 * C);
