@@ -60,29 +60,69 @@ def family(name, tag):
     return name.replace("mdf_", "").replace("_fwd", "") + "_kernel"
 
 
-def profile_pass(model, inputs, steps=3):
-    """Per-launch HIP-event timing of every hand-written kernel (events recorded on the launch stream)."""
+def _wall_ms(fn, reps=3):
+    """GPU time of fn() from ONE HIP event pair on the launch stream (no per-launch instrumentation), mean over reps."""
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def bracketed_launches(fn, steps=3):
+    """Per-launch HIP-event timing of every hand-written kernel fn() issues (events recorded on the launch stream), with the
+    cost of the instrumentation itself calibrated out IN SITU: an event pair per launch stretches the stream (marker packets,
+    the dispatch gap behind each marker), so the instrumented run's wall W_prof exceeds the plain run's W_plain and the raw
+    brackets over-count (the family sum exceeded the one-at-a-time wall).  delta = (W_prof - W_plain) /
+    brackets is subtracted from every bracket; since the raw brackets are disjoint intervals inside W_prof, the corrected
+    sum cannot exceed W_plain.  -> (records [(abi, tag, ms, work)] of all steps, info dict)"""
     from mdfnet_hip import ops
+    w_plain = _wall_ms(fn, steps)
+    recs, w_prof = [], 0.0
+    for _ in range(steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        ops.profile_begin()
+        fn()
+        e1.record()
+        recs += ops.profile_end()
+        w_prof += e0.elapsed_time(e1)
+    w_prof /= steps
+    per = len(recs) / steps
+    delta = max(0.0, (w_prof - w_plain) / max(per, 1.0))
+    recs = [(n, tag, max(ms - delta, 0.0), work) for n, tag, ms, work in recs]
+    return recs, {"wall_plain_ms": round(w_plain, 4), "wall_instrumented_ms": round(w_prof, 4), "brackets_per_step": round(per, 1),
+                  "bracket_cost_us": round(delta * 1e3, 2),
+                  "note": "per-launch times = HIP-event bracket minus bracket_cost_us (calibrated in this run from the two walls)"}
+
+
+def family_table(recs, steps, family_of):
+    """records of `steps` steps -> one entry per kernel family: launches, ms, algorithmic work, achieved vs CDNA4 peak."""
     agg = {}
-    with torch.no_grad():
-        for _ in range(steps):
-            ops.profile_begin()
-            model(*inputs)
-            for name, tag, ms, work in ops.profile_end():
-                if name == "mdf_conv3d_pack_weights":
-                    continue
-                f = agg.setdefault(family(name, tag), {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0,
-                                                       "bound": work.get("bound", "hbm"), "top": {}})
-                f["ms"] += ms
-                f["flops"] += work.get("flops", 0.0)
-                f["bytes"] += work.get("bytes", 0.0)
-                f["launches"] += 1
-                t = f["top"].setdefault(tag, [0.0, 0.0, 0.0, 0])
-                t[0] += ms; t[1] += work.get("flops", 0.0); t[2] += work.get("bytes", 0.0); t[3] += 1
+    for name, tag, ms, work in recs:
+        fam = family_of(name, tag)
+        if fam is None:
+            continue
+        f = agg.setdefault(fam, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0,
+                                 "bound": work.get("bound", "hbm"), "top": {}})
+        f["ms"] += ms
+        f["flops"] += work.get("flops", 0.0)
+        f["bytes"] += work.get("bytes", 0.0)
+        f["launches"] += 1
+        t = f["top"].setdefault(tag, [0.0, 0.0, 0.0, 0])
+        t[0] += ms; t[1] += work.get("flops", 0.0); t[2] += work.get("bytes", 0.0); t[3] += 1
     out = []
     for fam, f in agg.items():
         ms = f["ms"] / steps
         rec = {"kernel": fam, "launches_per_step": f["launches"] // steps, "ms_per_step": round(ms, 4), "bound": f["bound"]}
+        if ms <= 0:
+            out.append(rec)
+            continue
         if f["bound"] == "mfma" and f["flops"]:
             ach = f["flops"] / steps / (ms * 1e-3) / 1e12
             rec.update(achieved=round(ach, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -95,8 +135,8 @@ def profile_pass(model, inputs, steps=3):
             # layers whose arithmetic intensity is below the fp32 ridge (157.3 TF/s / 8 TB/s = 19.7 flop/B) are
             # HBM-bound by their algorithmic bytes and are reported against the HBM peak instead
             ridge = PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
-            hi = [v for v in f["top"].values() if v[2] and v[1] / v[2] >= ridge]
-            lo = {k: v for k, v in f["top"].items() if v[2] and v[1] / v[2] < ridge}
+            hi = [v for v in f["top"].values() if v[2] and v[1] / v[2] >= ridge and v[0] > 0]
+            lo = {k: v for k, v in f["top"].items() if v[2] and v[1] / v[2] < ridge and v[0] > 0}
             if hi:
                 hms = sum(v[0] for v in hi) / steps
                 hfl = sum(v[1] for v in hi) / steps
@@ -109,24 +149,152 @@ def profile_pass(model, inputs, steps=3):
                                              "frac": round(lby / (lms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "bound": "hbm",
                                              "shapes": sorted(lo.keys())}
         heavy = max(f["top"].items(), key=lambda kv: kv[1][0])
-        rec["heaviest_launch"] = {"shape": heavy[0], "ms": round(heavy[1][0] / heavy[1][3], 4)}
-        if f["bound"] == "mfma" and heavy[1][1]:
-            rec["heaviest_launch"]["tflops"] = round(heavy[1][1] / heavy[1][3] / (heavy[1][0] / heavy[1][3] * 1e-3) / 1e12, 2)
-        elif heavy[1][2]:
-            rec["heaviest_launch"]["gbs"] = round(heavy[1][2] / heavy[1][3] / (heavy[1][0] / heavy[1][3] * 1e-3) / 1e9, 1)
+        if heavy[1][0] > 0:
+            rec["heaviest_launch"] = {"shape": heavy[0], "ms": round(heavy[1][0] / heavy[1][3], 4)}
+            if f["bound"] == "mfma" and heavy[1][1]:
+                rec["heaviest_launch"]["tflops"] = round(heavy[1][1] / heavy[1][3] / (heavy[1][0] / heavy[1][3] * 1e-3) / 1e12, 2)
+            elif heavy[1][2]:
+                rec["heaviest_launch"]["gbs"] = round(heavy[1][2] / heavy[1][3] / (heavy[1][0] / heavy[1][3] * 1e-3) / 1e9, 1)
         out.append(rec)
     out.sort(key=lambda r: -r["ms_per_step"])
     return out
 
 
-def measured_traffic():
-    """HBM bytes per forward per kernel family, measured offline with rocprofv3 PMC (FETCH_SIZE / WRITE_SIZE in separate
-    passes, gfx950 corrections applied; scripts/summarize_traffic.py) and committed under profiles/."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if not os.path.exists(path):
-        return {}
-    with open(path) as f:
-        return json.load(f).get("families", {})
+def profile_pass(model, inputs, steps=3):
+    """Eval forward, one view at a time: per-family table of the hand-written kernels + the instrumentation calibration."""
+    def fwd():
+        with torch.no_grad():
+            model(*inputs)
+    recs, info = bracketed_launches(fwd, steps)
+    return family_table(recs, steps, lambda n, t: None if n == "mdf_conv3d_pack_weights" else family(n, t)), info
+
+
+def measured_traffic(kind="eval"):
+    """HBM bytes per step per kernel family, measured offline with rocprofv3 PMC (FETCH_SIZE / WRITE_SIZE in separate
+    passes, gfx950 corrections applied; scripts/summarize_traffic.py) and committed under profiles/: the newest round's file
+    for this workload.  -> (families dict, file name)"""
+    names = {"eval": ["r03_traffic.json", "r02_traffic.json", "r01_traffic.json"],
+             "train": ["r03_train_traffic.json", "r02_train_traffic.json"]}[kind]
+    for name in names:
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                return json.load(f).get("families", {}), "profiles/" + name
+    return {}, None
+
+
+def attach_traffic(kernels, traffic, source, fam_of):
+    for k in kernels:
+        key = next((v for pre, v in fam_of if k["kernel"].startswith(pre)), None)
+        if key in traffic:
+            k["traffic"] = {"hbm_bytes_per_step": round(traffic[key]["hbm_bytes_per_forward"]),
+                            "read": round(traffic[key]["read_bytes_per_forward"]),
+                            "write": round(traffic[key]["write_bytes_per_forward"]),
+                            "source": f"{source} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 on gfx950)"}
+
+
+# --------------------------------------------------------------------------- BASELINE config 3: the training step
+TRAIN_W, TRAIN_H, TRAIN_V = 768, 576, 5
+
+
+def train_family(name, tag):
+    if name == "mdf_conv3d_fwd":
+        return "conv3d forward + input gradients (regulariser): conv_lds_kernel / conv3d_kernel, fp32 MFMA"
+    if name == "mdf_conv2d_fwd":
+        return "conv2d forward + input gradients (feature pyramid, refine, prob partial sums): conv_lds_kernel, fp32 MFMA"
+    if name == "mdf_conv3d_wgrad":
+        return "wgrad3d: wgrad_lds_kernel / wgrad_kernel (weight gradients, split-K fp32 MFMA)"
+    if name == "mdf_conv2d_wgrad":
+        return "wgrad2d: wgrad_lds_kernel / wgrad2d_kernel (weight gradients, split-K fp32 MFMA)"
+    if name.startswith("mdf_bn_"):
+        return "batchnorm (batch statistics, apply, backward reduce + backward): bn_*_kernel"
+    if name == "mdf_warp_aggregate_vec_train":
+        return "aggregate scatter (pass 3): warp_bwd_kernel" if "pass3" in tag else "aggregate passes 0-2: warp_train_kernel"
+    if name.startswith("mdf_prob_") or name == "mdf_upsample2_bilinear_bwd":
+        return "prob head + upsample backward"
+    if name.startswith("mdf_masked_smooth_l1"):
+        return "loss (masked smooth-L1, 4 scales)"
+    if name in ("mdf_pack_batch", "mdf_adam_step"):
+        return "weight packing + Adam (one launch each)"
+    return "small per-pixel heads and control kernels"
+
+
+def training_block(dev, steps, blocks, stock_steps):
+    """BASELINE.json configs[2] on ONE GPU (rank 0, N=1; reported NEXT to the headline, never as `value`): one training step =
+    forward + loss + backward + flat-bucket gather (the all-reduce is the identity at world 1) + Adam at 768x576, 5 views,
+    batch 1 (the per-GPU share of batch 8 on 8 GPUs), on the hand-written training kernels (reference: train.py:36-45)."""
+    import statistics
+    from mdfnet_hip import synth, ddp, layers
+    from mdfnet_hip.optim import FlatAdam
+    from net import loss as loss_mod
+    model = build(dev).train()
+    bucket = ddp.FlatBucket(model)
+    opt = FlatAdam(bucket, lr=1e-3)
+    crit = loss_mod.Loss().to(dev)
+    imgs, extr, intr, dr = (t.to(dev) for t in synth.make_scene(TRAIN_W, TRAIN_H, TRAIN_V, batch=1, rot_deg=2.0, seed=3))
+    gt = {str(k): (torch.rand(1, TRAIN_H >> k, TRAIN_W >> k, device=dev) * 400 + 480) for k in (3, 2, 1, 0)}   # dtutrain.py:55-58
+
+    def step(optimizer=opt):
+        out = model(imgs, extr, intr, dr)
+        loss = crit(out, gt, dr)
+        bucket.zero_grad()
+        loss.backward()
+        bucket.allreduce_gradients()
+        optimizer.step()
+        return loss.detach()
+
+    for _ in range(3):
+        first = step()
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(blocks):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = step()
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) / steps)
+    med = statistics.median(times)
+    assert torch.isfinite(last).item()
+    recs, info = bracketed_launches(step, 3)
+    kernels = family_table(recs, 3, train_family)
+    traffic, source = measured_traffic("train")
+    gflop = sum(k.get("algorithmic_gflop_per_step", 0.0) for k in kernels)
+    rec = {"workload": f"BlendedMVS-shaped training step {TRAIN_W}x{TRAIN_H}, {TRAIN_V} views, batch 1 on one GPU (BASELINE configs[2] "
+                       "per-GPU share): forward + masked smooth-L1 loss + backward + gradient bucket + Adam, hypotheses (48,24,8), "
+                       "batch-statistics BatchNorm, synthetic tensors, seeded weights",
+           "ms_per_step": round(1e3 * med, 3), "samples_per_s": round(1.0 / med, 2), "steps": steps, "blocks": blocks,
+           "ms_per_step_blocks": [round(1e3 * t, 3) for t in times], "dtype": "f32",
+           "loss_first": round(float(first), 3), "loss_last": round(float(last), 3),
+           "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+           "mfma_algorithmic_gflop_per_step": round(gflop, 1),
+           "whole_step_frac_of_fp32_mfma_peak": round(gflop / (med * 1e3) / PEAK_FP32_MFMA_TFLOPS, 4),
+           "hip_kernels_ms_per_step": round(sum(k["ms_per_step"] for k in kernels), 3),
+           "hip_launches_per_step": sum(k["launches_per_step"] for k in kernels),
+           "instrumentation": info, "kernels": kernels}
+    if traffic:
+        rec["traffic"] = {"source": f"{source} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 on gfx950; conv = 2-D + 3-D "
+                                    "forward and input-gradient launches, wgrad = 2-D + 3-D)",
+                          "hbm_bytes_per_step": {k: {"read": round(v["read_bytes_per_forward"]), "write": round(v["write_bytes_per_forward"]),
+                                                     "total": round(v["hbm_bytes_per_forward"]), "launches": v["launches_per_forward"]}
+                                                 for k, v in traffic.items()}}
+    if stock_steps > 0:
+        # the same step through PyTorch-ROCm's own autograd (MIOpen convs, ATen grid_sample / BatchNorm): a stated baseline
+        layers._TRAIN_STOCK = True
+        try:
+            sopt = torch.optim.Adam(model.parameters(), lr=1e-3)
+            step(sopt)                                   # warm-up (MIOpen find)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(stock_steps):
+                step(sopt)
+            torch.cuda.synchronize()
+            st = (time.perf_counter() - t0) / stock_steps
+            rec["stock_pytorch_rocm_baseline"] = {"ms_per_step": round(1e3 * st, 1), "samples_per_s": round(1.0 / st, 3), "steps": stock_steps,
+                                                  "note": "same model, inputs and step through torch autograd on this GPU (MDF_TRAIN_STOCK route)",
+                                                  "speedup": round(st / med, 1)}
+        finally:
+            layers._TRAIN_STOCK = False
+    return rec
 
 
 def cpu_baseline(timed_views=3):
@@ -177,16 +345,27 @@ def main():
                     help="items in flight on that many HIP streams (the eval driver's pipelining); 1 = strictly one at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--blocks", type=int, default=3,
+                    help="the K-step timed block is repeated this many times (each one barrier + synchronize bracketed); the "
+                         "MEDIAN block is reported, all of them under `blocks_ms_per_step`")
+    ap.add_argument("--rank-timeout", type=float, default=1500.0,
+                    help="self-launched multi-rank runs (plain `python bench.py --gpus N`): seconds after which all ranks are stopped")
+    ap.add_argument("--no-training", action="store_true", help="skip the BASELINE configs[2] training-step block (rank 0, N=1)")
+    ap.add_argument("--train-steps", type=int, default=20)
+    ap.add_argument("--train-stock-steps", type=int, default=2, help="steps of the stock PyTorch-ROCm autograd baseline (0 = skip)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks ourselves, before this process touches the GPU (no HIP call
         # has happened yet; the children are fresh subprocesses, nothing is exec'ed over an initialised process)
         from mdfnet_hip import shard
-        raise SystemExit(shard.launch_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+        raise SystemExit(shard.launch_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:], timeout=args.rank_timeout))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:      # own share of the host cores, set in-process before the first HIP call (is_available() below is one)
+        from mdfnet_hip import shard
+        shard.pin_rank_affinity(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); the product path has no CPU fallback")
     # rehearsal knobs for a 1-GPU box (never set by the driver): several ranks on one card, gloo instead of RCCL
@@ -235,36 +414,46 @@ def main():
         for _ in range(max(args.warmup, 2 * args.in_flight if args.in_flight > 1 else 0)):   # also warms each stream's allocator pool
             one_step()
         pipe.drain()
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            one_step()
-        pipe.drain()
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        block_dts = []
+        for _ in range(max(1, args.blocks)):
+            # one block = EXACTLY K steps bracketed by barrier + synchronize on both sides, max over ranks
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                one_step()
+            pipe.drain()
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            bdt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([bdt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                bdt = float(t.item())
+            block_dts.append(bdt)
+        dt = sorted(block_dts)[len(block_dts) // 2]          # the median block
         out = last["out"]
         # the same K steps strictly one at a time (latency view of the same work), rank 0 only, outside the timed region
         dt_serial = None
         if rank == 0 and args.in_flight > 1:
-            torch.cuda.synchronize()
-            ts = time.perf_counter()
-            for _ in range(args.steps):
-                model(inputs[0], *fresh_cameras())
-            torch.cuda.synchronize()
-            dt_serial = time.perf_counter() - ts
+            ser = []
+            for _ in range(max(1, args.blocks)):
+                torch.cuda.synchronize()
+                ts = time.perf_counter()
+                for _ in range(args.steps):
+                    model(inputs[0], *fresh_cameras())
+                torch.cuda.synchronize()
+                ser.append(time.perf_counter() - ts)
+            dt_serial = sorted(ser)[len(ser) // 2]
     assert torch.isfinite(out["depth"]).all()
-    if world > 1:
-        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
-    kernels, cpu = None, None
+    kernels, cpu, prof_info, training = None, None, None, None
     if rank == 0 and not args.no_profile:
-        kernels = profile_pass(model, inputs)
+        kernels, prof_info = profile_pass(model, inputs)
+    if rank == 0 and world == 1 and not args.no_training:
+        training = training_block(dev, args.train_steps, max(1, args.blocks), args.train_stock_steps)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
     if rank == 0:
@@ -272,6 +461,8 @@ def main():
         rec = {"metric": "views/sec at DTU 1600x1200x5-view x4-scale", "value": round(views_per_s, 3), "unit": "views/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
                "items_in_flight": args.in_flight,
+               "blocks_ms_per_step": {"all": [round(1e3 * b / args.steps, 3) for b in block_dts], "reported": "median",
+                                      "min": round(1e3 * min(block_dts) / args.steps, 3), "max": round(1e3 * max(block_dts) / args.steps, 3)},
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"DTU eval {WIDTH}x{HEIGHT} (1600x1200 cropped as load/dtueval.py:34), {VIEWS} views, "
                                       "3 cost-volume stages + x2 refine = 4 output scales, hypotheses (48,24,8), batch 1 per rank, "
@@ -286,15 +477,8 @@ def main():
         if kernels:
             # dominant kernel = the MFMA implicit-GEMM conv kernel (one template family, conv_lds.hip/conv3d.hip), summed
             # over its 2-D and 3-D launches: algorithmic flops / summed launch time
-            traffic = measured_traffic()
-            fam_of = {"conv": "mfma_conv", "warp": "warp_aggregate", "prob": "prob_head"}
-            for k in kernels:
-                key = next((v for pre, v in fam_of.items() if k["kernel"].startswith(pre)), None)
-                if key in traffic:
-                    k["traffic"] = {"hbm_bytes_per_step": round(traffic[key]["hbm_bytes_per_forward"]),
-                                    "read": round(traffic[key]["read_bytes_per_forward"]),
-                                    "write": round(traffic[key]["write_bytes_per_forward"]),
-                                    "source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 on gfx950)"}
+            traffic, tsource = measured_traffic("eval")
+            attach_traffic(kernels, traffic, tsource, (("conv", "mfma_conv"), ("warp", "warp_aggregate"), ("prob", "prob_head")))
             mf = [k for k in kernels if k["bound"] == "mfma" and "achieved" in k]
             if mf:
                 ms = sum(k["ms_per_step"] for k in mf)
@@ -304,7 +488,8 @@ def main():
                                    "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                                    "traffic": (round(traffic["mfma_conv"]["hbm_bytes_per_forward"]) if "mfma_conv" in traffic else None),
-                                   "traffic_unit": "HBM bytes per step over all launches of the family (PMC, offline)",
+                                   "traffic_unit": f"HBM bytes per step over all launches of the family (PMC, offline: {tsource})",
+                                   "instrumentation": prof_info,
                                    "mode": "one view at a time on one stream (profile pass after the timed region: per-launch HIP events "
                                            "on the launch stream); compare with one_at_a_time, not with the in-flight headline",
                                    "ms_per_step": round(ms, 3),
@@ -312,6 +497,8 @@ def main():
                                    "algorithmic_gflop_per_step": round(gf, 1)}
             rec["kernels"] = kernels
             rec["hip_kernels_ms_per_step"] = round(sum(k["ms_per_step"] for k in kernels), 3)
+        if training:
+            rec["training"] = training
         if cpu:
             rec["cpu_baseline"] = cpu
         print(json.dumps(rec), flush=True)

@@ -39,6 +39,7 @@ struct TrainParams {
   Geom g;
   int B, D, n_src, hypos_per_pixel, dchunk, nblk_x;
   int dslice;             // planes per blockIdx.z (the depth range is cut into gridDim.z slices: more blocks for the small cfg3 maps)
+  int all_atomic;         // debug (MDF_WARP_BWD_ATOMIC=1): every window update is an LDS atomic -- the checker of the claim-based plain adds
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -324,9 +325,16 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
       const float mu = vpar[4 * v + 2], is = vpar[4 * v + 3];
       float pend0[4] = {0.f, 0.f, 0.f, 0.f}, pend1[4] = {0.f, 0.f, 0.f, 0.f};   // pending tap sums of the current corner set
       int cxa = -1, cxb = -1, cya = -1, cyb = -1;
+      // Tap liveness comes from the WEIGHTS (a tap whose weight was non-zero for some pending plane), never from the pending
+      // value: an out-of-bounds tap has weight 0 and lies outside the bounding box `bb` (built from the same weight test), but
+      // 0 * (non-finite gradient) = NaN would pass a value test and index the window out of range.  grid_sample's backward
+      // likewise adds nothing for out-of-bounds taps and propagates NaN through the in-bounds ones.
+      unsigned lm = 0;
       auto flush_taps = [&](int xa, int xb, int ya, int yb) {
         bool plain = false;
-        if (use_win) {
+        const unsigned m = lm;
+        lm = 0;
+        if (use_win && !p.all_atomic) {
           const int slot = min(max((ya - ymin) * ww + (xa - xmin), 0), kWinFloats / 8 - 1);   // the window texel of (xa,ya): no false sharing
           my_claim[slot] = (unsigned char)pl;
           plain = (my_claim[slot] == (unsigned char)pl) && (xb == xa + 1) && (yb == ya + 1);
@@ -337,7 +345,7 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
         if (plain) {          // this pixel owns its texels among the pixels flushing in this instruction
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            if (a0[k] != 0.0f || a1[k] != 0.0f) {      // zero-weight (out-of-bounds) taps never leave the registers
+            if (m & (1u << k)) {      // zero-weight (out-of-bounds) taps never leave the registers
               const int tx = (k & 1) ? xb : xa, ty = (k & 2) ? yb : ya;
               float2* o = reinterpret_cast<float2*>(win + ((ty - ymin) * ww + (tx - xmin)) * G + 2 * sub);
               float2 cur = *o;
@@ -349,7 +357,7 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
         } else {
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            if (a0[k] != 0.0f || a1[k] != 0.0f) {
+            if (m & (1u << k)) {
               const int tx = (k & 1) ? xb : xa, ty = (k & 2) ? yb : ya;
               if (use_win) {
                 float* o = win + ((ty - ymin) * ww + (tx - xmin)) * G + 2 * sub;
@@ -405,6 +413,7 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
           for (int k = 0; k < 4; ++k) {
             pend0[k] = fmaf(t.wt[k], g0, pend0[k]);
             pend1[k] = fmaf(t.wt[k], g1, pend1[k]);
+            lm |= (t.wt[k] != 0.0f) ? (1u << k) : 0u;      // NaN weights (z == 0 planes) count as live, as in `bb`
           }
         }
       }
@@ -473,6 +482,8 @@ int launch_bwd(TrainParams& p, int C, hipStream_t st) {
   if (dch < 1) dch = 1;
   const int nz = depth_slices(p, dch);
   p.dchunk = dch;
+  const char* dbg = getenv("MDF_WARP_BWD_ATOMIC");      // read per call: tests flip it inside one process
+  p.all_atomic = (dbg && atoi(dbg) > 0) ? 1 : 0;
   const size_t lds = (size_t)dch * p.n_src * ppb * sizeof(TapXY) + (size_t)kWinFloats * sizeof(float);
   dim3 grid(p.nblk_x, p.B, nz), block(kThreads);
   switch (C) {

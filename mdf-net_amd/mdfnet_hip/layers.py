@@ -94,16 +94,18 @@ def model_mode(training):
 
 
 def use_hip(mod, *tensors):
-    """Slot dispatch.  Inference (module in eval mode / no autograd graph wanted) runs the hand-written kernels and
-    REFUSES CPU tensors -- there is no CPU fallback.  Training (module.training, an enclosing CoreNet in training mode,
-    or inputs that require grad) runs the stock-op path of mdfnet_hip/stockops.py.  `mod` is None for plain functions."""
+    """Slot dispatch for INFERENCE.  A module in eval mode with no autograd graph wanted runs the hand-written eval kernels and
+    REFUSES CPU tensors -- there is no CPU fallback.  Returns False in training mode (module.training, an enclosing CoreNet in
+    training mode, or inputs that require grad): the callers have asked `hip_train` first (GPU tensors -> the hand-written
+    training kernels of train_ops.py), so what is left is CPU tensors / MDF_TRAIN_STOCK, i.e. mdfnet_hip/stockops.py.
+    `mod` is None for plain functions."""
     ts = [t for t in tensors if isinstance(t, torch.Tensor)]
     training = mod.training if mod is not None else bool(getattr(_mode, "training", False))
     if training or (torch.is_grad_enabled() and any(t.requires_grad for t in ts)):
         return False
     if not all(t.is_cuda for t in ts):
         raise RuntimeError("inference slots run on hand-written MI355X kernels only (got a CPU tensor); there is no CPU "
-                           "fallback -- model.train() selects the stock-op training path")
+                           "fallback (training mode on CPU tensors is the stock-op rehearsal path of mdfnet_hip/stockops.py)")
     return True
 
 

@@ -23,6 +23,27 @@ class FlatAdam(torch.optim.Optimizer):
         self.steps = 0
         self._table = None
 
+    # The moments live in two flat buffers, not in torch's per-parameter `state`: carry them (and the step count that drives
+    # the bias correction) through state_dict()/load_state_dict() so optimizer checkpointing cannot silently reset them.
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["flat_adam"] = {"exp_avg": self.exp_avg.detach().clone(), "exp_avg_sq": self.exp_avg_sq.detach().clone(), "steps": int(self.steps)}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        flat = state_dict.pop("flat_adam", None)
+        if flat is None:
+            raise MdfHipError("FlatAdam.load_state_dict: no 'flat_adam' entry (moments + step count); a torch.optim.Adam state cannot "
+                              "be loaded into the flat buffers")
+        if flat["exp_avg"].numel() != self.exp_avg.numel():
+            raise MdfHipError(f"FlatAdam.load_state_dict: {flat['exp_avg'].numel()} moment elements for a bucket of {self.exp_avg.numel()}")
+        super().load_state_dict(state_dict)
+        with torch.no_grad():
+            self.exp_avg.copy_(flat["exp_avg"])
+            self.exp_avg_sq.copy_(flat["exp_avg_sq"])
+        self.steps = int(flat["steps"])
+
     def _build_table(self):
         params = self.bucket.params
         L = lib()

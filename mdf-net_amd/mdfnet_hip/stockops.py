@@ -1,11 +1,12 @@
-"""Stock PyTorch-op implementations of the hot-path slots for the TRAINING path.
+"""Stock PyTorch-op restatement of the hot-path slots in TRAINING mode -- NOT the product's GPU training path.
 
-`model.train()` needs autograd through every slot and train-mode BatchNorm (batch statistics, including the
-1-channel BatchNorm3d inside VectorAggregate).  The hand-written kernels are forward/eval-only this round, so the
-training mode of each slot is written with plain torch ops (device-agnostic; on an MI355X they run PyTorch-ROCm).
-This is an explicit mode, selected by `module.training` / `requires_grad`, never a silent fallback for inference:
-the eval path has no stock-op route (net/core.py raises without a GPU).  Arithmetic follows the reference:
-net/unit/base.py:85-126, homoaggregate.py:25-69, depthhypos.py:27-215, regress.py:5-25."""
+On an MI355X `model.train()` runs the hand-written training kernels (mdfnet_hip/train_ops.py).  This module is what a
+slot runs for CPU tensors in training mode, and exists for two things only: the gloo rehearsals of the data-parallel
+driver on machines without a GPU (tests/test_train_cpu.py, tests/test_train_data_cpu.py), and -- pinned there to the
+reference's own training golden (loss + gradients, rtol 1e-4) -- as the same-host autograd checker of tests/test_train_gpu.py.
+`MDF_TRAIN_STOCK=1` (bench.py's stated PyTorch-ROCm baseline, scripts/bench_train.py) routes GPU tensors here for an A/B.
+It is an explicit mode, never a silent fallback: inference has no stock-op route (net/core.py raises without a GPU).
+Arithmetic follows the reference: net/unit/base.py:85-126, homoaggregate.py:25-69, depthhypos.py:27-215, regress.py:5-25."""
 import torch
 import torch.nn.functional as F
 

@@ -17,7 +17,12 @@ from . import lib
 from . import ops
 from .ops import _abi, _f32c, _need_gpu, _stream, _src_array, _hypos_arg
 
-BN_MOMENTUM = 0.1
+def _momentum(bn):
+    """nn.BatchNorm's momentum=None means a CUMULATIVE average (factor 1/num_batches_tracked), which the finalize kernels do
+    not implement; the reference never uses it (base.py:50-68: default 0.1)."""
+    if bn.momentum is None:
+        raise NotImplementedError("BatchNorm(momentum=None) (cumulative moving average) is not built into the training kernels")
+    return bn.momentum
 
 
 # --------------------------------------------------------------------------- BatchNorm(batch stats) + ReLU
@@ -68,7 +73,7 @@ def bn_finalize(sums, bn, n, c, groups=1):
     nn.BatchNorm.train()."""
     aux = torch.empty(groups * 4 * c, device=sums.device, dtype=torch.float32)
     track = bn.track_running_stats and bn.running_mean is not None
-    mom = BN_MOMENTUM if bn.momentum is None else bn.momentum
+    mom = _momentum(bn)
     _abi("mdf_bn_finalize_fwd", (sums.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), ctypes.c_float(bn.eps), ctypes.c_float(mom),
                                  n, c, groups, aux.data_ptr(), bn.running_mean.data_ptr() if track else None,
                                  bn.running_var.data_ptr() if track else None,
@@ -81,7 +86,7 @@ def bn_finalize_apply(sums, bn, y, res, n, c, groups=1):
     aux = torch.empty(groups * 4 * c, device=y.device, dtype=torch.float32)
     z = torch.empty_like(y)
     track = bn.track_running_stats and bn.running_mean is not None
-    mom = BN_MOMENTUM if bn.momentum is None else bn.momentum
+    mom = _momentum(bn)
     _abi("mdf_bn_finalize_apply_fwd", (y.data_ptr(), sums.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), ctypes.c_float(bn.eps),
                                        ctypes.c_float(mom), None if res is None else res.data_ptr(), z.data_ptr(), aux.data_ptr(),
                                        bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
@@ -306,7 +311,7 @@ class AggregateTrainFn(torch.autograd.Function):
                                              red.data_ptr(), 2 * nsrc, st))
         _agg_call(_PASS_STATS, feas[0], feas[1:], proj, hyp, pp, par, None, None, None, None, red, None, None, None, b, c, g, d, h, w)
         track = bn.track_running_stats and bn.running_mean is not None
-        mom = BN_MOMENTUM if bn.momentum is None else bn.momentum
+        mom = _momentum(bn)
         _abi("mdf_aggregate_train_finalize", (red.data_ptr(), gmd.data_ptr(), btd.data_ptr(), ctypes.c_float(bn.eps), ctypes.c_float(mom), n, g,
                                               nsrc, par.data_ptr(), bn.running_mean.data_ptr() if track else None,
                                               bn.running_var.data_ptr() if track else None,

@@ -56,7 +56,7 @@ class CoreNet(torch.nn.Module):
         -> train: {"depth": [1/8, 1/4, 1/2, 1/1]};  eval: {"depth": [B,H,W], "confidence": [B,H,W]}."""
         if not self.training and not origin_imgs.is_cuda:
             raise RuntimeError("CoreNet inference runs on hand-written MI355X kernels only: move the model and inputs to a "
-                               "GPU (there is no CPU fallback; model.train() selects the stock-op training path)")
+                               "GPU (there is no CPU fallback; model.train() on a GPU runs the hand-written training kernels)")
         if origin_imgs.is_cuda:
             # one device->host hop for the control-plane tensors (cameras, range); the slots then find host
             # mirrors and never synchronise again

@@ -24,7 +24,9 @@ class Loss(torch.nn.Module):
                 # the same masked mean without boolean indexing: `e[valid]` has a data-dependent size, i.e. a device->host
                 # synchronisation in the middle of every training step
                 per = F.smooth_l1_loss(e, gt, reduction="none")
-                total = total + (per * valid).sum() / valid.sum()
+                # where(), not `per * valid`: a non-finite estimate at an INVALID pixel must not poison the sum (NaN * 0 = NaN);
+                # the reference's e[valid] never sees it
+                total = total + torch.where(valid, per, per.new_zeros(())).sum() / valid.sum()
             else:
                 total = total + F.smooth_l1_loss(e[valid], gt[valid], reduction="mean")
         return total

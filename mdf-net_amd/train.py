@@ -1,8 +1,9 @@
 """Training driver (counterpart of the reference's train.py:11-110): same CLI (-p/-d/-l), Adam lr 1e-3 with the poly
 decay lr*(1-(e-1)/E)^0.9, per-epoch checkpoint {'epoch','model'} without a `module.` prefix, epoch_loss.txt.
 Data parallel = one process per GPU (`torchrun --nproc-per-node N train.py ...`): flat-bucket gradient all-reduce
-over RCCL (mdfnet_hip/ddp.py) instead of nn.DataParallel.  The model's training mode runs the stock-op path
-(mdfnet_hip/stockops.py); the hand-written kernels serve inference."""
+over RCCL (mdfnet_hip/ddp.py) instead of nn.DataParallel.  On a GPU the model's training mode runs the hand-written
+training kernels (mdfnet_hip/train_ops.py: forward + backward of every slot, the loss, one-launch Adam); CPU tensors take
+the stock-op restatement (mdfnet_hip/stockops.py), which exists for the gloo rehearsals and as the tests' same-host checker."""
 import argparse
 import logging
 import os
@@ -34,6 +35,17 @@ def train_one_epoch(model, bucket, optimizer, loss_criterion, batches, device, l
         log("\r" + "epoch: " + str(epoch) + " batch: " + str(it + 1) + "/" + str(len(batches))
             + " time:{: .3f}".format(time.time() - t0) + " loss:{: .5f}\t".format(cur), end="", flush=True)
     return total / max(len(batches), 1)
+
+
+def split_global_batch(batch_size, world):
+    """The reference's batch_size is the GLOBAL batch (nn.DataParallel scatters it over the GPUs, train.py:24-26, config.py:54,74);
+    here every rank takes batch_size / world samples.  A batch the ranks cannot share equally would silently change the
+    optimisation (6 on 4 ranks -> 4, 6 on 8 ranks -> 8): refuse it, naming the choices."""
+    if batch_size % world != 0:
+        ok = [d for d in range(1, batch_size + 1) if batch_size % d == 0]
+        raise SystemExit(f"train.py: global batch_size {batch_size} does not divide over {world} ranks (each rank must take the same "
+                         f"share); use a world size in {ok} or change batch_size in config.py")
+    return batch_size // world
 
 
 def main():
@@ -73,7 +85,7 @@ def main():
     optimizer = FlatAdam(bucket, lr=train_args.lr)
     initial = {k: v.detach().cpu().clone() for k, v in model.named_parameters()} if dump_dir else None
     criterion = loss_mod.Loss().to(device)
-    per_rank = max(train_args.batch_size // world, 1)       # the reference's batch is the GLOBAL batch (DataParallel scatter)
+    per_rank = split_global_batch(train_args.batch_size, world)
     sampler = DistributedSampler(dataset, world, rank, shuffle=True, drop_last=True) if world > 1 else None
     batches = DataLoader(dataset, batch_size=per_rank, shuffle=(sampler is None), sampler=sampler,
                          num_workers=train_args.nworks, drop_last=True, pin_memory=True)

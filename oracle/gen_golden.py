@@ -79,6 +79,40 @@ class HostValueRecorder:
         return out
 
 
+def gen_train(model, sd, ref_loss):
+    """Training-mode golden: one forward + Loss + backward of the real reference at 96x64x3, batch 2 (train.py:36-45).  The
+    host-side control-plane values of the run (projection products, camera products, the gauss-fit row, the log thresholds)
+    are recorded like for the e2e goldens, so that the GPU test can be given the build host's own LAPACK/BLAS results and be
+    held to the eval leg's bars."""
+    model.train()
+    model.load_state_dict(sd)
+    model.zero_grad()
+    imgs, extr, intr, dr = synth.make_scene(96, 64, 3, batch=2, rot_deg=3.0, seed=31)
+    rng = np.random.RandomState(7)
+    gt = {k: torch.from_numpy((425 + 510 * rng.rand(2, 64 // s, 96 // s)).astype(np.float32))
+          for k, s in (("3", 8), ("2", 4), ("1", 2), ("0", 1))}
+    gt["3"][:, :2] = 0.0  # masked-out region (gt <= depth_min)
+    with HostValueRecorder() as rec:
+        out = model(imgs, extr, intr, dr)
+    loss = ref_loss.Loss()(out, gt, dr)
+    loss.backward()
+    tg = {"loss": npy(loss)}
+    tg.update(rec.values(3))
+    for st in (1, 2):
+        tg[f"host_log_thresh{st}"] = npy(torch.log(model.Depth_hypos[st].prob_thresh))
+    for i, d in enumerate(out["depth"]):
+        tg[f"depth{i}"] = npy(d)
+    params = dict(model.named_parameters())
+    for k in ("Backbone.conv01.0.conv.weight", "Homoaggre.0.depth_weight.0.conv.weight",
+              "Homoaggre.2.depth_weight.1.bias", "Regular.2.prob.weight", "Regular.0.conv01.0.conv.weight",
+              "Refine.conv2.2.weight"):
+        tg["grad:" + k] = npy(params[k].grad)
+    for k in gt:
+        tg["gt" + k] = npy(gt[k])
+    np.savez_compressed(os.path.join(OUT, "train_tiny.npz"), **tg)
+    print("train loss", float(loss))
+
+
 def gen_io():
     """PFM bytes written by the reference's tools/data_io.py:44-71 for a known array, and its parse of a pair file."""
     import tempfile
@@ -177,6 +211,8 @@ def main():
     sd = synth.seeded_state_dict(model.state_dict(), seed=1)
     model.load_state_dict(sd)
     model.eval()
+    if "--only-train" in sys.argv:
+        return gen_train(model, sd, ref_loss)
     meta = {k: list(v.shape) for k, v in model.state_dict().items()}
     np.savez(os.path.join(OUT, "state_dict_meta.npz"),
              keys=np.array(list(meta.keys())), shapes=np.array([str(s) for s in meta.values()]),
@@ -287,29 +323,7 @@ def main():
     e2e("e2e_cfg1.npz", 160, 128, 3, 1, 0.0, 0, False)       # BASELINE config 1 shape
     e2e("e2e_5view.npz", 320, 256, 5, 1, 5.0, 21, False)
 
-    # ------------------------------------------------------------------ training-mode golden
-    model.train()
-    model.load_state_dict(sd)
-    imgs, extr, intr, dr = synth.make_scene(96, 64, 3, batch=2, rot_deg=3.0, seed=31)
-    rng = np.random.RandomState(7)
-    gt = {k: torch.from_numpy((425 + 510 * rng.rand(2, 64 // s, 96 // s)).astype(np.float32))
-          for k, s in (("3", 8), ("2", 4), ("1", 2), ("0", 1))}
-    gt["3"][:, :2] = 0.0  # masked-out region (gt <= depth_min)
-    out = model(imgs, extr, intr, dr)
-    loss = ref_loss.Loss()(out, gt, dr)
-    loss.backward()
-    tg = {"loss": npy(loss)}
-    for i, d in enumerate(out["depth"]):
-        tg[f"depth{i}"] = npy(d)
-    params = dict(model.named_parameters())
-    for k in ("Backbone.conv01.0.conv.weight", "Homoaggre.0.depth_weight.0.conv.weight",
-              "Homoaggre.2.depth_weight.1.bias", "Regular.2.prob.weight", "Regular.0.conv01.0.conv.weight",
-              "Refine.conv2.2.weight"):
-        tg["grad:" + k] = npy(params[k].grad)
-    for k in gt:
-        tg["gt" + k] = npy(gt[k])
-    np.savez_compressed(os.path.join(OUT, "train_tiny.npz"), **tg)
-    print("train loss", float(loss))
+    gen_train(model, sd, ref_loss)
     gen_io()
     gen_filter()
     for f in sorted(os.listdir(OUT)):

@@ -136,8 +136,11 @@ def test_regulariser_vs_reference_golden(golden, seeded_sd, stage):
     np.testing.assert_allclose(d2.cpu().numpy(), g[f"reg{stage}_depth"], rtol=0, atol=3e-4)
 
 
-def test_train_mode_uses_stock_path_with_autograd(seeded_sd):
-    """model.train() selects the stock-op training path (batch-stat BN, autograd) -- an explicit mode, not a fallback."""
+def test_train_mode_runs_the_hip_training_kernels_with_autograd(seeded_sd):
+    """model.train() on a GPU puts the regulariser's forward + backward on the hand-written training kernels
+    (mdfnet_hip/train_ops.py:RegulariserTrainFn; batch-statistics BN) behind autograd -- an explicit mode, not a fallback."""
+    from mdfnet_hip import ops as _ops
+    _ops.count_begin()
     model = build_model()
     model.load_state_dict(seeded_sd)
     model.train().to(DEV)
@@ -145,7 +148,9 @@ def test_train_mode_uses_stock_path_with_autograd(seeded_sd):
     prob = model.Regular[1](x)
     assert prob.shape == (2, 16, 16, 16) and prob.requires_grad
     prob.sum().backward()
+    calls = _ops.count_end()
     assert x.grad is not None and model.Regular[1].prob.weight.grad is not None
+    assert calls.get("mdf_conv3d_wgrad", 0) > 0 and calls.get("mdf_bn_relu_bwd", 0) > 0, calls
 
 
 @pytest.mark.parametrize("cin,D,h,w", [(8, 8, 37, 53), (16, 48, 20, 70), (8, 24, 16, 16), (16, 3, 9, 65), (8, 1, 5, 7), (8, 60, 6, 6)])

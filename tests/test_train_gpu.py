@@ -161,6 +161,94 @@ def test_vector_aggregate_training_forward_backward(stage, b, h, w, nviews, per_
         assert _rel(pa.grad, pr.grad) < (5e-4 if pa.numel() > 1 else 1e-2), k
 
 
+def _aggregate_case(stage, width, height, nviews, seed, hyp_spread=20.0):
+    """Homoaggre[stage] in training mode at the stage's share of a width x height item: (module, device inputs)."""
+    from net.unit.homoaggregate import VectorAggregate
+    from net.unit.scale import scale_cam
+    c, g, d = ((64, 32, 48), (32, 16, 24), (16, 8, 8))[stage]
+    h, w = height >> (3 - stage), width >> (3 - stage)
+    torch.manual_seed(seed)
+    mod = VectorAggregate(g)
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.add_(0.3 * torch.randn_like(p))
+    intr, extr, dr = synth.make_cameras(width, height, nviews, batch=1, rot_deg=2.0, seed=seed + 7)
+    rp, sps = scale_cam(intr, extr, stage)
+    feats = [torch.randn(1, c, h, w) for _ in range(nviews)]
+    if stage == 0:
+        hyp = torch.linspace(425, 935, d).reshape(1, d, 1, 1)
+    else:
+        hyp = (425 + 510 * torch.rand(1, 1, h, w)) + torch.linspace(-hyp_spread, hyp_spread, d).reshape(1, d, 1, 1)
+    return mod.train().to(DEV), feats, rp, sps, hyp
+
+
+@pytest.mark.parametrize("stage", [0, 1, 2])
+def test_aggregate_scatter_claim_vs_all_atomics_full_size(stage, monkeypatch):
+    """the claim-based NON-atomic LDS window updates of warp_bwd_kernel (csrc/warp_aggregate_train.hip) at the
+    full cfg3 size (768x576, 5 views: 96x72x64ch, 192x144x32ch, 384x288x16ch), where a lost add would pass every finite /
+    loss-decreasing check: d src and d ref against the SAME pass with every window update an LDS atomic (MDF_WARP_BWD_ATOMIC=1,
+    read per call).  The two differ by fp32 summation order only.  (homoaggregate.py:16-20,35-46 backward)"""
+    mod, feats, rp, sps, hyp = _aggregate_case(stage, 768, 576, 5, seed=40 + stage)
+    torch.manual_seed(stage)
+    grads = {}
+    for mode in ("claim", "atomic"):
+        if mode == "atomic":
+            monkeypatch.setenv("MDF_WARP_BWD_ATOMIC", "1")
+        else:
+            monkeypatch.delenv("MDF_WARP_BWD_ATOMIC", raising=False)
+        fd = [f.to(DEV).requires_grad_(True) for f in feats]
+        cost = mod(fd, rp.to(DEV), tuple(s.to(DEV) for s in sps), hyp.to(DEV))
+        if mode == "claim":
+            dcost = torch.randn_like(cost)
+        cost.backward(dcost)
+        grads[mode] = [f.grad.clone() for f in fd] + [p.grad.clone() for p in mod.parameters()]
+        mod.zero_grad()
+    monkeypatch.delenv("MDF_WARP_BWD_ATOMIC", raising=False)
+    worst = 0.0
+    for i, (a, b) in enumerate(zip(grads["claim"], grads["atomic"])):
+        assert torch.isfinite(a).all() and float(b.abs().max()) > 0
+        e_max, e_l2 = _rel(a, b), _l2(a, b)
+        worst = max(worst, e_max)
+        # a lost add drops one tap contribution: ~1e-2..1 of that texel's value; reordering fp32 sums of <= a few hundred terms: ~1e-6
+        assert e_max < 2e-5 and e_l2 < 2e-6, (i, e_max, e_l2)
+    print(f"\nstage {stage}: claim-based vs all-atomic scatter, worst max-rel difference {worst:.2e}")
+
+
+@pytest.mark.parametrize("stage", [0, 2])
+def test_aggregate_backward_nonfinite_gradient_does_not_fault(stage):
+    """a non-finite upstream gradient (a diverged step, or the NaN statistics a z == 0 plane gives) must propagate as
+    NaN like torch's grid_sample backward -- and must not index the scatter's LDS window out of range: an out-of-bounds tap has
+    weight 0, lies outside the window's bounding box, and 0 * NaN = NaN used to pass the kernel's `value != 0` liveness test."""
+    mod, feats, rp, sps, hyp = _aggregate_case(stage, 256, 192, 4, seed=60 + stage, hyp_spread=200.0)
+    # strong parallax + a wide depth range: many samples leave the source maps (out-of-bounds taps next to live ones)
+    sps = tuple(s.clone() for s in sps)
+    for i, s_ in enumerate(sps):
+        s_[:, 0, 3] += (-1) ** i * 0.4 * (256 >> (3 - stage)) * 650.0      # ~0.4 map widths of shift at mid range
+    fd = [f.to(DEV).requires_grad_(True) for f in feats]
+    cost = mod(fd, rp.to(DEV), tuple(s.to(DEV) for s in sps), hyp.to(DEV))
+    dcost = torch.randn_like(cost)
+    dcost[:, :, ::2] = float("nan")
+    dcost[:, :, 1, ::3] = float("inf")
+    cost.backward(dcost)
+    torch.cuda.synchronize()                       # a fault would surface here
+    assert torch.isnan(fd[1].grad).any() and torch.isnan(fd[0].grad).any()
+    # z == 0 for every sample of source view 0 (row 2 of its projection zeroed, as the H4 golden does): NaN positions, NaN statistics
+    sps0 = tuple(s.clone() for s in sps)
+    sps0[0][:, 2, :] = 0.0
+    mod.zero_grad()
+    fd = [f.to(DEV).requires_grad_(True) for f in feats]
+    cost = mod(fd, rp.to(DEV), tuple(s.to(DEV) for s in sps0), hyp.to(DEV))
+    cost.backward(torch.randn_like(cost))
+    torch.cuda.synchronize()
+    assert torch.isnan(cost).any()
+    # and the device still computes: the finite case right after
+    mod.zero_grad()
+    fd = [f.to(DEV).requires_grad_(True) for f in feats]
+    cost = mod(fd, rp.to(DEV), tuple(s.to(DEV) for s in sps), hyp.to(DEV))
+    cost.backward(torch.randn_like(cost))
+    assert torch.isfinite(cost).all() and all(torch.isfinite(f.grad).all() for f in fd)
+
+
 @pytest.mark.parametrize("weights", ["default_init", "seeded_peaked"])
 @pytest.mark.parametrize("stage", [0, 1, 2])
 def test_regulariser_training_forward_backward(stage, weights, seeded_sd):
@@ -237,8 +325,15 @@ def test_training_step_on_gpu_vs_reference_golden(golden, seeded_sd):
     used = []
     orig = train_ops._abi
     train_ops._abi = lambda name, *a, **k: (used.append(name), orig(name, *a, **k))[1]
+    # the host-side control-plane values (projection / camera products, gauss-fit row, log thresholds) are the BUILD host's,
+    # recorded while the reference produced this golden (oracle/gen_golden.py:gen_train): everything the GPU computes is then
+    # compared with the reference's own training step at the eval leg's bars, on any host
+    rec = ops.recorded_host_values(projs=[g[f"host_proj{st}"] for st in range(3)], cams=[g[f"host_cam{st}"] for st in range(3)],
+                                   fit_row=g["host_fit_row"],
+                                   log_thresh={1: float(g["host_log_thresh1"]), 2: float(g["host_log_thresh2"])})
     try:
-        out, loss = _step(m, DEV, g)
+        with rec:
+            out, loss = _step(m, DEV, g)
         bucket.zero_grad()
         loss.backward()
     finally:
@@ -248,10 +343,9 @@ def test_training_step_on_gpu_vs_reference_golden(golden, seeded_sd):
     for i, d in enumerate(out["depth"]):
         err = np.abs(d.detach().cpu().numpy() - g[f"depth{i}"])
         print(f"\ndepth{i}: max |d| vs reference {err.max():.3e} mean {err.mean():.3e}")
-        # cross-host leg (goldens from the build host, SURVEY H2/H3: the fit row / projections of THIS host's LAPACK differ,
-        # 1.2-1.4e-3 mm in eval mode) on top of train-mode BatchNorm over tiny volumes; the same-host comparison with the
-        # tight bound is test_all_parameter_gradients_vs_cpu_autograd below
-        assert err.mean() < (5e-3 if i < 3 else 2e-2) and err.max() < 0.5
+        # the metric's own bar (mean |d depth| <= 1e-3 mm) on the three cost-volume stages; the randomly initialised refinement
+        # net has gain ~4 on its input error (a trained one ~1), hence 4e-3 on the full-resolution output
+        assert err.mean() <= (1e-3 if i < 3 else 4e-3) and err.max() < 0.5, (i, err.mean(), err.max())
     np.testing.assert_allclose(float(loss.detach()), float(g["loss"]), rtol=2e-5)
     params = dict(m.named_parameters())
     assert all(p.grad is not None for p in params.values())
@@ -261,8 +355,7 @@ def test_training_step_on_gpu_vs_reference_golden(golden, seeded_sd):
             got = params[k[5:]].grad.cpu().numpy()
             rel = np.abs(got - ref).max() / np.abs(ref).max()
             print(f"{k}: max rel err {rel:.2e}")
-            # scalar parameters: cancelling sums over ~1e5 voxels whose hypotheses carry the cross-host drift (stage 2)
-            assert rel <= (5e-2 if ref.size == 1 else 5e-3), (k, rel)
+            assert rel <= 5e-3, (k, rel)
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)
     opt.step()                                      # the optimizer consumes the bucket's views
     assert torch.isfinite(torch.cat([p.detach().reshape(-1) for p in m.parameters()])).all()
