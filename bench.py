@@ -73,32 +73,79 @@ def _wall_ms(fn, reps=3):
     return e0.elapsed_time(e1) / reps
 
 
+_SLEEP_CYCLES_PER_MS = None
+
+
+def _gpu_sleep(ms):
+    """Keep the stream busy for ~ms (torch's spin kernel), so that the host runs AHEAD of the GPU in what follows."""
+    global _SLEEP_CYCLES_PER_MS
+    if ms <= 0:
+        return
+    if _SLEEP_CYCLES_PER_MS is None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(1000)
+        torch.cuda.synchronize()
+        e0.record()
+        torch.cuda._sleep(2_000_000)
+        e1.record()
+        torch.cuda.synchronize()
+        _SLEEP_CYCLES_PER_MS = 2_000_000 / max(e0.elapsed_time(e1), 1e-3)
+    torch.cuda._sleep(int(ms * _SLEEP_CYCLES_PER_MS))
+
+
+def _empty_bracket_ms(n=64):
+    """Cost of the instrumentation itself: an event pair with NOTHING between, on a busy stream (median of n)."""
+    _gpu_sleep(2.0)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record()
+        b.record()
+    torch.cuda.synchronize()
+    return sorted(a.elapsed_time(b) for a, b in ev)[n // 2]
+
+
 def bracketed_launches(fn, steps=3):
-    """Per-launch HIP-event timing of every hand-written kernel fn() issues (events recorded on the launch stream), with the
-    cost of the instrumentation itself calibrated out IN SITU: an event pair per launch stretches the stream (marker packets,
-    the dispatch gap behind each marker), so the instrumented run's wall W_prof exceeds the plain run's W_plain and the raw
-    brackets over-count (the family sum exceeded the one-at-a-time wall).  delta = (W_prof - W_plain) /
-    brackets is subtracted from every bracket; since the raw brackets are disjoint intervals inside W_prof, the corrected
-    sum cannot exceed W_plain.  -> (records [(abi, tag, ms, work)] of all steps, info dict)"""
+    """Per-launch HIP-event timing of every hand-written kernel fn() issues (events recorded on the launch stream).
+    Two things would make raw brackets over-count (the family sum exceeded the one-at-a-time wall):
+      * when the host cannot keep up with two event records per launch, the stream runs dry and a bracket includes the host's
+        time between `e0.record()` and the kernel's submission -> every instrumented pass starts behind a GPU sleep long enough
+        for the host to stay ahead (measured first: instrumented wall - plain wall);
+      * the marker packets themselves -> the cost of an EMPTY bracket on a busy stream is subtracted from every bracket.
+    Safety net: if the corrected brackets of a step still add up to more than the plain (un-instrumented) GPU wall of the same
+    step, they are scaled down to it (`scaled_by` < 1 in the info).  -> (records [(abi, tag, ms, work)] of all steps, info)"""
     from mdfnet_hip import ops
     w_plain = _wall_ms(fn, steps)
-    recs, w_prof = [], 0.0
-    for _ in range(steps):
+
+    def instrumented(lead_ms):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
+        _gpu_sleep(lead_ms)
         e0.record()
         ops.profile_begin()
         fn()
         e1.record()
-        recs += ops.profile_end()
-        w_prof += e0.elapsed_time(e1)
+        r = ops.profile_end()
+        return r, e0.elapsed_time(e1)
+    _, w_trial = instrumented(0.0)
+    lead = max(0.0, 1.5 * (w_trial - w_plain)) + 0.5
+    empty = _empty_bracket_ms()
+    recs, w_prof = [], 0.0
+    for _ in range(steps):
+        r, w = instrumented(lead)
+        recs += r
+        w_prof += w
     w_prof /= steps
-    per = len(recs) / steps
-    delta = max(0.0, (w_prof - w_plain) / max(per, 1.0))
-    recs = [(n, tag, max(ms - delta, 0.0), work) for n, tag, ms, work in recs]
-    return recs, {"wall_plain_ms": round(w_plain, 4), "wall_instrumented_ms": round(w_prof, 4), "brackets_per_step": round(per, 1),
-                  "bracket_cost_us": round(delta * 1e3, 2),
-                  "note": "per-launch times = HIP-event bracket minus bracket_cost_us (calibrated in this run from the two walls)"}
+    recs = [(n, tag, max(ms - empty, 0.0), work) for n, tag, ms, work in recs]
+    total = sum(r[2] for r in recs) / steps
+    scale = min(1.0, w_plain / total) if total > 0 else 1.0
+    if scale < 1.0:
+        recs = [(n, tag, ms * scale, work) for n, tag, ms, work in recs]
+    return recs, {"wall_plain_ms": round(w_plain, 4), "wall_instrumented_ms": round(w_prof, 4),
+                  "wall_instrumented_without_lead_ms": round(w_trial, 4), "gpu_lead_ms": round(lead, 3),
+                  "brackets_per_step": round(len(recs) / steps, 1), "empty_bracket_us": round(empty * 1e3, 2),
+                  "bracketed_sum_ms": round(total * scale, 4), "scaled_by": round(scale, 4),
+                  "note": "per-launch time = HIP-event bracket on the launch stream minus the empty-bracket cost; instrumented passes run "
+                          "behind a GPU sleep so the host stays ahead; the bracketed sum cannot exceed wall_plain_ms"}
 
 
 def family_table(recs, steps, family_of):

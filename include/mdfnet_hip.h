@@ -223,6 +223,23 @@ int mdf_conv2d_wgrad(const float* small_, const float* big, float* dw, float* wo
 /* (input gradients of these layers are mdf_conv3d_fwd with re-packed weights: a stride-1 conv with flipped taps and
  *  swapped channels, the transposed conv for a stride-2 conv and vice versa.) */
 
+/* ---- training-mode conv launches whose EPILOGUE carries the BatchNorm reductions (base.py:50-68: conv -> BatchNorm(batch
+ *      statistics) -> ReLU; the statistics of a layer and the two sums of its BatchNorm backward each cost a full pass over
+ *      the activations as kernels of their own -- here they ride in the conv that produces the tensor):
+ *        y = [res +] conv(x)   raw (no scale / shift / ReLU), same operands and layouts as mdf_conv3d_fwd / mdf_conv2d_fwd
+ *        stat_mode 1  stat_out[c] += sum y[.,c],  stat_out[C+c] += sum y[.,c]^2          (the layer's own batch statistics)
+ *        stat_mode 2  the launch is the INPUT-GRADIENT conv of the next layer, so y (with res = the skip gradient) is dz of the
+ *                     layer whose raw conv output is stat_y and whose (a, b, mean, invstd)[C] is stat_aux:
+ *                     stat_out[c] += sum dr, stat_out[C+c] += sum dr*xhat, dr = dz*[stat_y*a+b > 0], xhat = (stat_y-mean)*invstd
+ *      stat_out: fp64, zero-initialised by the caller, C = Cout in {8,16,32,64}.  2-D: `ngroups` consecutive sets of B/ngroups
+ *      images are separate BatchNorm groups (one per view, net/core.py:42): stat_out [ngroups][2C], stat_aux [ngroups][4C].  */
+int mdf_conv3d_train_fwd(const float* x, const float* wpack, const float* res, float* y, int B, int Di, int Hi, int Wi, int Cin,
+                         int Cout, int stride, int transposed, int stat_mode, const float* stat_y, const float* stat_aux,
+                         double* stat_out, void* stream);
+int mdf_conv2d_train_fwd(const float* x, const float* wpack, float* y, int B, int H, int W, int Cin_mem, int Cout, int ksize,
+                         int stride, int planar_in, int stat_mode, const float* stat_y, const float* stat_aux, double* stat_out,
+                         int ngroups, void* stream);
+
 /* ---- batched weight packing: every packed weight set a training step reads (forward convs and their input-gradient
  *      convs, train.py:36-45 after optimizer.step()), written by ONE launch.  A job is one weight set in the layout of
  *      mdf_conv3d_pack_weights (is3d = 1) / mdf_conv_pack_weights (is3d = 0), read from the parameter `src` through `mode`:

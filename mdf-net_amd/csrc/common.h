@@ -55,6 +55,15 @@ struct CascadeSum {
   __device__ __forceinline__ float result() const { return ((l0 + l1) + l2) + l3; }
 };
 
+// Epilogue sums of the training path (conv3d.hip / conv_lds.hip; all null / 0 for inference): see ConvParams::stat_mode.
+struct ConvStat {
+  int mode;
+  const float* y;
+  const float* aux;
+  double* out;
+  int group_imgs;      // 2-D: images per BatchNorm group (the tensor is [groups][imgs][H][W][C]); 0 = one group
+};
+
 }  // namespace mdf
 
 #define MDF_REQUIRE(cond, ...) \

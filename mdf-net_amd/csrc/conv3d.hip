@@ -39,7 +39,31 @@ struct ConvParams {
   int relu;
   long long m_total;  // voxels in the M index space (per parity class for kTr)
   unsigned nblk;
+  // training (ST kernels): per-channel sums of the OUTPUT ride in the epilogue -- one pass over the activations less per BatchNorm
+  //   stat_mode 1: out[c] += sum y, out[C+c] += sum y^2 of the raw conv output (the layer's own batch statistics)
+  //   stat_mode 2: the output is dz of the PRODUCING layer (input gradient + skip gradient): out[c] += sum dr,
+  //                out[C+c] += sum dr*xhat with dr = dz*[y*a+b > 0], xhat = (y-mean)*invstd; stat_y = that layer's raw conv
+  //                output (same shape as the output), stat_aux = its (a, b, mean, invstd)[C]
+  int stat_mode;
+  const float* stat_y;
+  const float* stat_aux;
+  double* stat_out;
 };
+
+// fp64 LDS add (ds_add_f64) / the DPP sum over the 16 lanes of an MFMA column group (lanes q*16 .. q*16+15 hold the 16
+// voxels of one m-tile for the same 4 output channels)
+__device__ __forceinline__ void lds_add_f64(double* p, double v) { atomicAdd(p, v); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov_f<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov_f<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov_f<0x141>(v);   // row_half_mirror
+  v += dpp_mov_f<0x140>(v);   // row_mirror
+  return v;
+}
 
 template <int KPL>
 struct Frag;
@@ -67,7 +91,7 @@ struct Frag<2> {
 // SPLITK = 4: the four waves of a block share ONE wave tile and each takes every 4th tap; partial accumulators are summed
 // through LDS.  For tiny volumes (a few thousand voxels, 27*64 deep K) this turns ~90 serial-latency-bound blocks into 4x
 // as many quarter-length ones.
-template <int CIN, int COUT, int MODE, int MT, int SPLITK>
+template <int CIN, int COUT, int MODE, int MT, int SPLITK, int ST = 0>
 __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
   constexpr int KPL = (CIN >= 16) ? 4 : 2;   // k values per lane per chunk
   constexpr int CK = 4 * KPL;                // cin per chunk
@@ -134,6 +158,18 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
   for (int t = 0; t < MT; ++t)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ST: block-level fp64 table of the epilogue sums [2][64] + the producing layer's (a, b, mean, invstd) [4][64]
+  __shared__ double st_tab[ST ? 128 : 1];
+  __shared__ float st_aux[ST ? 256 : 1];
+  if constexpr (ST != 0) {
+    if (threadIdx.x < 128) st_tab[threadIdx.x] = 0.0;
+    if (p.stat_mode == 2) {
+      const int c = threadIdx.x & 63;
+      st_aux[threadIdx.x] = (c < COUT) ? p.stat_aux[(threadIdx.x >> 6) * COUT + c] : 0.f;
+    }
+    // (made visible by the barrier in front of the epilogue)
+  }
 
   // Epilogue operands (folded BN, residual) are fetched NOW so their L2 round trip overlaps the tap loop: a block lives for
   // one wave tile (10-20 us), an exposed ~1 us at its end is 5-10 % of it.
@@ -276,6 +312,7 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
       }
   }
 
+  if constexpr (ST != 0 && SPLITK == 1) __syncthreads();   // the tables above (split-K has passed a barrier already)
   // epilogue: lane owns couts nt*16 + 4q .. +3 of voxel out_vox[t]
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -284,6 +321,7 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
     const int pw_out = (MODE == kTr) ? r0 / COUT : 0;
     const int c0 = (MODE == kTr) ? r0 % COUT : r0;
     const float4 al = ep_al[nt], be = ep_be[nt];
+    float ps[4] = {0.f, 0.f, 0.f, 0.f}, pq[4] = {0.f, 0.f, 0.f, 0.f};   // ST: this lane's sums over its m-tiles
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       if (!live[t]) continue;
@@ -300,6 +338,37 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
         o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
       }
       *reinterpret_cast<float4*>(p.y + oi) = o;
+      if constexpr (ST != 0) {
+        const float ov[4] = {o.x, o.y, o.z, o.w};
+        if (p.stat_mode == 1) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { ps[k] += ov[k]; pq[k] = fmaf(ov[k], ov[k], pq[k]); }
+        } else {
+          const float4 yv4 = *reinterpret_cast<const float4*>(p.stat_y + oi);
+          const float yv[4] = {yv4.x, yv4.y, yv4.z, yv4.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float dr = (fmaf(yv[k], st_aux[c0 + k], st_aux[64 + c0 + k]) > 0.0f) ? ov[k] : 0.0f;
+            ps[k] += dr;
+            pq[k] = fmaf(dr, (yv[k] - st_aux[128 + c0 + k]) * st_aux[192 + c0 + k], pq[k]);
+          }
+        }
+      }
+    }
+    if constexpr (ST != 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float a1 = row16_sum(ps[k]), a2 = row16_sum(pq[k]);
+        if (n16 == 0) { lds_add_f64(&st_tab[c0 + k], (double)a1); lds_add_f64(&st_tab[64 + c0 + k], (double)a2); }
+      }
+    }
+  }
+  if constexpr (ST != 0) {
+    __syncthreads();
+    if (threadIdx.x < 2 * COUT) {
+      const int c = threadIdx.x % COUT, which = threadIdx.x / COUT;
+      const double v = st_tab[which * 64 + c];
+      if (v != 0.0) atomicAdd(&p.stat_out[which * COUT + c], v);
     }
   }
 }
@@ -481,26 +550,26 @@ __global__ void pack_batch_kernel(const PackJob* __restrict__ jobs, const int* _
   for (int k = 0; k < kPackPerBlock / 256; ++k) pack_job_elem(j, base + k * 256 + threadIdx.x);
 }
 
-template <int CIN, int COUT, int MODE, int MT, int SPLITK>
+template <int CIN, int COUT, int MODE, int MT, int SPLITK, int ST>
 int launch_conv(ConvParams& p, hipStream_t st) {
   const long long per_blk = (SPLITK > 1 ? 1LL : 4LL) * MT * 16;
   p.nblk = (unsigned)((p.m_total + per_blk - 1) / per_blk);
   dim3 grid(p.nblk, MODE == kTr ? 4 : 1), block(256);
-  hipLaunchKernelGGL((conv3d_kernel<CIN, COUT, MODE, MT, SPLITK>), grid, block, 0, st, p);
+  hipLaunchKernelGGL((conv3d_kernel<CIN, COUT, MODE, MT, SPLITK, ST>), grid, block, 0, st, p);
   return mdf::check_launch("conv3d_kernel");
 }
 
-template <int CIN, int COUT, int MODE>
+template <int CIN, int COUT, int MODE, int ST>
 int launch_conv_mt(ConvParams& p, hipStream_t st) {
   constexpr int ROWS = (MODE == kTr) ? 2 * COUT : COUT;
   constexpr int MTMAX = (ROWS > 32) ? 2 : 4;
   // small volumes: shrink the wave tile so the grid still covers the 256 CUs a few times over
   const long long tiles_big = p.m_total / (64LL * MTMAX) * (MODE == kTr ? 4 : 1);
-  if (tiles_big >= 1024) return launch_conv<CIN, COUT, MODE, MTMAX, 1>(p, st);
+  if (tiles_big >= 1024) return launch_conv<CIN, COUT, MODE, MTMAX, 1, ST>(p, st);
   // few tiles and a deep K (27*CIN >= 864): split the taps over the block's waves
   const long long tiles_1 = p.m_total / 16 * (MODE == kTr ? 4 : 1);
-  if (MODE != kTr && CIN >= 32 && tiles_1 < 4096) return launch_conv<CIN, COUT, MODE, 1, 4>(p, st);  // (transposed classes have only 2-8 taps)
-  return launch_conv<CIN, COUT, MODE, 1, 1>(p, st);
+  if (MODE != kTr && CIN >= 32 && tiles_1 < 4096) return launch_conv<CIN, COUT, MODE, 1, 4, ST>(p, st);  // (transposed classes have only 2-8 taps)
+  return launch_conv<CIN, COUT, MODE, 1, 1, ST>(p, st);
 }
 
 }  // namespace
@@ -569,13 +638,15 @@ extern "C" int mdf_pack_batch(const void* jobs_dev, const int* block_job_dev, in
   return mdf::check_launch("pack_batch_kernel");
 }
 
+using mdf::ConvStat;
+
 int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
                           float res_scale, const float* res_up, float* y, int B, int D, int H, int W, int Cin, int Cin_mem, int Cout, int KD,
-                          int KHW, int stride, int relu, void* stream, int planar_in, int shuffle2);
+                          int KHW, int stride, int relu, void* stream, int planar_in, int shuffle2, const ConvStat* stat);
 
-extern "C" int mdf_conv2d_fwd(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
-                              float res_scale, const float* res_up, float* y, int B, int H, int W, int Cin_mem, int Cout, int ksize, int stride,
-                              int relu, int planar_in, int pixel_shuffle2, void* stream) {
+static int conv2d_entry(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
+                        float res_scale, const float* res_up, float* y, int B, int H, int W, int Cin_mem, int Cout, int ksize, int stride,
+                        int relu, int planar_in, int pixel_shuffle2, void* stream, const ConvStat* stat) {
   MDF_REQUIRE(x && wpack && y, "null pointer argument");
   MDF_REQUIRE(B > 0 && H > 0 && W > 0, "bad shape");
   MDF_REQUIRE((long long)B * H * W * Cin_mem < (1ll << 31), "input too large for 32-bit offsets");
@@ -584,18 +655,46 @@ extern "C" int mdf_conv2d_fwd(const float* x, const float* wpack, const float* a
   MDF_REQUIRE(!planar_in || Cin_mem < 4, "planar (NCHW) input is supported for Cin < 4 only (the image layer)");
   MDF_REQUIRE(!pixel_shuffle2 || (Cout == 32 && stride == 1 && !res && !res_up), "pixel_shuffle2 output is built for Cout = 32, stride 1, no residual");
   const int rc = mdf_conv_lds_dispatch(x, wpack, alpha, beta, res, res_scale, res_up, y, B, 1, H, W, padded_cin(Cin_mem), Cin_mem, Cout, 1,
-                                       ksize, stride, relu, stream, planar_in, pixel_shuffle2);
+                                       ksize, stride, relu, stream, planar_in, pixel_shuffle2, stat);
   if (rc == MDF_EUNSUPPORTED)
-    return mdf::fail(MDF_EUNSUPPORTED, "conv2d Cin=%d Cout=%d k=%d stride=%d is not built", Cin_mem, Cout, ksize, stride);
+    return mdf::fail(MDF_EUNSUPPORTED, "conv2d Cin=%d Cout=%d k=%d stride=%d%s is not built", Cin_mem, Cout, ksize, stride, stat ? " (with epilogue sums)" : "");
   return rc;
 }
 
-#define MDF_CONV_CASE(ci, co, mode)                          \
-  if (Cin == ci && Cout == co && m == mode) return launch_conv_mt<ci, co, mode>(p, (hipStream_t)stream);
+extern "C" int mdf_conv2d_fwd(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
+                              float res_scale, const float* res_up, float* y, int B, int H, int W, int Cin_mem, int Cout, int ksize, int stride,
+                              int relu, int planar_in, int pixel_shuffle2, void* stream) {
+  return conv2d_entry(x, wpack, alpha, beta, res, res_scale, res_up, y, B, H, W, Cin_mem, Cout, ksize, stride, relu, planar_in, pixel_shuffle2,
+                      stream, nullptr);
+}
 
-extern "C" int mdf_conv3d_fwd(const float* x, const float* wpack, const float* alpha, const float* beta,
-                              const float* res, float* y, int B, int Di, int Hi, int Wi, int Cin, int Cout, int stride,
-                              int transposed, int relu, void* stream) {
+static int check_stat(int stat_mode, const float* stat_y, const float* stat_aux, const double* stat_out, int Cout) {
+  MDF_REQUIRE(stat_mode == 1 || stat_mode == 2, "stat_mode=%d not in {1 (sum y, sum y^2), 2 (BatchNorm-backward sums)}", stat_mode);
+  MDF_REQUIRE(stat_out, "stat_out is null");
+  MDF_REQUIRE(stat_mode == 1 || (stat_y && stat_aux), "stat_mode 2 needs stat_y and stat_aux");
+  MDF_REQUIRE(Cout % 4 == 0 && Cout >= 8 && Cout <= 64, "epilogue sums are built for Cout in {8,..,64}, Cout %% 4 == 0 (got %d)", Cout);
+  return MDF_OK;
+}
+
+// Training: the RAW 2-D conv (no scale / shift / ReLU) whose epilogue also accumulates per-channel sums of its output, per
+// BatchNorm group (ngroups consecutive sets of B/ngroups images): see ConvParams::stat_mode.  stat_out [ngroups][2*Cout]
+// fp64, zero-initialised by the caller; stat_aux [ngroups][4*Cout].
+extern "C" int mdf_conv2d_train_fwd(const float* x, const float* wpack, float* y, int B, int H, int W, int Cin_mem, int Cout, int ksize,
+                                    int stride, int planar_in, int stat_mode, const float* stat_y, const float* stat_aux, double* stat_out,
+                                    int ngroups, void* stream) {
+  if (int rc = check_stat(stat_mode, stat_y, stat_aux, stat_out, Cout)) return rc;
+  MDF_REQUIRE(ngroups >= 1 && B % ngroups == 0, "B=%d is not a multiple of ngroups=%d", B, ngroups);
+  const ConvStat st{stat_mode, stat_y, stat_aux, stat_out, B / ngroups};
+  return conv2d_entry(x, wpack, nullptr, nullptr, nullptr, 1.0f, nullptr, y, B, H, W, Cin_mem, Cout, ksize, stride, 0, planar_in, 0, stream, &st);
+}
+
+#define MDF_CONV_CASE(ci, co, mode)                          \
+  if (Cin == ci && Cout == co && m == mode)                  \
+    return stat ? launch_conv_mt<ci, co, mode, 1>(p, (hipStream_t)stream) : launch_conv_mt<ci, co, mode, 0>(p, (hipStream_t)stream);
+
+static int conv3d_entry(const float* x, const float* wpack, const float* alpha, const float* beta,
+                        const float* res, float* y, int B, int Di, int Hi, int Wi, int Cin, int Cout, int stride,
+                        int transposed, int relu, void* stream, const ConvStat* stat) {
   MDF_REQUIRE(x && wpack && y, "null pointer argument");
   MDF_REQUIRE((alpha == nullptr) == (beta == nullptr), "alpha and beta must both be given or both be NULL");
   MDF_REQUIRE(B > 0 && Di > 0 && Hi > 0 && Wi > 0, "bad shape");
@@ -605,6 +704,7 @@ extern "C" int mdf_conv3d_fwd(const float* x, const float* wpack, const float* a
   ConvParams p{};
   p.x = x; p.wpack = wpack; p.alpha = alpha; p.beta = beta; p.res = res; p.y = y;
   p.B = B; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.relu = relu;
+  if (stat) { p.stat_mode = stat->mode; p.stat_y = stat->y; p.stat_aux = stat->aux; p.stat_out = stat->out; }
   const int m = transposed ? kTr : (stride == 2 ? kS2 : kS1);
   if (m == kS1) { p.Do = Di; p.Ho = Hi; p.Wo = Wi; }
   else if (m == kS2) { p.Do = (Di - 1) / 2 + 1; p.Ho = (Hi - 1) / 2 + 1; p.Wo = (Wi - 1) / 2 + 1; }
@@ -615,7 +715,7 @@ extern "C" int mdf_conv3d_fwd(const float* x, const float* wpack, const float* a
     return e ? atoll(e) : 150000LL;
   }();
   if (m == kS1 && p.m_total >= lds_min) {  // large stride-1 layers: LDS-staged planes (conv_lds.hip)
-    const int rc = mdf_conv_lds_dispatch(x, wpack, alpha, beta, res, 1.0f, nullptr, y, B, Di, Hi, Wi, Cin, Cin, Cout, 3, 3, 1, relu, stream, 0, 0);
+    const int rc = mdf_conv_lds_dispatch(x, wpack, alpha, beta, res, 1.0f, nullptr, y, B, Di, Hi, Wi, Cin, Cin, Cout, 3, 3, 1, relu, stream, 0, 0, stat);
     if (rc != MDF_EUNSUPPORTED) return rc;
   }
   // stride 1 (every Cin x Cout the nets use)
@@ -627,4 +727,22 @@ extern "C" int mdf_conv3d_fwd(const float* x, const float* wpack, const float* a
   MDF_CONV_CASE(64, 32, kTr) MDF_CONV_CASE(32, 16, kTr) MDF_CONV_CASE(16, 8, kTr)
   return mdf::fail(MDF_EUNSUPPORTED, "conv3d Cin=%d Cout=%d stride=%d transposed=%d is not built", Cin, Cout, stride,
                    transposed);
+}
+
+extern "C" int mdf_conv3d_fwd(const float* x, const float* wpack, const float* alpha, const float* beta,
+                              const float* res, float* y, int B, int Di, int Hi, int Wi, int Cin, int Cout, int stride,
+                              int transposed, int relu, void* stream) {
+  return conv3d_entry(x, wpack, alpha, beta, res, y, B, Di, Hi, Wi, Cin, Cout, stride, transposed, relu, stream, nullptr);
+}
+
+// Training: the RAW 3-D conv / transposed conv ([res +] conv(x), no scale / shift / ReLU) whose epilogue also accumulates
+// per-channel sums of its output (ConvParams::stat_mode) into stat_out [2*Cout] fp64, zero-initialised by the caller.
+// stat_mode 1 serves the forward pass (the layer's batch statistics); stat_mode 2 the backward pass, where this launch is the
+// input-gradient conv of the NEXT layer and its output (+ res, the skip gradient) is dz of the layer that produced stat_y.
+extern "C" int mdf_conv3d_train_fwd(const float* x, const float* wpack, const float* res, float* y, int B, int Di, int Hi, int Wi, int Cin,
+                                    int Cout, int stride, int transposed, int stat_mode, const float* stat_y, const float* stat_aux,
+                                    double* stat_out, void* stream) {
+  if (int rc = check_stat(stat_mode, stat_y, stat_aux, stat_out, Cout)) return rc;
+  const ConvStat st{stat_mode, stat_y, stat_aux, stat_out, 0};
+  return conv3d_entry(x, wpack, nullptr, nullptr, res, y, B, Di, Hi, Wi, Cin, Cout, stride, transposed, 0, stream, &st);
 }

@@ -39,7 +39,27 @@ struct LdsConvParams {
   int sched_slot;                      // which pair of g_sched words this launch uses (one per stream)
   int shuffle2;                        // 2-D, Cout = 32: write PixelShuffle(2) of the result ([B,2Ho,2Wo,8]); rows packed sub-pixel-major
   int prefetch_early;                  // 3-D: issue the next plane's loads before (1) or after (0) the MFMA block
+  // training (ST kernels): per-channel sums of the output in the epilogue, see conv3d.hip ConvParams::stat_mode
+  int stat_mode;
+  const float* stat_y;
+  const float* stat_aux;               // [groups][4*COUT]
+  double* stat_out;                    // [groups][2*COUT]
+  int stat_group_imgs;                 // 2-D: images per BatchNorm group (0: one group)
 };
+
+// fp64 LDS add and the DPP sum over the 16 lanes that hold the 16 MFMA columns of one 4-channel row group
+__device__ __forceinline__ void lds_add_f64(double* p, double v) { atomicAdd(p, v); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov_f<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov_f<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov_f<0x141>(v);   // row_half_mirror
+  v += dpp_mov_f<0x140>(v);   // row_mirror
+  return v;
+}
 
 template <int N> struct VecT;
 template <> struct VecT<4> { typedef float4 type; };
@@ -150,11 +170,43 @@ struct Cfg {
   // from global memory: the per-call L1/L2 round trip was ~1000 exposed cycles per depth step, in-kernel stamps)
   static constexpr int EPI_OFF = RING * PLANE + 4;   // floats
   static constexpr size_t LDS_BYTES = (size_t)RING * PLANE * sizeof(float) + 16 + 128 * sizeof(float);
+  // ST kernels: + fp64 sums [2][64] + the producing layer's (a, b, mean, invstd) [4][64]
+  static constexpr int STAT_OFF = EPI_OFF + 128, SAUX_OFF = STAT_OFF + 256;   // floats (STAT_OFF*4 is a multiple of 8)
+  static constexpr size_t LDS_BYTES_ST = LDS_BYTES + 512 * sizeof(float);
 };
+
+// ST epilogue: the lane's 4 output values o[] of channels c0.. at output index oi -> its running sums (ps, pq)
+template <typename C>
+__device__ __forceinline__ void stat_accum(const LdsConvParams& p, const float* lds_base, size_t oi, int c0, const float (&o)[4],
+                                           float (&ps)[4], float (&pq)[4]) {
+  if (p.stat_mode == 1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ps[k] += o[k]; pq[k] = fmaf(o[k], o[k], pq[k]); }
+  } else {
+    const float* ax = lds_base + C::SAUX_OFF;
+    const float4 yv4 = *reinterpret_cast<const float4*>(p.stat_y + oi);
+    const float yv[4] = {yv4.x, yv4.y, yv4.z, yv4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float dr = (fmaf(yv[k], ax[c0 + k], ax[64 + c0 + k]) > 0.0f) ? o[k] : 0.0f;
+      ps[k] += dr;
+      pq[k] = fmaf(dr, (yv[k] - ax[128 + c0 + k]) * ax[192 + c0 + k], pq[k]);
+    }
+  }
+}
+template <typename C>
+__device__ __forceinline__ void stat_commit(float* lds_base, int c0, int n16, const float (&ps)[4], const float (&pq)[4]) {
+  double* tab = reinterpret_cast<double*>(lds_base + C::STAT_OFF);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float a1 = row16_sum(ps[k]), a2 = row16_sum(pq[k]);
+    if (n16 == 0) { lds_add_f64(&tab[c0 + k], (double)a1); lds_add_f64(&tab[64 + c0 + k], (double)a2); }
+  }
+}
 
 // One output row-tile of one depth plane: MTL live m-tiles (16 voxels each) x all couts.  Fully unrolled over the
 // taps: LDS offsets are immediates, no bounds logic (halos are zero-filled in LDS).
-template <typename C, int KD, int KHW, int SHW, int COUT, int MTL>
+template <typename C, int KD, int KHW, int SHW, int COUT, int MTL, int ST = 0>
 __device__ __forceinline__ void step(const float* const (&planes)[KD], __amdgpu_buffer_rsrc_t wres, int wvoff, const LdsConvParams& p,
                                      size_t row_vox, int w0, int q, int n16, const float (&wr)[C::WN][C::NT][C::KPL],
                                      const float (&al)[C::NT][4], const float (&be)[C::NT][4], const float (&wfirst)[2][C::NT][C::KPL]) {
@@ -162,6 +214,7 @@ __device__ __forceinline__ void step(const float* const (&planes)[KD], __amdgpu_
   typedef typename VecT<KPL>::type vec_t;
   extern __shared__ __attribute__((aligned(16))) float lds_base_[];
   const float* epi_tab = lds_base_ + C::EPI_OFF;
+  static_assert(ST == 0 || COUT % 4 == 0, "epilogue sums need Cout % 4 == 0");
   f32x4 acc[MTL][NT];
 #pragma unroll
   for (int t = 0; t < MTL; ++t)
@@ -240,6 +293,7 @@ __device__ __forceinline__ void step(const float* const (&planes)[KD], __amdgpu_
         be_l[k] = epi_tab[64 + c0 + k];
       }
     }
+    float ps[4] = {0.f, 0.f, 0.f, 0.f}, pq[4] = {0.f, 0.f, 0.f, 0.f};   // ST: this lane's sums over its m-tiles
 #pragma unroll
     for (int t = 0; t < MTL; ++t) {
       const int ow = w0 + (t * 16 + n16) * C::RWF + phase;
@@ -286,6 +340,7 @@ __device__ __forceinline__ void step(const float* const (&planes)[KD], __amdgpu_
           o[2] = rr.z + o[2] * p.res_scale; o[3] = rr.w + o[3] * p.res_scale;
         }
         *reinterpret_cast<float4*>(p.y + oi) = make_float4(o[0], o[1], o[2], o[3]);
+        if constexpr (ST != 0) stat_accum<C>(p, lds_base_, oi, c0, o, ps, pq);
       } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -293,6 +348,7 @@ __device__ __forceinline__ void step(const float* const (&planes)[KD], __amdgpu_
         }
       }
     }
+    if constexpr (ST != 0) stat_commit<C>(lds_base_, c0, n16, ps, pq);
   }
 }
 
@@ -306,7 +362,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // ---- Winograd form (Cfg::WINO) ---------------------------------------------------------------------------------
 // Weight fragments (pack_weights_wino_kernel, conv3d.hip): [kd][chunk][ab = a*4+b][nt][lane][4], U = G g_kd G^T.
-template <typename C, int COUT, int NKD>
+template <typename C, int COUT, int NKD, int ST = 0>
 __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __amdgpu_buffer_rsrc_t wres, int wvoff, const LdsConvParams& p,
                                           int b, int d, int h, int w0, int q, int n16, const float (&wfirst)[2][C::NT][C::KPL]) {
   constexpr int NCH = C::NCH, NTALL = C::NT, NT = C::NTP, S = C::S, PW = C::PW;
@@ -451,6 +507,7 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __a
       al_l[k] = epi_tab[c0 + k];
       be_l[k] = epi_tab[64 + c0 + k];
     }
+    float ps[4] = {0.f, 0.f, 0.f, 0.f}, pq[4] = {0.f, 0.f, 0.f, 0.f};   // ST: this lane's sums over its 2x2 outputs
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
       if (h + pr >= p.Ho) continue;
@@ -472,13 +529,15 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __a
           o[2] = rr.z + o[2] * p.res_scale; o[3] = rr.w + o[3] * p.res_scale;
         }
         *reinterpret_cast<float4*>(p.y + oi) = make_float4(o[0], o[1], o[2], o[3]);
+        if constexpr (ST != 0) stat_accum<C>(p, lds_base_, oi, c0, o, ps, pq);
       }
     }
+    if constexpr (ST != 0) stat_commit<C>(lds_base_, c0, n16, ps, pq);
   }
   }  // pass
 }
 
-template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT, int RW = 1, int WG = 0>
+template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT, int RW = 1, int WG = 0, int ST = 0>
 // Register budget: the unrolled, pipelined tap loop wants ~280 registers (one 64-bit address pair per weight tap), which
 // leaves ONE wave per SIMD.  Capping at 256 (two resident blocks per CU) is worth 6-10 % for the single-n-tile kernels
 // (A/B in one process, scripts/bench_conv3d.py); with 2+ n-tiles the cap makes hipcc spill, so those stay uncapped.
@@ -501,6 +560,32 @@ __global__ __launch_bounds__(256, ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 :
   if (tid < 128) {   // epilogue table (1 / 0 beyond COUT or without BN)
     const int c = tid & 63;
     lds[C::EPI_OFF + tid] = (tid < 64) ? ((c < COUT && p.alpha) ? p.alpha[c] : 1.f) : ((c < COUT && p.beta) ? p.beta[c] : 0.f);
+  }
+  // ST: the block's fp64 sums [2][64] (sent to memory with one atomic per channel when the block -- or, 2-D, its run of tiles
+  // inside one BatchNorm group -- is done) and, mode 2, the producing layer's (a, b, mean, invstd) of the current group
+  [[maybe_unused]] double* st_tab = reinterpret_cast<double*>(lds + C::STAT_OFF);
+  [[maybe_unused]] int st_group = 0;
+  [[maybe_unused]] auto st_load_aux = [&](int grp) {
+    if (p.stat_mode == 2) {
+      const int c = tid & 63;
+      lds[C::SAUX_OFF + tid] = (c < COUT) ? p.stat_aux[(size_t)grp * 4 * COUT + (tid >> 6) * COUT + c] : 0.f;
+    }
+  };
+  [[maybe_unused]] auto st_flush = [&](int grp) {     // all waves have committed (caller put a barrier in front)
+    if (tid < 2 * COUT) {
+      const int c = tid % COUT, which = tid / COUT;
+      const double v = st_tab[which * 64 + c];
+      if (v != 0.0) atomicAdd(&p.stat_out[(size_t)grp * 2 * COUT + which * COUT + c], v);
+      st_tab[which * 64 + c] = 0.0;
+    }
+  };
+  if constexpr (ST != 0) {
+    if (tid < 128) st_tab[tid] = 0.0;
+    if constexpr (KD == 1) {
+      const int t_first = (int)((long long)blockIdx.x * p.n_tiles / gridDim.x);
+      st_group = p.stat_group_imgs > 0 ? (t_first / (p.tiles_w * p.tiles_h)) / p.stat_group_imgs : 0;
+    }
+    st_load_aux(st_group);
   }
   __syncthreads();
   // per-lane constants for the whole kernel: epilogue scale/shift of the lane's 4 couts, and (small layers) all weights
@@ -622,6 +707,16 @@ __global__ __launch_bounds__(256, ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 :
 #endif
       for (int tl = t_begin; tl < t_end; ++tl) {
         const int slot = (C::RING == 1) ? 0 : ((tl - t_begin) & 1);
+        if constexpr (ST != 0) {     // the run crosses into the next BatchNorm group (block-uniform, rare): send the sums, switch tables
+          const int grp = p.stat_group_imgs > 0 ? tb / p.stat_group_imgs : 0;
+          if (grp != st_group) {
+            __syncthreads();
+            st_flush(st_group);
+            st_group = grp;
+            st_load_aux(grp);
+            __syncthreads();
+          }
+        }
         const bool row_live2 = (th0 + wave * C::WROWS) < p.Ho;
         const int cols2 = (min(p.Wo - tw0, C::TWO) + RW - 1) / RW;   // live MFMA columns
         const int mt_live2 = row_live2 ? (cols2 + 15) / 16 : 0;
@@ -644,13 +739,13 @@ __global__ __launch_bounds__(256, ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 :
           const float* planes[1] = {lds + slot * C::PLANE + lane_lds};
           const size_t row_vox = ((size_t)cb * p.Ho + (ch0 + wave)) * p.Wo;
           if constexpr (C::WINO) {
-            step_wino<C, COUT, 1>(planes, wres, wvoff, p, cb, 0, ch0 + 2 * wave, cw0, q, n16, wfirst);
+            step_wino<C, COUT, 1, ST>(planes, wres, wvoff, p, cb, 0, ch0 + 2 * wave, cw0, q, n16, wfirst);
           } else {
             switch (mt_live2) {
-              case 1: step<C, KD, KHW, SHW, COUT, 1>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be, wfirst); break;
-              case 2: if (MT >= 2) step<C, KD, KHW, SHW, COUT, (MT >= 2 ? 2 : 1)>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be, wfirst); break;
-              case 3: if (MT >= 3) step<C, KD, KHW, SHW, COUT, (MT >= 3 ? 3 : 1)>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be, wfirst); break;
-              default: step<C, KD, KHW, SHW, COUT, MT>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be, wfirst); break;
+              case 1: step<C, KD, KHW, SHW, COUT, 1, ST>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be, wfirst); break;
+              case 2: if (MT >= 2) step<C, KD, KHW, SHW, COUT, (MT >= 2 ? 2 : 1), ST>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be, wfirst); break;
+              case 3: if (MT >= 3) step<C, KD, KHW, SHW, COUT, (MT >= 3 ? 3 : 1), ST>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be, wfirst); break;
+              default: step<C, KD, KHW, SHW, COUT, MT, ST>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be, wfirst); break;
             }
           }
         }
@@ -760,13 +855,13 @@ __global__ __launch_bounds__(256, ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 :
         for (int kd = 0; kd < KD; ++kd) planes[kd] = lds + slot_of(d + kd - C::PD) * C::PLANE + lane_lds;
         const size_t row_vox = (((size_t)b * p.D + d) * p.Ho + (h0 + wave)) * p.Wo;
         if constexpr (C::WINO) {
-          step_wino<C, COUT, 3>(planes, wres, wvoff, p, b, d, h0 + 2 * wave, w0, q, n16, wfirst);
+          step_wino<C, COUT, 3, ST>(planes, wres, wvoff, p, b, d, h0 + 2 * wave, w0, q, n16, wfirst);
         } else {
           switch (mt_live) {
-            case 1: step<C, KD, KHW, SHW, COUT, 1>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be, wfirst); break;
-            case 2: if (MT >= 2) step<C, KD, KHW, SHW, COUT, (MT >= 2 ? 2 : 1)>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be, wfirst); break;
-            case 3: if (MT >= 3) step<C, KD, KHW, SHW, COUT, (MT >= 3 ? 3 : 1)>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be, wfirst); break;
-            default: step<C, KD, KHW, SHW, COUT, MT>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be, wfirst); break;
+            case 1: step<C, KD, KHW, SHW, COUT, 1, ST>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be, wfirst); break;
+            case 2: if (MT >= 2) step<C, KD, KHW, SHW, COUT, (MT >= 2 ? 2 : 1), ST>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be, wfirst); break;
+            case 3: if (MT >= 3) step<C, KD, KHW, SHW, COUT, (MT >= 3 ? 3 : 1), ST>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be, wfirst); break;
+            default: step<C, KD, KHW, SHW, COUT, MT, ST>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be, wfirst); break;
           }
         }
       }
@@ -797,6 +892,10 @@ __global__ __launch_bounds__(256, ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 :
     atomicAdd(&g_stamps[6], n_items_done); atomicAdd(&g_stamps[7], n_dsteps);
   }
 #endif
+  if constexpr (ST != 0) {
+    __syncthreads();
+    st_flush(st_group);
+  }
   if (KD > 1 && tid == 0) {
     const unsigned done = atomicAdd(&g_sched[2 * p.sched_slot + 1], 1u);
     if (done == gridDim.x - 1) {  // last block out: re-arm the counters for the next launch
@@ -807,13 +906,14 @@ __global__ __launch_bounds__(256, ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 :
   }
 }
 
-template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT, int RW = 1, int WG = 0>
+template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT, int RW = 1, int WG = 0, int ST = 0>
 int launch_lds(LdsConvParams& p, hipStream_t st) {
   typedef Cfg<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW, WG> C;
+  constexpr size_t kLds = ST ? C::LDS_BYTES_ST : C::LDS_BYTES;
   p.tiles_h = (p.Ho + C::TH - 1) / C::TH;
   p.tiles_w = (p.Wo + C::TWO - 1) / C::TWO;
   const long long tiles = (long long)p.B * p.tiles_h * p.tiles_w;
-  const int blocks_per_cu = (int)(160 * 1024 / C::LDS_BYTES) < 1 ? 1 : (int)(160 * 1024 / C::LDS_BYTES);
+  const int blocks_per_cu = (int)(160 * 1024 / kLds) < 1 ? 1 : (int)(160 * 1024 / kLds);
   const int max_grid = 256 * (blocks_per_cu > 4 ? 4 : blocks_per_cu);
   // 3-D: items = tile x depth chunk, handed out dynamically; aim for >= ~6 items per resident block (smooths the cheaper
   // partially-filled tile columns) while keeping >= 3 planes per chunk (prologue = KD-1 extra planes).
@@ -852,14 +952,14 @@ int launch_lds(LdsConvParams& p, hipStream_t st) {
   }
   // the dynamic-LDS attribute is a per-DEVICE property of the function: one flag per device (several GPUs in one
   // process, DataParallel-style).  Benign race: the call is idempotent.
-  static bool attr_done_dev[64] = {};
+  static bool attr_done_dev[64] = {};     // (one per template instantiation, ST included)
   int dev_id = 0;
   (void)hipGetDevice(&dev_id);
   bool& attr_done = attr_done_dev[(dev_id >= 0 && dev_id < 64) ? dev_id : 0];
   if (!attr_done || dev_id >= 64) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW, WG>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-    if (e != hipSuccess) return mdf::fail(MDF_EHIP, "hipFuncSetAttribute(dynamic LDS %zu): %s", C::LDS_BYTES, hipGetErrorString(e));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW, WG, ST>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+    if (e != hipSuccess) return mdf::fail(MDF_EHIP, "hipFuncSetAttribute(dynamic LDS %zu): %s", kLds, hipGetErrorString(e));
     attr_done = true;
   }
   int grid = max_grid;
@@ -867,13 +967,13 @@ int launch_lds(LdsConvParams& p, hipStream_t st) {
   if (grid > p.n_items) grid = p.n_items;
   if (getenv("MDF_CONV_DEBUG")) {
     int nb = -1;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW, WG>, 256, C::LDS_BYTES);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW, WG, ST>, 256, kLds);
     hipFuncAttributes fa{};
-    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW, WG>));
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW, WG, ST>));
     fprintf(stderr, "[conv_lds<%d,%d,%d,%d,%d,%d,%d,rw%d>] LDS %zu B dyn + %zu static, regs %d, occupancy API: %d blocks/CU (%s), grid %d, items %d\n",
-            CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW, C::LDS_BYTES, fa.sharedSizeBytes, fa.numRegs, nb, hipGetErrorString(e), grid, p.n_items);
+            CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW, kLds, fa.sharedSizeBytes, fa.numRegs, nb, hipGetErrorString(e), grid, p.n_items);
   }
-  hipLaunchKernelGGL((conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW, WG>), dim3(grid), dim3(256), C::LDS_BYTES, st, p);
+  hipLaunchKernelGGL((conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW, WG, ST>), dim3(grid), dim3(256), kLds, st, p);
   return mdf::check_launch("conv_lds_kernel");
 }
 
@@ -894,8 +994,12 @@ extern "C" int mdf_debug_read_stamps(unsigned long long* out8, int reset) {
 // Internal entry used by mdf_conv3d_fwd (stride-1 3x3x3) and mdf_conv2d_fwd.  Returns MDF_EUNSUPPORTED when the
 // configuration has no LDS-kernel instantiation (caller falls back to conv v1 / reports the error).
 #define LDS_CASE(ci, cim, co, kd, k, s, mt)                                                      \
-  if (Cin == ci && Cin_mem == cim && Cout == co && KD == kd && KHW == k && stride == s)          \
+  if (!stat && Cin == ci && Cin_mem == cim && Cout == co && KD == kd && KHW == k && stride == s) \
     return launch_lds<ci, cim, co, kd, k, s, mt>(p, (hipStream_t)stream);
+// layers the training step runs raw with epilogue sums (forward statistics / backward reductions): both variants
+#define LDS_CASE_T(ci, cim, co, kd, k, s, mt)                                                    \
+  if (Cin == ci && Cin_mem == cim && Cout == co && KD == kd && KHW == k && stride == s)          \
+    return stat ? launch_lds<ci, cim, co, kd, k, s, mt, 1, 0, 1>(p, (hipStream_t)stream) : launch_lds<ci, cim, co, kd, k, s, mt>(p, (hipStream_t)stream);
 
 // stream -> scheduler slot (launches on one stream are ordered, so they can share a slot; different streams must not).
 // A slot stays bound to its stream handle until mdf_release_stream(stream) gives it back (long-lived processes that
@@ -926,31 +1030,40 @@ extern "C" int mdf_release_stream(void* stream) {
 
 // w-phase variants read the expanded packing that conv3d.hip appends after the plain one (mdf_conv_rw_of / pack functions)
 #define LDS_CASE_RW(ci, cim, co, kd, k, s, mt, rw)                                               \
-  if (use_rw && Cin == ci && Cin_mem == cim && Cout == co && KD == kd && KHW == k && stride == s && !res_up) { \
+  if (!stat && use_rw && Cin == ci && Cin_mem == cim && Cout == co && KD == kd && KHW == k && stride == s && !res_up) { \
     p.wpack = wpack + (size_t)kd * k * k * ci * 16;                                              \
     return launch_lds<ci, cim, co, kd, k, s, mt, rw>(p, (hipStream_t)stream);                    \
+  }
+#define LDS_CASE_RW_T(ci, cim, co, kd, k, s, mt, rw)                                             \
+  if (use_rw && Cin == ci && Cin_mem == cim && Cout == co && KD == kd && KHW == k && stride == s && !res_up) { \
+    p.wpack = wpack + (size_t)kd * k * k * ci * 16;                                              \
+    return stat ? launch_lds<ci, cim, co, kd, k, s, mt, rw, 0, 1>(p, (hipStream_t)stream) : launch_lds<ci, cim, co, kd, k, s, mt, rw>(p, (hipStream_t)stream); \
   }
 
 // Winograd variants read the transform-domain weights appended behind the plain (and w-phase) packing
 #define LDS_CASE_WG(ci, co)                                                                      \
   if (use_wg && KD == 3 && KHW == 3 && stride == 1 && Cin == ci && Cin_mem == ci && Cout == co && !res_up) { \
     p.wpack = wpack + (size_t)27 * ci * (((co + 15) / 16) * 16) + (co == 8 ? (size_t)36 * ci * 16 : 0); \
-    return launch_lds<ci, ci, co, 3, 3, 1, 1, 2, 1>(p, (hipStream_t)stream);                     \
+    return stat ? launch_lds<ci, ci, co, 3, 3, 1, 1, 2, 1, 1>(p, (hipStream_t)stream) : launch_lds<ci, ci, co, 3, 3, 1, 1, 2, 1>(p, (hipStream_t)stream); \
   }
 #define LDS_CASE_WG2(ci, co)                                                                     \
   if (use_wg && KD == 1 && KHW == 3 && stride == 1 && Cin == ci && Cin_mem == ci && Cout == co && !res_up && !shuffle2) { \
     p.wpack = wpack + (size_t)9 * ci * (((co + 15) / 16) * 16);                                  \
-    return launch_lds<ci, ci, co, 1, 3, 1, 1, 2, 1>(p, (hipStream_t)stream);                     \
+    return stat ? launch_lds<ci, ci, co, 1, 3, 1, 1, 2, 1, 1>(p, (hipStream_t)stream) : launch_lds<ci, ci, co, 1, 3, 1, 1, 2, 1>(p, (hipStream_t)stream); \
   }
 
 int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
                           float res_scale, const float* res_up, float* y, int B, int D, int H, int W, int Cin, int Cin_mem, int Cout, int KD,
-                          int KHW, int stride, int relu, void* stream, int planar_in, int shuffle2) {
+                          int KHW, int stride, int relu, void* stream, int planar_in, int shuffle2, const mdf::ConvStat* stat) {
   static const bool use_wg = [] { const char* e = getenv("MDF_CONV_WINOGRAD"); return e ? atoi(e) != 0 : true; }();   // dev A/B
   static const bool use_rw = [] { const char* e = getenv("MDF_CONV_RW"); return e ? atoi(e) != 0 : true; }();   // dev A/B
   LdsConvParams p{};
   p.x = x; p.wpack = wpack; p.alpha = alpha; p.beta = beta; p.res = res; p.res_scale = res_scale; p.res_up = res_up; p.y = y;
   p.B = B; p.D = D; p.H = H; p.W = W; p.relu = relu; p.planar_in = planar_in; p.shuffle2 = shuffle2;
+  if (stat) {
+    if (Cout % 4 != 0 || shuffle2 || res_up) return mdf::fail(MDF_EUNSUPPORTED, "epilogue sums: Cout %% 4 == 0, no pixel-shuffle / upsample-add");
+    p.stat_mode = stat->mode; p.stat_y = stat->y; p.stat_aux = stat->aux; p.stat_out = stat->out; p.stat_group_imgs = stat->group_imgs;
+  }
   p.sched_slot = sched_slot_of(stream);
   if (p.sched_slot < 0) return mdf::fail(MDF_EUNSUPPORTED, "conv kernels support up to %d distinct HIP streams per process", kSchedSlots);
   {
@@ -964,9 +1077,9 @@ int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha
   LDS_CASE_WG(16, 16) LDS_CASE_WG(32, 16) LDS_CASE_WG(32, 32) LDS_CASE_WG(16, 8)
   LDS_CASE_WG2(16, 16) LDS_CASE_WG2(32, 32) LDS_CASE_WG2(64, 64)
   // Cout < 16: w-phase form (RW output voxels per MFMA column)
-  LDS_CASE_RW(16, 16, 8, 3, 3, 1, 2, 2) LDS_CASE_RW(8, 8, 8, 3, 3, 1, 2, 2)
+  LDS_CASE_RW_T(16, 16, 8, 3, 3, 1, 2, 2) LDS_CASE_RW_T(8, 8, 8, 3, 3, 1, 2, 2)
   LDS_CASE_RW(16, 16, 4, 1, 3, 1, 1, 4) LDS_CASE_RW(8, 8, 4, 1, 3, 1, 1, 4)
-  LDS_CASE_RW(8, 8, 8, 1, 3, 1, 2, 2) LDS_CASE_RW(4, 3, 8, 1, 3, 1, 2, 2) LDS_CASE_RW(4, 1, 8, 1, 3, 1, 2, 2)   // also the HBM-bound ones: 64-B stores, half the LDS reads
+  LDS_CASE_RW_T(8, 8, 8, 1, 3, 1, 2, 2) LDS_CASE_RW_T(4, 3, 8, 1, 3, 1, 2, 2) LDS_CASE_RW(4, 1, 8, 1, 3, 1, 2, 2)   // also the HBM-bound ones: 64-B stores, half the LDS reads
   // 3-D regulariser layers (stride 1)
   LDS_CASE(32, 32, 16, 3, 3, 1, 2) LDS_CASE(16, 16, 16, 3, 3, 1, 4) LDS_CASE(16, 16, 8, 3, 3, 1, 4) LDS_CASE(8, 8, 8, 3, 3, 1, 4)
   LDS_CASE(32, 32, 32, 3, 3, 1, 2)
@@ -974,7 +1087,7 @@ int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha
   // 2-D layers of the feature pyramid / refinement (KD = 1)
   LDS_CASE(4, 3, 8, 1, 3, 1, 4) LDS_CASE(8, 8, 8, 1, 3, 1, 4) LDS_CASE(16, 16, 16, 1, 3, 1, 4) LDS_CASE(32, 32, 32, 1, 3, 1, 2)
   LDS_CASE(64, 64, 64, 1, 3, 1, 1)
-  LDS_CASE(8, 8, 16, 1, 5, 2, 2) LDS_CASE(16, 16, 32, 1, 5, 2, 2) LDS_CASE(32, 32, 64, 1, 5, 2, 1)
+  LDS_CASE_T(8, 8, 16, 1, 5, 2, 2) LDS_CASE_T(16, 16, 32, 1, 5, 2, 2) LDS_CASE_T(32, 32, 64, 1, 5, 2, 1)
   LDS_CASE(16, 16, 64, 1, 1, 1, 4) LDS_CASE(32, 32, 64, 1, 1, 1, 2) LDS_CASE(64, 64, 16, 1, 1, 1, 1) LDS_CASE(64, 64, 32, 1, 1, 1, 1)
   LDS_CASE(64, 64, 64, 1, 1, 1, 1)
   LDS_CASE(32, 32, 32, 1, 1, 1, 2) LDS_CASE(32, 32, 16, 1, 1, 1, 2) LDS_CASE(16, 16, 16, 1, 1, 1, 4)   // composed FPN heads

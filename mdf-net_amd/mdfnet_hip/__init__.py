@@ -55,6 +55,8 @@ SIGNATURES = {
     "mdf_bn_relu_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_fp, c_fp, c_fp, c_fp]),
     "mdf_conv3d_wgrad_workspace": (c_i64, [c_int] * 6),
     "mdf_conv3d_wgrad": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp]),
+    "mdf_conv3d_train_fwd": (c_int, [c_fp] * 4 + [c_int] * 9 + [c_fp] * 4),
+    "mdf_conv2d_train_fwd": (c_int, [c_fp] * 3 + [c_int] * 9 + [c_fp] * 3 + [c_int, c_fp]),
     "mdf_conv2d_wgrad_workspace": (c_i64, [c_int] * 6),
     "mdf_conv2d_wgrad": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp]),
     "mdf_pack_job_bytes": (c_i64, []),

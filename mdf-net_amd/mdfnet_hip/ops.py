@@ -367,6 +367,57 @@ def conv3d_ndhwc(x, wpack, cin, cout, stride=1, transposed=False, alpha=None, be
     return y
 
 
+def conv3d_train(x, wpack, cin, cout, stride, transposed, res, stat_mode, stat_out, stat_y=None, stat_aux=None):
+    """Training: y = [res +] conv(x) raw, with per-channel sums of y accumulated into `stat_out` [2*cout] fp64 by the conv's
+    epilogue (mdf_conv3d_train_fwd).  stat_mode 1: (sum y, sum y^2); 2: y is dz of the layer whose raw output is stat_y and whose
+    BatchNorm constants are stat_aux -> (sum dr, sum dr*xhat)."""
+    _need_gpu(x, wpack, stat_out)
+    b, d, h, w, c = x.shape
+    assert c == cin and x.is_contiguous()
+    if transposed:
+        do, ho, wo = 2 * d, 2 * h, 2 * w
+    elif stride == 2:
+        do, ho, wo = (d - 1) // 2 + 1, (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    else:
+        do, ho, wo = d, h, w
+    y = torch.empty((b, do, ho, wo, cout), device=x.device, dtype=torch.float32)
+    if res is not None:
+        assert res.shape == y.shape and res.is_contiguous()
+    if stat_mode == 2:
+        assert stat_y.shape == y.shape and stat_y.is_contiguous() and stat_aux.numel() == 4 * cout
+    assert stat_out.numel() == 2 * cout and stat_out.dtype == torch.float64
+    _abi("mdf_conv3d_train_fwd", (x.data_ptr(), wpack.data_ptr(), None if res is None else res.data_ptr(), y.data_ptr(), b, d, h, w, cin, cout,
+                                  stride, int(transposed), stat_mode, None if stat_y is None else stat_y.data_ptr(),
+                                  None if stat_aux is None else stat_aux.data_ptr(), stat_out.data_ptr(), _stream(y)),
+         tag=f"{cin}->{cout} {'T' if transposed else 's%d' % stride} {d}x{h}x{w} +sums{stat_mode}",
+         work={"flops": 2.0 * 27 * cin * cout * b * (d * h * w if transposed else do * ho * wo),
+               "bytes": 4.0 * (x.numel() + y.numel() * (1 + (res is not None) + (stat_mode == 2))), "bound": "mfma"})
+    return y
+
+
+def conv2d_train(x, wpack, cin, cout, ksize, stride, planar_in, stat_mode, stat_out, ngroups, stat_y=None, stat_aux=None):
+    """2-D counterpart (mdf_conv2d_train_fwd): `ngroups` consecutive sets of images are separate BatchNorm groups."""
+    _need_gpu(x, wpack, stat_out)
+    if planar_in:
+        b, c, h, w = x.shape
+    else:
+        b, h, w, c = x.shape
+    assert c == cin and x.is_contiguous() and b % ngroups == 0
+    pad = (ksize - 1) // 2
+    ho, wo = (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
+    y = torch.empty((b, ho, wo, cout), device=x.device, dtype=torch.float32)
+    if stat_mode == 2:
+        assert stat_y.shape == y.shape and stat_y.is_contiguous() and stat_aux.numel() == ngroups * 4 * cout
+    assert stat_out.numel() == ngroups * 2 * cout and stat_out.dtype == torch.float64
+    _abi("mdf_conv2d_train_fwd", (x.data_ptr(), wpack.data_ptr(), y.data_ptr(), b, h, w, cin, cout, ksize, stride, int(planar_in), stat_mode,
+                                  None if stat_y is None else stat_y.data_ptr(), None if stat_aux is None else stat_aux.data_ptr(),
+                                  stat_out.data_ptr(), ngroups, _stream(y)),
+         tag=f"{cin}->{cout} k{ksize}s{stride} {h}x{w}x{b} +sums{stat_mode}",
+         work={"flops": 2.0 * ksize * ksize * cin * cout * b * ho * wo, "bytes": 4.0 * (x.numel() + y.numel() * (1 + (stat_mode == 2))),
+               "bound": "mfma"})
+    return y
+
+
 def pack_prob_weight(weight):
     """[1,Cin,3,3,3] `prob` conv weight -> packed 2-D weight whose output channels are the three kd slices (+ one zero
     channel), for the partial-sum route of prob_head."""

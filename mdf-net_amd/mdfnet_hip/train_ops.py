@@ -103,11 +103,13 @@ def bn_relu_apply(y, aux, res, n, c, groups=1):
     return z
 
 
-def bn_relu_backward(dz, y, aux, gamma, n, c, groups=1, pool=None):
-    """-> (dy, dgamma, dbeta)  (parameter gradients summed over the groups)."""
-    red = torch.zeros(groups * 2 * c, device=y.device, dtype=torch.float64) if pool is None else pool.take(groups * 2 * c)
-    _abi("mdf_bn_relu_bwd_reduce", (dz.data_ptr(), y.data_ptr(), aux.data_ptr(), n, c, groups, red.data_ptr(), _stream(y)),
-         tag=f"bwd-reduce C{c} N{n}x{groups}", work={"bytes": 8.0 * n * c * groups, "bound": "hbm"})
+def bn_relu_backward(dz, y, aux, gamma, n, c, groups=1, pool=None, red=None):
+    """-> (dy, dgamma, dbeta)  (parameter gradients summed over the groups).  `red` [groups][2c] = (sum dr, sum dr*xhat) when the
+    conv that produced dz has already accumulated them in its epilogue (ops.conv*_train, stat_mode 2); else reduced here."""
+    if red is None:
+        red = torch.zeros(groups * 2 * c, device=y.device, dtype=torch.float64) if pool is None else pool.take(groups * 2 * c)
+        _abi("mdf_bn_relu_bwd_reduce", (dz.data_ptr(), y.data_ptr(), aux.data_ptr(), n, c, groups, red.data_ptr(), _stream(y)),
+             tag=f"bwd-reduce C{c} N{n}x{groups}", work={"bytes": 8.0 * n * c * groups, "bound": "hbm"})
     dy = torch.empty_like(y)
     dgamma = torch.empty(c, device=y.device, dtype=torch.float32)
     dbeta = torch.empty(c, device=y.device, dtype=torch.float32)
@@ -152,14 +154,20 @@ def dgrad_pack(conv, transposed):
     return cache_of_key(conv, "dgrad").get((w,), build)
 
 
-def conv3d_dgrad(conv, transposed, dy, add_to=None):
-    """dx = [add_to +] (input gradient of the layer) as one launch of the forward conv kernel family."""
+def conv3d_dgrad(conv, transposed, dy, add_to=None, stat=None):
+    """dx = [add_to +] (input gradient of the layer) as one launch of the forward conv kernel family.  stat = (y_p, aux_p, red):
+    dx is the complete dz of the layer that produced this layer's input (raw conv output y_p, BatchNorm constants aux_p) --
+    its BatchNorm-backward sums are accumulated into `red` by the launch's epilogue."""
     wp = dgrad_pack(conv, transposed)
     if transposed:        # backward of ConvTranspose3d(Cin->Cout): stride-2 conv Cout -> Cin
-        return ops.conv3d_ndhwc(dy, wp, conv.out_channels, conv.in_channels, 2, False, None, None, False, add_to)
-    if conv.stride[0] == 2:
-        return ops.conv3d_ndhwc(dy, wp, conv.out_channels, conv.in_channels, 2, True, None, None, False, add_to)
-    return ops.conv3d_ndhwc(dy, wp, conv.out_channels, conv.in_channels, 1, False, None, None, False, add_to)
+        stride, tr = 2, False
+    elif conv.stride[0] == 2:
+        stride, tr = 2, True
+    else:
+        stride, tr = 1, False
+    if stat is not None:
+        return ops.conv3d_train(dy, wp, conv.out_channels, conv.in_channels, stride, tr, add_to, 2, stat[2], stat[0], stat[1])
+    return ops.conv3d_ndhwc(dy, wp, conv.out_channels, conv.in_channels, stride, tr, None, None, False, add_to)
 
 
 # --------------------------------------------------------------------------- prob head backward
@@ -182,11 +190,18 @@ def prob_head_backward(prob, hypos, ddepth, dprob, x_feat, weight):
 
 
 # --------------------------------------------------------------------------- regulariser: layer tape
+FUSE_BN_SUMS = True      # dev A/B (tests): False = statistics / backward sums as separate passes (mdf_bn_stats_fwd, mdf_bn_relu_bwd_reduce)
+
+
 class Tape:
-    """Forward record of the regulariser's layer program (net/unit/regular.py: `features`), replayed backwards."""
+    """Forward record of the regulariser's layer program (net/unit/regular.py: `features`), replayed backwards.
+    The per-channel sums of every BatchNorm ride in the epilogue of the conv that produces the tensor they are taken over:
+    forward, the layer's own conv (sum y, sum y^2); backward, the input-gradient conv of the NEXT layer, whose output (plus the
+    skip gradient in its `res` operand) is this layer's complete dz (sum dr, sum dr*xhat)."""
 
     def __init__(self):
         self.layers, self.pool = [], None
+        self.producer, self.uses = {}, {}      # id(z) -> layer index; id(tensor) -> consumers (conv input or skip) on the tape
 
     def layer(self, conv, bn, x, res):
         if self.pool is None:
@@ -194,10 +209,19 @@ class Tape:
         tr = isinstance(conv, torch.nn.ConvTranspose3d)
         stride = conv.stride[0]
         wp = ops_pack_fwd(conv, tr)
-        y = ops.conv3d_ndhwc(x, wp, conv.in_channels, conv.out_channels, stride, tr, None, None, False, None)   # raw conv
         c = conv.out_channels
+        if FUSE_BN_SUMS:
+            sums = self.pool.take(2 * c)
+            y = ops.conv3d_train(x, wp, conv.in_channels, c, stride, tr, None, 1, sums)                             # raw conv + statistics
+        else:
+            y = ops.conv3d_ndhwc(x, wp, conv.in_channels, c, stride, tr, None, None, False, None)                   # raw conv
+            sums = bn_stats(y, y.numel() // c, c, pool=self.pool)
         n = y.numel() // c
-        z, aux = bn_finalize_apply(bn_stats(y, n, c, pool=self.pool), bn, y, res, n, c)
+        z, aux = bn_finalize_apply(sums, bn, y, res, n, c)
+        self.producer[id(z)] = len(self.layers)
+        for t in (x, res):
+            if t is not None:
+                self.uses[id(t)] = self.uses.get(id(t), 0) + 1
         self.layers.append((conv, bn, tr, stride, x, y, aux, res, z))
         return z
 
@@ -206,18 +230,30 @@ class Tape:
         {param: grad} and leaves the input gradients in `grads`."""
         pg = {}
         pool = step_pool(self.layers[0][4].device)
-        for conv, bn, tr, stride, x, y, aux, res, z in reversed(self.layers):
+        pending, red_of = dict(self.uses), {}
+        for li in reversed(range(len(self.layers))):
+            conv, bn, tr, stride, x, y, aux, res, z = self.layers[li]
             dz = grads.pop(id(z))
             if res is not None:
                 grads[id(res)] = dz if id(res) not in grads else grads[id(res)] + dz
+                pending[id(res)] -= 1
             c = conv.out_channels
             n = y.numel() // c
-            dy, pg[bn.weight], pg[bn.bias] = bn_relu_backward(dz, y, aux, bn.weight, n, c, pool=pool)
+            dy, pg[bn.weight], pg[bn.bias] = bn_relu_backward(dz, y, aux, bn.weight, n, c, pool=pool, red=red_of.pop(li, None))
             if tr:      # ConvTranspose3d: small = x (input), big = dy (twice the size)
                 pg[conv.weight] = conv3d_wgrad(x, dy, 2, tuple(conv.weight.shape))
             else:
                 pg[conv.weight] = conv3d_wgrad(dy, x, stride, tuple(conv.weight.shape))
-            grads[id(x)] = conv3d_dgrad(conv, tr, dy, add_to=grads.get(id(x)))
+            pending[id(x)] -= 1
+            prod = self.producer.get(id(x))
+            stat = None
+            if FUSE_BN_SUMS and prod is not None and pending[id(x)] == 0:
+                # every other consumer of x (skip connections: later layers) has been walked: this launch's output is the COMPLETE
+                # dz of layer `prod`
+                pl = self.layers[prod]
+                stat = (pl[5], pl[6], pool.take(2 * pl[0].out_channels))
+                red_of[prod] = stat[2]
+            grads[id(x)] = conv3d_dgrad(conv, tr, dy, add_to=grads.get(id(x)), stat=stat)
         return pg
 
 
@@ -419,11 +455,14 @@ def _dgrad2d_pack(conv):
     raise NotImplementedError(f"conv2d input gradient for k={k} stride={stride}")
 
 
-def conv2d_dgrad(conv, dy):
-    """Input gradient of a Conv2d(k3,s1,p1) or Conv2d(k5,s2,p2) layer, NHWC, on the forward conv kernels."""
+def conv2d_dgrad(conv, dy, stat=None, groups=1):
+    """Input gradient of a Conv2d(k3,s1,p1) or Conv2d(k5,s2,p2) layer, NHWC, on the forward conv kernels.  stat = (y_p, aux_p, red)
+    (k3 only): the BatchNorm-backward sums of the producing layer ride in the launch's epilogue, as in conv3d_dgrad."""
     k, cin, cout = conv.kernel_size[0], conv.in_channels, conv.out_channels
     packs = _dgrad2d_pack(conv)
     if k == 3:
+        if stat is not None:
+            return ops.conv2d_train(dy, packs, cout, cin, 3, 1, False, 2, stat[2], groups, stat[0], stat[1])
         return ops.conv2d_nhwc(dy, packs, cout, cin, 3, 1)
     zs = [ops.conv2d_nhwc(dy, wp, cout, n, 3, 1) for wp, n in packs]
     z = zs[0] if len(zs) == 1 else torch.cat(zs, dim=-1)
@@ -437,6 +476,7 @@ class Tape2D:
 
     def __init__(self, groups):
         self.groups, self.layers, self.pool = groups, [], None
+        self.producer = {}
 
     def layer(self, conv, bn, x, planar_in=False, x_for_wgrad=None):
         k, stride = conv.kernel_size[0], conv.stride[0]
@@ -444,24 +484,41 @@ class Tape2D:
         if self.pool is None:
             self.pool = step_pool(x.device)
         wp = cache_of_key(conv, "fwd").get((conv.weight,), lambda: ops.pack_conv2d_weight(conv.weight))
-        y = ops.conv2d_nhwc(x, wp, conv.in_channels, conv.out_channels, k, stride, planar_in=planar_in)        # raw conv
         c = conv.out_channels
+        if FUSE_BN_SUMS:
+            sums = self.pool.take(self.groups * 2 * c)
+            y = ops.conv2d_train(x, wp, conv.in_channels, c, k, stride, planar_in, 1, sums, self.groups)                 # raw conv + statistics
+        else:
+            y = ops.conv2d_nhwc(x, wp, conv.in_channels, c, k, stride, planar_in=planar_in)                            # raw conv
+            sums = bn_stats(y, y.numel() // c // self.groups, c, self.groups, pool=self.pool)
         n = y.numel() // c // self.groups
-        z, aux = bn_finalize_apply(bn_stats(y, n, c, self.groups, pool=self.pool), bn, y, None, n, c, self.groups)
+        z, aux = bn_finalize_apply(sums, bn, y, None, n, c, self.groups)
+        self.producer[id(z)] = len(self.layers)
         self.layers.append((conv, bn, x if x_for_wgrad is None else x_for_wgrad, y, aux, z, x_for_wgrad is not None))
         return z
 
     def backward(self, grads):
         pg = {}
         pool = step_pool(self.layers[0][3].device)
-        for conv, bn, x, y, aux, z, is_input in reversed(self.layers):
+        red_of = {}
+        for li in reversed(range(len(self.layers))):
+            conv, bn, x, y, aux, z, is_input = self.layers[li]
             dz = grads.pop(id(z))
             c = conv.out_channels
             n = y.numel() // c // self.groups
-            dy, pg[bn.weight], pg[bn.bias] = bn_relu_backward(dz.contiguous(), y, aux, bn.weight, n, c, self.groups, pool=pool)
+            dy, pg[bn.weight], pg[bn.bias] = bn_relu_backward(dz.contiguous(), y, aux, bn.weight, n, c, self.groups, pool=pool,
+                                                               red=red_of.pop(li, None))
             pg[conv.weight] = conv2d_wgrad(dy, x, conv.kernel_size[0], conv.stride[0], tuple(conv.weight.shape))
             if not is_input:
-                dx = conv2d_dgrad(conv, dy)
+                prod = self.producer.get(id(x))
+                stat = None
+                if FUSE_BN_SUMS and prod is not None and id(x) not in grads and conv.kernel_size[0] == 3 and conv.stride[0] == 1:
+                    # x feeds this layer only (the pyramid outputs t2..t4 also receive a gradient from the heads and are consumed by
+                    # k5-s2 layers): the launch's output is the complete dz of layer `prod`
+                    pl = self.layers[prod]
+                    stat = (pl[3], pl[4], pool.take(self.groups * 2 * pl[0].out_channels))
+                    red_of[prod] = stat[2]
+                dx = conv2d_dgrad(conv, dy, stat=stat, groups=self.groups)
                 grads[id(x)] = dx if id(x) not in grads else grads[id(x)] + dx
         return pg
 

@@ -88,6 +88,117 @@ def test_conv3d_input_and_weight_gradients(cin, cout, stride, tr):
     assert _rel(dw, conv.weight.grad.cpu()) < 3e-5
 
 
+def _bn_sums_reference(out, stat_y=None, aux=None, groups=1):
+    """float64 reference of the epilogue sums over a channels-last tensor [B,...,C] split into `groups` along B."""
+    c = out.shape[-1]
+    o = out.detach().cpu().double().reshape(groups, -1, c)
+    if stat_y is None:
+        return torch.cat([o.sum(1), (o * o).sum(1)], dim=1).reshape(-1)
+    yv = stat_y.detach().cpu().double().reshape(groups, -1, c)
+    a, b, mu, inv = (t.unsqueeze(1) for t in aux.detach().cpu().double().reshape(groups, 4, c).unbind(1))
+    # the mask is taken exactly as the kernels take it: fp32 fma(y, a, b) > 0
+    mask = torch.addcmul(aux.detach().cpu().reshape(groups, 4, c)[:, 1].unsqueeze(1), stat_y.detach().cpu().reshape(groups, -1, c),
+                         aux.detach().cpu().reshape(groups, 4, c)[:, 0].unsqueeze(1)) > 0
+    dr = torch.where(mask, o, torch.zeros_like(o))
+    return torch.cat([dr.sum(1), (dr * (yv - mu) * inv).sum(1)], dim=1).reshape(-1)
+
+
+def _sums_close(got, ref, terms):
+    """sums of `terms` fp32 values: fp32 partials per wave tile, fp64 beyond -> relative to the sum of magnitudes, ~1e-6."""
+    got, ref = got.cpu().double(), ref.double()
+    scale = ref.abs().max().clamp(min=1e-30)
+    return float((got - ref).abs().max() / scale)
+
+
+@pytest.mark.parametrize("cin,cout,stride,tr,dhw", [
+    # small volumes: conv3d_kernel (v1), every mode incl. split-K; large ones (>= 150k voxels): the LDS kernels (Winograd / w-phase / direct)
+    (32, 16, 1, False, (4, 6, 22)), (64, 64, 1, False, (2, 5, 9)), (16, 32, 2, False, (4, 6, 20)), (8, 16, 2, False, (8, 36, 52)),
+    (64, 32, 2, True, (2, 3, 11)), (16, 8, 2, True, (4, 18, 26)),
+    (16, 16, 1, False, (8, 140, 150)), (32, 16, 1, False, (6, 130, 200)), (32, 32, 1, False, (6, 130, 200)), (16, 8, 1, False, (8, 140, 150)),
+    (8, 8, 1, False, (8, 141, 151))])
+def test_conv3d_epilogue_sums(cin, cout, stride, tr, dhw):
+    """mdf_conv3d_train_fwd: the raw conv is the one mdf_conv3d_fwd computes (bit-identical), and the per-channel sums its epilogue
+    accumulates equal float64 sums over that output -- mode 1 (sum y, sum y^2: the layer's batch statistics) and mode 2 (BatchNorm-
+    backward sums of the output taken as dz against another layer's raw output and constants), with and without a skip operand."""
+    torch.manual_seed(cin * 7 + cout + stride)
+    d, h, w = dhw
+    x = torch.randn(1, d, h, w, cin, device=DEV)
+    wt = torch.randn((cin, cout, 3, 3, 3) if tr else (cout, cin, 3, 3, 3), device=DEV) * 0.1
+    wp = ops.pack_conv3d_weight(wt, transposed=tr)
+    y_plain = ops.conv3d_ndhwc(x, wp, cin, cout, stride, tr, None, None, False, None)
+    sums = torch.zeros(2 * cout, device=DEV, dtype=torch.float64)
+    y = ops.conv3d_train(x, wp, cin, cout, stride, tr, None, 1, sums)
+    assert torch.equal(y, y_plain)
+    nvox = y.numel() // cout
+    assert _sums_close(sums, _bn_sums_reference(y), nvox) < 2e-6
+    # mode 2 (+ skip operand)
+    res = torch.randn_like(y)
+    stat_y = torch.randn_like(y) * 2 + 0.3
+    aux = torch.cat([torch.rand(cout) + 0.5, torch.randn(cout) * 0.3, torch.randn(cout) * 0.2, torch.rand(cout) + 0.5]).to(DEV)
+    red = torch.zeros(2 * cout, device=DEV, dtype=torch.float64)
+    dz = ops.conv3d_train(x, wp, cin, cout, stride, tr, res, 2, red, stat_y, aux)
+    assert torch.equal(dz, ops.conv3d_ndhwc(x, wp, cin, cout, stride, tr, None, None, False, res))
+    assert _sums_close(red, _bn_sums_reference(dz, stat_y, aux), nvox) < 2e-6
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,hw", [(3, 8, 3, 1, (40, 72)), (8, 8, 3, 1, (40, 72)), (16, 16, 3, 1, (20, 36)), (32, 32, 3, 1, (22, 34)),
+                                                   (64, 64, 3, 1, (10, 18)), (8, 16, 5, 2, (40, 72)), (16, 32, 5, 2, (20, 36)), (32, 64, 5, 2, (20, 36))])
+def test_conv2d_epilogue_sums_per_group(cin, cout, k, stride, hw):
+    """mdf_conv2d_train_fwd with 3 BatchNorm groups of 2 images: a block's run of tiles crosses image and group boundaries."""
+    torch.manual_seed(cin + cout + k)
+    h, w = hw
+    groups, b = 3, 6
+    planar = cin == 3
+    x = torch.randn((b, cin, h, w) if planar else (b, h, w, cin), device=DEV)
+    wt = torch.randn(cout, cin, k, k, device=DEV) * 0.1
+    wp = ops.pack_conv2d_weight(wt)
+    y_plain = ops.conv2d_nhwc(x, wp, cin, cout, k, stride, planar_in=planar)
+    sums = torch.zeros(groups * 2 * cout, device=DEV, dtype=torch.float64)
+    y = ops.conv2d_train(x, wp, cin, cout, k, stride, planar, 1, sums, groups)
+    assert torch.equal(y, y_plain)
+    assert _sums_close(sums, _bn_sums_reference(y, groups=groups), y.numel() // cout // groups) < 2e-6
+    if k == 3 and not planar:
+        stat_y = torch.randn_like(y) * 2 + 0.3
+        aux = torch.stack([torch.cat([torch.rand(cout) + 0.5, torch.randn(cout) * 0.3, torch.randn(cout) * 0.2, torch.rand(cout) + 0.5])
+                           for _ in range(groups)]).to(DEV)
+        red = torch.zeros(groups * 2 * cout, device=DEV, dtype=torch.float64)
+        dz = ops.conv2d_train(x, wp, cin, cout, k, stride, False, 2, red, groups, stat_y, aux.reshape(-1))
+        assert torch.equal(dz, y_plain)
+        assert _sums_close(red, _bn_sums_reference(dz, stat_y, aux, groups=groups), y.numel() // cout // groups) < 2e-6
+
+
+@pytest.mark.parametrize("stage", [0, 1])
+def test_fused_bn_sums_equal_the_separate_passes(stage, seeded_sd, monkeypatch):
+    """The regulariser's training forward + backward with the BatchNorm sums in the conv epilogues (default) against the same
+    with mdf_bn_stats_fwd / mdf_bn_relu_bwd_reduce as passes of their own: same launches otherwise, so the results agree to the
+    rounding of the sums (fp32 partials in a different order)."""
+    m = build_model()
+    m.load_state_dict(seeded_sd)
+    reg = m.Regular[stage].train().to(DEV)
+    g, d, h, w = ((32, 48, 12, 20), (16, 24, 24, 40))[stage]
+    torch.manual_seed(stage)
+    cost = torch.rand(2, g, d, h, w, device=DEV)
+    hyp = ((425 + 510 * torch.rand(2, 1, h, w)) + torch.linspace(-20, 20, d).reshape(1, d, 1, 1)).to(DEV)
+    dd = torch.randn(2, h, w, device=DEV)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(train_ops, "FUSE_BN_SUMS", fused)
+        ops.count_begin()
+        c = cost.clone().requires_grad_(True)
+        prob, depth = reg(c, hyp)
+        depth.backward(dd)
+        calls = ops.count_end()
+        res[fused] = [prob.detach(), depth.detach(), c.grad] + [p.grad.clone() for p in reg.parameters()]
+        reg.zero_grad()
+        if fused:
+            assert calls.get("mdf_bn_stats_fwd", 0) == 0 and calls.get("mdf_conv3d_train_fwd", 0) >= 10
+            assert calls.get("mdf_bn_relu_bwd_reduce", 0) == 1, calls          # only the last layer (its dz comes from the prob head)
+        else:
+            assert calls.get("mdf_conv3d_train_fwd", 0) == 0 and calls.get("mdf_bn_relu_bwd_reduce", 0) >= 10
+    for i, (a, b_) in enumerate(zip(res[True], res[False])):
+        assert _l2(a, b_) < 2e-5, (i, _l2(a, b_))
+
+
 @pytest.mark.parametrize("c,d", [(8, 8), (16, 24)])
 def test_prob_head_backward(c, d):
     torch.manual_seed(c)
@@ -209,8 +320,13 @@ def test_aggregate_scatter_claim_vs_all_atomics_full_size(stage, monkeypatch):
         assert torch.isfinite(a).all() and float(b.abs().max()) > 0
         e_max, e_l2 = _rel(a, b), _l2(a, b)
         worst = max(worst, e_max)
-        # a lost add drops one tap contribution: ~1e-2..1 of that texel's value; reordering fp32 sums of <= a few hundred terms: ~1e-6
-        assert e_max < 2e-5 and e_l2 < 2e-6, (i, e_max, e_l2)
+        # a lost add drops one tap contribution: ~1e-2..1 of that texel's value; reordering fp32 sums of <= a few hundred terms: ~1e-6.
+        # (the head-parameter gradients behind the features are cancelling sums over every voxel through float atomics whose
+        # order differs from run to run: looser)
+        if i < len(feats):
+            assert e_max < 2e-5 and e_l2 < 4e-6, (i, e_max, e_l2)
+        else:
+            assert e_max < 1e-3, (i, e_max, e_l2)
     print(f"\nstage {stage}: claim-based vs all-atomic scatter, worst max-rel difference {worst:.2e}")
 
 
@@ -349,13 +465,33 @@ def test_training_step_on_gpu_vs_reference_golden(golden, seeded_sd):
     np.testing.assert_allclose(float(loss.detach()), float(g["loss"]), rtol=2e-5)
     params = dict(m.named_parameters())
     assert all(p.grad is not None for p in params.values())
-    for k in g:
-        if k.startswith("grad:"):
-            ref = g[k]
-            got = params[k[5:]].grad.cpu().numpy()
-            rel = np.abs(got - ref).max() / np.abs(ref).max()
-            print(f"{k}: max rel err {rel:.2e}")
-            assert rel <= 5e-3, (k, rel)
+    got = {k[5:]: params[k[5:]].grad.detach().cpu().numpy().copy() for k in g if k.startswith("grad:")}
+    # Conditioning of each golden gradient, MEASURED: the same step with the images moved by one fp32 ulp (relative 2^-23, random
+    # sign).  A gradient that moves by s under a rounding-level change of the input cannot agree better than ~s between ANY two
+    # fp32 implementations (the reference's own CPU result included); the bar is 5e-3, or 8 s where the quantity is that
+    # ill-conditioned (the scalar biases are cancelling sums over ~1e5 voxels).
+    imgs, extr, intr, dr = synth.make_scene(96, 64, 3, batch=2, rot_deg=3.0, seed=31)
+    torch.manual_seed(0)
+    ulp = 1.0 + (torch.randint(0, 2, imgs.shape).float() * 2 - 1) * 2.0 ** -23
+    from net.loss import Loss
+    gt = {k: T(g["gt" + k]).to(DEV) for k in ("3", "2", "1", "0")}
+    rec2 = ops.recorded_host_values(projs=[g[f"host_proj{st}"] for st in range(3)], cams=[g[f"host_cam{st}"] for st in range(3)],
+                                    fit_row=g["host_fit_row"],
+                                    log_thresh={1: float(g["host_log_thresh1"]), 2: float(g["host_log_thresh2"])})
+    with rec2:
+        out2 = m((imgs * ulp).to(DEV), extr.to(DEV), intr.to(DEV), dr.to(DEV))
+    bucket.zero_grad()
+    Loss()(out2, gt, dr.to(DEV)).backward()
+    for k, mine in got.items():
+        ref = g["grad:" + k]
+        rel = np.abs(mine - ref).max() / np.abs(ref).max()
+        sens = np.abs(params[k].grad.detach().cpu().numpy() - mine).max() / np.abs(mine).max()
+        print(f"grad:{k}: max rel err vs reference {rel:.2e}; moves by {sens:.2e} under a 1-ulp change of the images")
+        assert rel <= max(5e-3, 8 * sens), (k, rel, sens)
+    bucket.zero_grad()
+    for k, mine in got.items():
+        params[k].grad = torch.from_numpy(mine).to(DEV)
+    bucket.allreduce_gradients()
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)
     opt.step()                                      # the optimizer consumes the bucket's views
     assert torch.isfinite(torch.cat([p.detach().reshape(-1) for p in m.parameters()])).all()
