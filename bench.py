@@ -245,16 +245,16 @@ TRAIN_W, TRAIN_H, TRAIN_V = 768, 576, 5
 
 
 def train_family(name, tag):
-    if name == "mdf_conv3d_fwd":
+    if name in ("mdf_conv3d_fwd", "mdf_conv3d_train_fwd"):
         return "conv3d forward + input gradients (regulariser): conv_lds_kernel / conv3d_kernel, fp32 MFMA"
-    if name == "mdf_conv2d_fwd":
+    if name in ("mdf_conv2d_fwd", "mdf_conv2d_train_fwd"):
         return "conv2d forward + input gradients (feature pyramid, refine, prob partial sums): conv_lds_kernel, fp32 MFMA"
     if name == "mdf_conv3d_wgrad":
         return "wgrad3d: wgrad_lds_kernel / wgrad_kernel (weight gradients, split-K fp32 MFMA)"
     if name == "mdf_conv2d_wgrad":
         return "wgrad2d: wgrad_lds_kernel / wgrad2d_kernel (weight gradients, split-K fp32 MFMA)"
     if name.startswith("mdf_bn_"):
-        return "batchnorm (batch statistics, apply, backward reduce + backward): bn_*_kernel"
+        return "batchnorm (apply, backward; the sums ride in the conv epilogues): bn_*_kernel"
     if name == "mdf_warp_aggregate_vec_train":
         return "aggregate scatter (pass 3): warp_bwd_kernel" if "pass3" in tag else "aggregate passes 0-2: warp_train_kernel"
     if name.startswith("mdf_prob_") or name == "mdf_upsample2_bilinear_bwd":

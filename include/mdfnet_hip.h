@@ -192,18 +192,20 @@ int mdf_consistency_fuse_fwd(const float* depth_ref, const float* conf, const fl
 int mdf_bn_stats_fwd(const float* y, long long N, int C, int ngroups, double* sums, void* stream);
 int mdf_bn_finalize_fwd(const double* sums, const float* gamma, const float* beta, float eps, float momentum, long long N,
                         int C, int ngroups, float* aux, float* running_mean, float* running_var,
-                        long long* num_batches_tracked, void* stream);
+                        long long* num_batches_tracked, int nslices, void* stream);
 int mdf_bn_relu_apply_fwd(const float* y, const float* aux, const float* res, float* z, long long N, int C, int ngroups,
                           void* stream);
 /* finalize + apply as one launch (what the training path uses): z = [res +] relu(y*a + b) with (a, b) derived from `sums` in
  * the kernel; aux [ngroups][4C] is written for the backward pass, the running statistics are updated as by finalize.   */
 int mdf_bn_finalize_apply_fwd(const float* y, const double* sums, const float* gamma, const float* beta, float eps, float momentum,
                               const float* res, float* z, float* aux, float* running_mean, float* running_var,
-                              long long* num_batches_tracked, long long N, int C, int ngroups, void* stream);
+                              long long* num_batches_tracked, long long N, int C, int ngroups, int nslices, void* stream);
 int mdf_bn_relu_bwd_reduce(const float* dz, const float* y, const float* aux, long long N, int C, int ngroups, double* red,
                            void* stream);
 int mdf_bn_relu_bwd(const float* dz, const float* y, const float* aux, const double* red, const float* gamma, long long N,
-                    int C, int ngroups, float* dy, float* dgamma, float* dbeta, void* stream);
+                    int C, int ngroups, float* dy, float* dgamma, float* dbeta, int nslices, void* stream);
+/* (`nslices`: the sums / reductions these three read may be spread over nslices copies [slice][group][2C] whose totals count --
+ *  that is how the conv epilogues of mdf_conv*_train_fwd deliver them; 1 for mdf_bn_stats_fwd / mdf_bn_relu_bwd_reduce.) */
 
 /* ---- weight gradient of nn.Conv3d(k3,p1,stride s) / nn.ConvTranspose3d(k3,s2,p1,op1) (net/unit/regular.py:17-43,
  *      80-110) as ONE correlation on the fp32 matrix cores:
@@ -232,13 +234,15 @@ int mdf_conv2d_wgrad(const float* small_, const float* big, float* dw, float* wo
  *                     layer whose raw conv output is stat_y and whose (a, b, mean, invstd)[C] is stat_aux:
  *                     stat_out[c] += sum dr, stat_out[C+c] += sum dr*xhat, dr = dz*[stat_y*a+b > 0], xhat = (stat_y-mean)*invstd
  *      stat_out: fp64, zero-initialised by the caller, C = Cout in {8,16,32,64}.  2-D: `ngroups` consecutive sets of B/ngroups
- *      images are separate BatchNorm groups (one per view, net/core.py:42): stat_out [ngroups][2C], stat_aux [ngroups][4C].  */
+ *      images are separate BatchNorm groups (one per view, net/core.py:42): stat_out [ngroups][2C], stat_aux [ngroups][4C].
+ *      `nslices` (1..64): stat_out is [nslices][ngroups][2C] and the sums are the TOTALS over the slices -- a launch spreads its
+ *      blocks over them so that no address takes more than a few dozen same-address atomics (~11 ns each, serialised).      */
 int mdf_conv3d_train_fwd(const float* x, const float* wpack, const float* res, float* y, int B, int Di, int Hi, int Wi, int Cin,
                          int Cout, int stride, int transposed, int stat_mode, const float* stat_y, const float* stat_aux,
-                         double* stat_out, void* stream);
+                         double* stat_out, int nslices, void* stream);
 int mdf_conv2d_train_fwd(const float* x, const float* wpack, float* y, int B, int H, int W, int Cin_mem, int Cout, int ksize,
                          int stride, int planar_in, int stat_mode, const float* stat_y, const float* stat_aux, double* stat_out,
-                         int ngroups, void* stream);
+                         int nslices, int ngroups, void* stream);
 
 /* ---- batched weight packing: every packed weight set a training step reads (forward convs and their input-gradient
  *      convs, train.py:36-45 after optimizer.step()), written by ONE launch.  A job is one weight set in the layout of

@@ -21,6 +21,33 @@ constexpr int kT = 256;
 
 __device__ __forceinline__ void lds_add(double* p, double v) { atomicAdd(p, v); }
 
+// The sums may arrive spread over `nslices` copies [slice][group][2C] (the conv epilogues of conv3d.hip / conv_lds.hip send
+// them that way to keep same-address atomics few): total of entry i of group g.
+__device__ __forceinline__ double sliced(const double* __restrict__ sums, int g, int i, int C, int ngroups, int nslices) {
+  double t = 0.0;
+  for (int s = 0; s < nslices; ++s) t += sums[((long long)s * ngroups + g) * 2 * C + i];
+  return t;
+}
+
+// The same for a whole block: totals of group g's 2C entries into LDS `tot` (2C <= 128), every thread issuing its share of the
+// nslices*2C loads at once (one L2 round trip instead of nslices dependent ones per value).  Ends with a barrier.
+__device__ __forceinline__ void sliced_block(const double* __restrict__ sums, int g, int C, int ngroups, int nslices, double* tot) {
+  const int tid = threadIdx.x, n2 = 2 * C;
+  __syncthreads();             // (a previous use of `tot` by the caller's loop is over)
+  if (tid < n2) tot[tid] = 0.0;
+  __syncthreads();
+  if (nslices == 1) {
+    if (tid < n2) tot[tid] = sums[(long long)g * n2 + tid];
+  } else {
+    for (int i = tid; i < nslices * n2; i += kT) {
+      const int s = i / n2, e = i - s * n2;
+      const double v = sums[((long long)s * ngroups + g) * n2 + e];
+      if (v != 0.0) lds_add(&tot[e], v);
+    }
+  }
+  __syncthreads();
+}
+
 template <bool BWD>
 __global__ __launch_bounds__(kT) void bn_reduce_kernel(const float* __restrict__ y, const float* __restrict__ dz,
                                                        const float* __restrict__ aux, long long n4, int C,
@@ -66,14 +93,13 @@ __global__ __launch_bounds__(kT) void bn_reduce_kernel(const float* __restrict__
 
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float eps, float momentum, double n, int C, int ngroups, float* __restrict__ aux,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt) {
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt, int nslices) {
   const int c = threadIdx.x;
   if (c < C) {
     for (int g = 0; g < ngroups; ++g) {     // groups = successive calls of the module: the running statistics see them in order
-      const double* s = sums + (long long)g * 2 * C;
       float* a4 = aux + (long long)g * 4 * C;
-      const double mean = s[c] / n;
-      double var = s[C + c] / n - mean * mean;
+      const double mean = sliced(sums, g, c, C, ngroups, nslices) / n;
+      double var = sliced(sums, g, C + c, C, ngroups, nslices) / n - mean * mean;
       if (var < 0.0) var = 0.0;
       const float invstd = (float)(1.0 / sqrt(var + (double)eps));
       const float a = gamma[c] * invstd;
@@ -126,15 +152,16 @@ __global__ __launch_bounds__(kT) void bn_finalize_apply_kernel(const float* __re
                                                                float momentum, double n, const float* __restrict__ res,
                                                                float* __restrict__ z, float* __restrict__ aux,
                                                                float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                               long long* __restrict__ nbt, long long n4, int C, int ngroups) {
+                                                               long long* __restrict__ nbt, long long n4, int C, int ngroups, int nslices) {
   const int tid = threadIdx.x, g = blockIdx.y;
   const int c0 = (4 * tid) % C;
-  const double* s = sums + (long long)g * 2 * C;
+  __shared__ double tot[128];
+  sliced_block(sums, g, C, ngroups, nslices, tot);
   float a[4], b[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const double mean = s[c0 + k] / n;
-    double var = s[C + c0 + k] / n - mean * mean;
+    const double mean = tot[c0 + k] / n;
+    double var = tot[C + c0 + k] / n - mean * mean;
     if (var < 0.0) var = 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     a[k] = gamma[c0 + k] * invstd;
@@ -144,15 +171,18 @@ __global__ __launch_bounds__(kT) void bn_finalize_apply_kernel(const float* __re
       a4[c0 + k] = a[k]; a4[C + c0 + k] = b[k]; a4[2 * C + c0 + k] = (float)mean; a4[3 * C + c0 + k] = invstd;
     }
   }
-  if (blockIdx.x == 0 && g == 0 && running_mean && tid < C) {
+  if (blockIdx.x == 0 && g == 0 && running_mean) {      // (block-uniform)
+    __shared__ double tg[128];
     for (int gg = 0; gg < ngroups; ++gg) {      // groups = successive calls of the module
-      const double* sg = sums + (long long)gg * 2 * C;
-      const double mean = sg[tid] / n;
-      double var = sg[C + tid] / n - mean * mean;
-      if (var < 0.0) var = 0.0;
-      const double unb = (n > 1.0) ? var * n / (n - 1.0) : var;
-      running_mean[tid] = (1.0f - momentum) * running_mean[tid] + momentum * (float)mean;
-      running_var[tid] = (1.0f - momentum) * running_var[tid] + momentum * (float)unb;
+      sliced_block(sums, gg, C, ngroups, nslices, tg);
+      if (tid < C) {
+        const double mean = tg[tid] / n;
+        double var = tg[C + tid] / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double unb = (n > 1.0) ? var * n / (n - 1.0) : var;
+        running_mean[tid] = (1.0f - momentum) * running_mean[tid] + momentum * (float)mean;
+        running_var[tid] = (1.0f - momentum) * running_var[tid] + momentum * (float)unb;
+      }
     }
     if (tid == 0 && nbt) *nbt += ngroups;
   }
@@ -178,26 +208,34 @@ __global__ __launch_bounds__(kT) void bn_finalize_apply_kernel(const float* __re
 __global__ __launch_bounds__(kT) void bn_relu_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ y,
                                                          const float* __restrict__ aux, const double* __restrict__ red,
                                                          const float* __restrict__ gamma, double inv_n, float* __restrict__ dy,
-                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, long long n4, int C) {
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, long long n4, int C, int nslices) {
   const int tid = threadIdx.x;
   const int c0 = (4 * tid) % C;
+  const int ngroups = (int)gridDim.y;
   dz += (long long)blockIdx.y * n4 * 4;
   y += (long long)blockIdx.y * n4 * 4;
   dy += (long long)blockIdx.y * n4 * 4;
   aux += (long long)blockIdx.y * 4 * C;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid < C) {   // parameter gradients: the groups are calls of ONE module, their gradients add
+  if (blockIdx.x == 0 && blockIdx.y == 0) {   // parameter gradients: the groups are calls of ONE module, their gradients add (block-uniform)
+    __shared__ double tg[128];
     double sb = 0.0, sg = 0.0;
-    for (int g = 0; g < (int)gridDim.y; ++g) { sb += red[(long long)g * 2 * C + tid]; sg += red[(long long)g * 2 * C + C + tid]; }
-    dbeta[tid] = (float)sb;
-    dgamma[tid] = (float)sg;
+    for (int g = 0; g < ngroups; ++g) {
+      sliced_block(red, g, C, ngroups, nslices, tg);
+      if (tid < C) { sb += tg[tid]; sg += tg[C + tid]; }
+    }
+    if (tid < C) {
+      dbeta[tid] = (float)sb;
+      dgamma[tid] = (float)sg;
+    }
   }
-  red += (long long)blockIdx.y * 2 * C;
+  __shared__ double tot[128];
+  sliced_block(red, (int)blockIdx.y, C, ngroups, nslices, tot);
   float a[4], b[4], mu[4], is[4], m1[4], m2[4], gi[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     a[k] = aux[c0 + k]; b[k] = aux[C + c0 + k]; mu[k] = aux[2 * C + c0 + k]; is[k] = aux[3 * C + c0 + k];
-    m1[k] = (float)(red[c0 + k] * inv_n);
-    m2[k] = (float)(red[C + c0 + k] * inv_n);
+    m1[k] = (float)(tot[c0 + k] * inv_n);
+    m2[k] = (float)(tot[C + c0 + k] * inv_n);
     gi[k] = gamma[c0 + k] * is[k];
   }
   const long long stride = (long long)gridDim.x * kT;
@@ -252,12 +290,12 @@ extern "C" int mdf_bn_stats_fwd(const float* y, long long N, int C, int ngroups,
 
 extern "C" int mdf_bn_finalize_fwd(const double* sums, const float* gamma, const float* beta, float eps, float momentum,
                                    long long N, int C, int ngroups, float* aux, float* running_mean, float* running_var,
-                                   long long* num_batches_tracked, void* stream) {
+                                   long long* num_batches_tracked, int nslices, void* stream) {
   MDF_REQUIRE(sums && gamma && beta && aux, "null pointer argument");
-  MDF_REQUIRE(C >= 1 && C <= 64 && N > 0 && ngroups >= 1, "bad shape");
+  MDF_REQUIRE(C >= 1 && C <= 64 && N > 0 && ngroups >= 1 && nslices >= 1, "bad shape");
   MDF_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running_mean and running_var go together");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, gamma, beta, eps, momentum, (double)N, C, ngroups, aux,
-                     running_mean, running_var, num_batches_tracked);
+                     running_mean, running_var, num_batches_tracked, nslices);
   return mdf::check_launch("bn_finalize_kernel");
 }
 
@@ -280,23 +318,23 @@ extern "C" int mdf_bn_relu_bwd_reduce(const float* dz, const float* y, const flo
 }
 
 extern "C" int mdf_bn_relu_bwd(const float* dz, const float* y, const float* aux, const double* red, const float* gamma, long long N,
-                               int C, int ngroups, float* dy, float* dgamma, float* dbeta, void* stream) {
+                               int C, int ngroups, float* dy, float* dgamma, float* dbeta, int nslices, void* stream) {
   if (int rc = check_bn(y, N, C)) return rc;
-  MDF_REQUIRE(dz && aux && red && gamma && dy && dgamma && dbeta && ngroups >= 1 && ngroups <= 65535, "bad argument");
+  MDF_REQUIRE(dz && aux && red && gamma && dy && dgamma && dbeta && ngroups >= 1 && ngroups <= 65535 && nslices >= 1, "bad argument");
   const long long n4 = N * C / 4;
   hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(grid_for(n4, ngroups), ngroups), dim3(kT), 0, (hipStream_t)stream, dz, y, aux, red, gamma, 1.0 / (double)N, dy,
-                     dgamma, dbeta, n4, C);
+                     dgamma, dbeta, n4, C, nslices);
   return mdf::check_launch("bn_relu_bwd_kernel");
 }
 
 extern "C" int mdf_bn_finalize_apply_fwd(const float* y, const double* sums, const float* gamma, const float* beta, float eps, float momentum,
                                          const float* res, float* z, float* aux, float* running_mean, float* running_var,
-                                         long long* num_batches_tracked, long long N, int C, int ngroups, void* stream) {
+                                         long long* num_batches_tracked, long long N, int C, int ngroups, int nslices, void* stream) {
   if (int rc = check_bn(y, N, C)) return rc;
-  MDF_REQUIRE(sums && gamma && beta && z && aux && ngroups >= 1 && ngroups <= 65535, "bad argument");
+  MDF_REQUIRE(sums && gamma && beta && z && aux && ngroups >= 1 && ngroups <= 65535 && nslices >= 1, "bad argument");
   MDF_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running_mean and running_var go together");
   const long long n4 = N * C / 4;
   hipLaunchKernelGGL(bn_finalize_apply_kernel, dim3(grid_for(n4, ngroups), ngroups), dim3(kT), 0, (hipStream_t)stream, y, sums, gamma, beta, eps,
-                     momentum, (double)N, res, z, aux, running_mean, running_var, num_batches_tracked, n4, C, ngroups);
+                     momentum, (double)N, res, z, aux, running_mean, running_var, num_batches_tracked, n4, C, ngroups, nslices);
   return mdf::check_launch("bn_finalize_apply_kernel");
 }

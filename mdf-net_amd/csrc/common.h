@@ -62,7 +62,29 @@ struct ConvStat {
   const float* aux;
   double* out;
   int group_imgs;      // 2-D: images per BatchNorm group (the tensor is [groups][imgs][H][W][C]); 0 = one group
+  int nslices;         // the sums are spread over this many copies ("slices") of [groups][2C]; the consumers add them up
 };
+
+// Sending a block's sums to memory costs 2C fp64 atomics on the SAME 2C addresses for every block, and same-address atomics
+// retire one per ~11 ns (rocprof, r03: a 2592-block launch paid 28 us for them -- more than its MFMA work).  A two-level
+// scheme with per-slice counters (last arriver collapses the slice) was built and is far worse: its release fence writes the
+// L2 back per block (24 -> 120 us).  So: block b adds into slice b % R of out[R][groups][2C] (contention / R, no ordering
+// needed) and the BatchNorm kernels that consume the sums add the R slices up (16 x 32 B per thread, L2 hits).
+inline int conv_stat_slices(long long blocks_per_group, int nslices) {
+  long long r = (blocks_per_group + 47) / 48;          // <= ~48 blocks per address
+  if (r > nslices) r = nslices;
+  return (int)(r < 1 ? 1 : r);
+}
+// tab: the block's LDS table [2][64] (sum, sum2).  out: slice 0 of this block's group; consecutive slices are slice_stride apart.
+template <int COUT>
+__device__ __forceinline__ void conv_stat_send(const double* tab, double* out, long long slice_stride, int R, unsigned local_blk) {
+  const int tid = threadIdx.x;
+  if (tid < 2 * COUT) {
+    const int c = tid % COUT, which = tid / COUT;
+    const double v = tab[which * 64 + c];
+    if (v != 0.0) atomicAdd(&out[(size_t)(local_blk % (unsigned)R) * slice_stride + which * COUT + c], v);
+  }
+}
 
 }  // namespace mdf
 

@@ -48,6 +48,7 @@ struct ConvParams {
   const float* stat_y;
   const float* stat_aux;
   double* stat_out;
+  int stat_slices;        // slices of stat_out this launch spreads its blocks over (common.h: conv_stat_send)
 };
 
 // fp64 LDS add (ds_add_f64) / the DPP sum over the 16 lanes of an MFMA column group (lanes q*16 .. q*16+15 hold the 16
@@ -106,7 +107,23 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
   const int wave = threadIdx.x >> 6;
   const int q = lane >> 4;    // k sub-slot / cout quad
   const int n16 = lane & 15;  // voxel inside the m-tile (B operand, C/D column)
-  const unsigned tile_blk = mdf::xcd_remap(blockIdx.x, p.nblk);
+  // ST: block-level fp64 table of the epilogue sums [2][64] + the producing layer's (a, b, mean, invstd) [4][64].  Sending the
+  // sums to memory costs 2*COUT same-address fp64 atomics per BLOCK (~10 ns each, serialised at the memory side): a one-tile
+  // block per 16-64 voxels made that the most expensive part of the small layers (rocprof: 32->32 split-K 24 -> 52 us).  The ST
+  // form therefore (a) is persistent above the number of blocks the chip holds at once (these kernels live on residency: the
+  // grid is capped at that, not lower) and (b) spreads the blocks over slices of stat_out (common.h: conv_stat_send).
+  __shared__ double st_tab[ST ? 128 : 1];
+  __shared__ float st_aux[ST ? 256 : 1];
+  if constexpr (ST != 0) {
+    if (threadIdx.x < 128) st_tab[threadIdx.x] = 0.0;
+    if (p.stat_mode == 2) {
+      const int c = threadIdx.x & 63;
+      st_aux[threadIdx.x] = (c < COUT) ? p.stat_aux[(threadIdx.x >> 6) * COUT + c] : 0.f;
+    }
+    __syncthreads();
+  }
+  for (unsigned vblk = blockIdx.x; vblk < (ST ? p.nblk : blockIdx.x + 1); vblk += gridDim.x) {
+  const unsigned tile_blk = mdf::xcd_remap(vblk, p.nblk);
   const long long m0 = (SPLITK > 1 ? (long long)tile_blk : (long long)tile_blk * 4 + wave) * (MT * 16);
 
   // transposed: parity class of this block
@@ -158,18 +175,6 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
   for (int t = 0; t < MT; ++t)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // ST: block-level fp64 table of the epilogue sums [2][64] + the producing layer's (a, b, mean, invstd) [4][64]
-  __shared__ double st_tab[ST ? 128 : 1];
-  __shared__ float st_aux[ST ? 256 : 1];
-  if constexpr (ST != 0) {
-    if (threadIdx.x < 128) st_tab[threadIdx.x] = 0.0;
-    if (p.stat_mode == 2) {
-      const int c = threadIdx.x & 63;
-      st_aux[threadIdx.x] = (c < COUT) ? p.stat_aux[(threadIdx.x >> 6) * COUT + c] : 0.f;
-    }
-    // (made visible by the barrier in front of the epilogue)
-  }
 
   // Epilogue operands (folded BN, residual) are fetched NOW so their L2 round trip overlaps the tap loop: a block lives for
   // one wave tile (10-20 us), an exposed ~1 us at its end is 5-10 % of it.
@@ -312,7 +317,6 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
       }
   }
 
-  if constexpr (ST != 0 && SPLITK == 1) __syncthreads();   // the tables above (split-K has passed a barrier already)
   // epilogue: lane owns couts nt*16 + 4q .. +3 of voxel out_vox[t]
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -363,13 +367,11 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
       }
     }
   }
+  if constexpr (ST != 0 && SPLITK > 1) __syncthreads();   // the next tile's partial sums overwrite `part`
+  }  // tile loop (one tile unless ST)
   if constexpr (ST != 0) {
     __syncthreads();
-    if (threadIdx.x < 2 * COUT) {
-      const int c = threadIdx.x % COUT, which = threadIdx.x / COUT;
-      const double v = st_tab[which * 64 + c];
-      if (v != 0.0) atomicAdd(&p.stat_out[which * COUT + c], v);
-    }
+    mdf::conv_stat_send<COUT>(st_tab, p.stat_out, 2 * COUT, p.stat_slices, blockIdx.y * gridDim.x + blockIdx.x);
   }
 }
 
@@ -554,7 +556,13 @@ template <int CIN, int COUT, int MODE, int MT, int SPLITK, int ST>
 int launch_conv(ConvParams& p, hipStream_t st) {
   const long long per_blk = (SPLITK > 1 ? 1LL : 4LL) * MT * 16;
   p.nblk = (unsigned)((p.m_total + per_blk - 1) / per_blk);
-  dim3 grid(p.nblk, MODE == kTr ? 4 : 1), block(256);
+  unsigned gx = p.nblk;
+  if (ST) {   // persistent above what the chip holds at once (8 blocks per CU)
+    const unsigned cap = (MODE == kTr) ? 512u : 2048u;
+    if (gx > cap) gx = cap;
+    p.stat_slices = mdf::conv_stat_slices((long long)gx * (MODE == kTr ? 4 : 1), p.stat_slices);
+  }
+  dim3 grid(gx, MODE == kTr ? 4 : 1), block(256);
   hipLaunchKernelGGL((conv3d_kernel<CIN, COUT, MODE, MT, SPLITK, ST>), grid, block, 0, st, p);
   return mdf::check_launch("conv3d_kernel");
 }
@@ -668,23 +676,24 @@ extern "C" int mdf_conv2d_fwd(const float* x, const float* wpack, const float* a
                       stream, nullptr);
 }
 
-static int check_stat(int stat_mode, const float* stat_y, const float* stat_aux, const double* stat_out, int Cout) {
+static int check_stat(int stat_mode, const float* stat_y, const float* stat_aux, const double* stat_out, int nslices, int Cout) {
   MDF_REQUIRE(stat_mode == 1 || stat_mode == 2, "stat_mode=%d not in {1 (sum y, sum y^2), 2 (BatchNorm-backward sums)}", stat_mode);
   MDF_REQUIRE(stat_out, "stat_out is null");
+  MDF_REQUIRE(nslices >= 1 && nslices <= 64, "nslices=%d out of range [1,64]", nslices);
   MDF_REQUIRE(stat_mode == 1 || (stat_y && stat_aux), "stat_mode 2 needs stat_y and stat_aux");
   MDF_REQUIRE(Cout % 4 == 0 && Cout >= 8 && Cout <= 64, "epilogue sums are built for Cout in {8,..,64}, Cout %% 4 == 0 (got %d)", Cout);
   return MDF_OK;
 }
 
 // Training: the RAW 2-D conv (no scale / shift / ReLU) whose epilogue also accumulates per-channel sums of its output, per
-// BatchNorm group (ngroups consecutive sets of B/ngroups images): see ConvParams::stat_mode.  stat_out [ngroups][2*Cout]
-// fp64, zero-initialised by the caller; stat_aux [ngroups][4*Cout].
+// BatchNorm group (ngroups consecutive sets of B/ngroups images): see ConvParams::stat_mode.  stat_out [nslices][ngroups][2*Cout]
+// fp64, zero-initialised by the caller (the sums are the totals over the slices); stat_aux [ngroups][4*Cout].
 extern "C" int mdf_conv2d_train_fwd(const float* x, const float* wpack, float* y, int B, int H, int W, int Cin_mem, int Cout, int ksize,
                                     int stride, int planar_in, int stat_mode, const float* stat_y, const float* stat_aux, double* stat_out,
-                                    int ngroups, void* stream) {
-  if (int rc = check_stat(stat_mode, stat_y, stat_aux, stat_out, Cout)) return rc;
+                                    int nslices, int ngroups, void* stream) {
+  if (int rc = check_stat(stat_mode, stat_y, stat_aux, stat_out, nslices, Cout)) return rc;
   MDF_REQUIRE(ngroups >= 1 && B % ngroups == 0, "B=%d is not a multiple of ngroups=%d", B, ngroups);
-  const ConvStat st{stat_mode, stat_y, stat_aux, stat_out, B / ngroups};
+  const ConvStat st{stat_mode, stat_y, stat_aux, stat_out, B / ngroups, nslices};
   return conv2d_entry(x, wpack, nullptr, nullptr, nullptr, 1.0f, nullptr, y, B, H, W, Cin_mem, Cout, ksize, stride, 0, planar_in, 0, stream, &st);
 }
 
@@ -704,7 +713,7 @@ static int conv3d_entry(const float* x, const float* wpack, const float* alpha, 
   ConvParams p{};
   p.x = x; p.wpack = wpack; p.alpha = alpha; p.beta = beta; p.res = res; p.y = y;
   p.B = B; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.relu = relu;
-  if (stat) { p.stat_mode = stat->mode; p.stat_y = stat->y; p.stat_aux = stat->aux; p.stat_out = stat->out; }
+  if (stat) { p.stat_mode = stat->mode; p.stat_y = stat->y; p.stat_aux = stat->aux; p.stat_out = stat->out; p.stat_slices = stat->nslices; }
   const int m = transposed ? kTr : (stride == 2 ? kS2 : kS1);
   if (m == kS1) { p.Do = Di; p.Ho = Hi; p.Wo = Wi; }
   else if (m == kS2) { p.Do = (Di - 1) / 2 + 1; p.Ho = (Hi - 1) / 2 + 1; p.Wo = (Wi - 1) / 2 + 1; }
@@ -736,13 +745,13 @@ extern "C" int mdf_conv3d_fwd(const float* x, const float* wpack, const float* a
 }
 
 // Training: the RAW 3-D conv / transposed conv ([res +] conv(x), no scale / shift / ReLU) whose epilogue also accumulates
-// per-channel sums of its output (ConvParams::stat_mode) into stat_out [2*Cout] fp64, zero-initialised by the caller.
+// per-channel sums of its output (ConvParams::stat_mode) into stat_out [nslices][2*Cout] fp64, zero-initialised by the caller.
 // stat_mode 1 serves the forward pass (the layer's batch statistics); stat_mode 2 the backward pass, where this launch is the
 // input-gradient conv of the NEXT layer and its output (+ res, the skip gradient) is dz of the layer that produced stat_y.
 extern "C" int mdf_conv3d_train_fwd(const float* x, const float* wpack, const float* res, float* y, int B, int Di, int Hi, int Wi, int Cin,
                                     int Cout, int stride, int transposed, int stat_mode, const float* stat_y, const float* stat_aux,
-                                    double* stat_out, void* stream) {
-  if (int rc = check_stat(stat_mode, stat_y, stat_aux, stat_out, Cout)) return rc;
-  const ConvStat st{stat_mode, stat_y, stat_aux, stat_out, 0};
+                                    double* stat_out, int nslices, void* stream) {
+  if (int rc = check_stat(stat_mode, stat_y, stat_aux, stat_out, nslices, Cout)) return rc;
+  const ConvStat st{stat_mode, stat_y, stat_aux, stat_out, 0, nslices};
   return conv3d_entry(x, wpack, nullptr, nullptr, res, y, B, Di, Hi, Wi, Cin, Cout, stride, transposed, 0, stream, &st);
 }

@@ -44,7 +44,8 @@ struct LdsConvParams {
   const float* stat_y;
   const float* stat_aux;               // [groups][4*COUT]
   double* stat_out;                    // [groups][2*COUT]
-  int stat_group_imgs;                 // 2-D: images per BatchNorm group (0: one group)
+  int stat_groups;                     // 2-D: BatchNorm groups (consecutive sets of B / groups images); the ST grid is groups x blocks-per-group
+  int stat_slices;                     // slices of stat_out [slices][groups][2C] the blocks are spread over (common.h: conv_stat_send)
 };
 
 // fp64 LDS add and the DPP sum over the 16 lanes that hold the 16 MFMA columns of one 4-channel row group
@@ -176,10 +177,10 @@ struct Cfg {
 };
 
 // ST epilogue: the lane's 4 output values o[] of channels c0.. at output index oi -> its running sums (ps, pq)
-template <typename C>
+template <typename C, int ST>
 __device__ __forceinline__ void stat_accum(const LdsConvParams& p, const float* lds_base, size_t oi, int c0, const float (&o)[4],
                                            float (&ps)[4], float (&pq)[4]) {
-  if (p.stat_mode == 1) {
+  if constexpr (ST == 1) {     // (the two modes are separate instantiations: together they cost the 2-D kernels an occupancy step)
 #pragma unroll
     for (int k = 0; k < 4; ++k) { ps[k] += o[k]; pq[k] = fmaf(o[k], o[k], pq[k]); }
   } else {
@@ -340,7 +341,7 @@ __device__ __forceinline__ void step(const float* const (&planes)[KD], __amdgpu_
           o[2] = rr.z + o[2] * p.res_scale; o[3] = rr.w + o[3] * p.res_scale;
         }
         *reinterpret_cast<float4*>(p.y + oi) = make_float4(o[0], o[1], o[2], o[3]);
-        if constexpr (ST != 0) stat_accum<C>(p, lds_base_, oi, c0, o, ps, pq);
+        if constexpr (ST != 0) stat_accum<C, ST>(p, lds_base_, oi, c0, o, ps, pq);
       } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -529,7 +530,7 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __a
           o[2] = rr.z + o[2] * p.res_scale; o[3] = rr.w + o[3] * p.res_scale;
         }
         *reinterpret_cast<float4*>(p.y + oi) = make_float4(o[0], o[1], o[2], o[3]);
-        if constexpr (ST != 0) stat_accum<C>(p, lds_base_, oi, c0, o, ps, pq);
+        if constexpr (ST != 0) stat_accum<C, ST>(p, lds_base_, oi, c0, o, ps, pq);
       }
     }
     if constexpr (ST != 0) stat_commit<C>(lds_base_, c0, n16, ps, pq);
@@ -543,7 +544,10 @@ template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT, int 
 // (A/B in one process, scripts/bench_conv3d.py); with 2+ n-tiles the cap makes hipcc spill, so those stay uncapped.
 // (Tighter caps for the 2-D kernels were tried: they spill the MFMA-heavy ones and do not help the latency-bound ones.)
 // (Winograd form with 32+ input channels: its 141 KB of LDS allow one block per CU anyway, so it may use the whole register file)
-__global__ __launch_bounds__(256, ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 : 1)) void conv_lds_kernel(const LdsConvParams p) {
+// (ST variants of the HBM-bound 2-D layers: the ~10 registers of the epilogue sums would cost an occupancy step -- 16->16 Winograd 26 -> 43 us,
+// 3->8 40 -> 58 us by rocprof -- so those keep their residency and spill a few registers instead)
+__global__ __launch_bounds__(256, (ST != 0 && KD == 1 && WG == 1 && CIN == 16) ? 3 : (ST != 0 && KD == 1 && CIN == 4) ? 4 :
+                                  ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 : 1)) void conv_lds_kernel(const LdsConvParams p) {
   typedef Cfg<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW, WG> C;
   constexpr int KPL = C::KPL, NG = C::NG, S = C::S, PW = C::PW, PH = C::PH;
   typedef typename VecT<KPL>::type vec_t;
@@ -564,28 +568,16 @@ __global__ __launch_bounds__(256, ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 :
   // ST: the block's fp64 sums [2][64] (sent to memory with one atomic per channel when the block -- or, 2-D, its run of tiles
   // inside one BatchNorm group -- is done) and, mode 2, the producing layer's (a, b, mean, invstd) of the current group
   [[maybe_unused]] double* st_tab = reinterpret_cast<double*>(lds + C::STAT_OFF);
-  [[maybe_unused]] int st_group = 0;
-  [[maybe_unused]] auto st_load_aux = [&](int grp) {
-    if (p.stat_mode == 2) {
-      const int c = tid & 63;
-      lds[C::SAUX_OFF + tid] = (c < COUT) ? p.stat_aux[(size_t)grp * 4 * COUT + (tid >> 6) * COUT + c] : 0.f;
-    }
-  };
-  [[maybe_unused]] auto st_flush = [&](int grp) {     // all waves have committed (caller put a barrier in front)
-    if (tid < 2 * COUT) {
-      const int c = tid % COUT, which = tid / COUT;
-      const double v = st_tab[which * 64 + c];
-      if (v != 0.0) atomicAdd(&p.stat_out[(size_t)grp * 2 * COUT + which * COUT + c], v);
-      st_tab[which * 64 + c] = 0.0;
-    }
-  };
+  // 2-D ST: the grid is groups x blocks-per-group and a block's run of tiles stays inside its BatchNorm group
+  [[maybe_unused]] const int st_bpg = (ST != 0 && KD == 1) ? (int)gridDim.x / (p.stat_groups > 0 ? p.stat_groups : 1) : (int)gridDim.x;
+  [[maybe_unused]] const int st_group = (ST != 0 && KD == 1) ? (int)blockIdx.x / st_bpg : 0;
+  [[maybe_unused]] const int st_local = (ST != 0 && KD == 1) ? (int)blockIdx.x % st_bpg : (int)blockIdx.x;
   if constexpr (ST != 0) {
     if (tid < 128) st_tab[tid] = 0.0;
-    if constexpr (KD == 1) {
-      const int t_first = (int)((long long)blockIdx.x * p.n_tiles / gridDim.x);
-      st_group = p.stat_group_imgs > 0 ? (t_first / (p.tiles_w * p.tiles_h)) / p.stat_group_imgs : 0;
+    if constexpr (ST == 2) {
+      const int c = tid & 63;
+      lds[C::SAUX_OFF + tid] = (c < COUT) ? p.stat_aux[(size_t)st_group * 4 * COUT + (tid >> 6) * COUT + c] : 0.f;
     }
-    st_load_aux(st_group);
   }
   __syncthreads();
   // per-lane constants for the whole kernel: epilogue scale/shift of the lane's 4 couts, and (small layers) all weights
@@ -649,8 +641,13 @@ __global__ __launch_bounds__(256, ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 :
 #endif
     if constexpr (KD == 1) {
       // ------------------------------------------------------------------ 2-D: one run of consecutive tiles, double-buffered
-      const int t_begin = (int)((long long)blockIdx.x * p.n_tiles / gridDim.x);
-      const int t_end = (int)((long long)(blockIdx.x + 1) * p.n_tiles / gridDim.x);
+      int t_begin = (int)((long long)blockIdx.x * p.n_tiles / gridDim.x);
+      int t_end = (int)((long long)(blockIdx.x + 1) * p.n_tiles / gridDim.x);
+      if constexpr (ST != 0) {   // per-group partition (n_tiles is a multiple of the group count)
+        const int tg = p.n_tiles / (p.stat_groups > 0 ? p.stat_groups : 1);
+        t_begin = st_group * tg + (int)((long long)st_local * tg / st_bpg);
+        t_end = st_group * tg + (int)((long long)(st_local + 1) * tg / st_bpg);
+      }
       if (t_begin >= t_end) break;
       auto tile_origin = [&](int tl, int& tb, int& th0, int& tw0) {
         const int twi = tl % p.tiles_w;
@@ -707,16 +704,6 @@ __global__ __launch_bounds__(256, ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 :
 #endif
       for (int tl = t_begin; tl < t_end; ++tl) {
         const int slot = (C::RING == 1) ? 0 : ((tl - t_begin) & 1);
-        if constexpr (ST != 0) {     // the run crosses into the next BatchNorm group (block-uniform, rare): send the sums, switch tables
-          const int grp = p.stat_group_imgs > 0 ? tb / p.stat_group_imgs : 0;
-          if (grp != st_group) {
-            __syncthreads();
-            st_flush(st_group);
-            st_group = grp;
-            st_load_aux(grp);
-            __syncthreads();
-          }
-        }
         const bool row_live2 = (th0 + wave * C::WROWS) < p.Ho;
         const int cols2 = (min(p.Wo - tw0, C::TWO) + RW - 1) / RW;   // live MFMA columns
         const int mt_live2 = row_live2 ? (cols2 + 15) / 16 : 0;
@@ -894,7 +881,8 @@ __global__ __launch_bounds__(256, ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 :
 #endif
   if constexpr (ST != 0) {
     __syncthreads();
-    st_flush(st_group);
+    mdf::conv_stat_send<COUT>(st_tab, p.stat_out + (size_t)st_group * 2 * COUT, (long long)(p.stat_groups > 0 ? p.stat_groups : 1) * 2 * COUT,
+                              p.stat_slices, (unsigned)st_local);
   }
   if (KD > 1 && tid == 0) {
     const unsigned done = atomicAdd(&g_sched[2 * p.sched_slot + 1], 1u);
@@ -965,6 +953,17 @@ int launch_lds(LdsConvParams& p, hipStream_t st) {
   int grid = max_grid;
   if (const char* g = getenv("MDF_CONV_GRID")) { if (atoi(g) > 0) grid = atoi(g); }   // dev: residency experiments
   if (grid > p.n_items) grid = p.n_items;
+  if (ST) {
+    if (KD == 1) {   // groups x blocks-per-group
+      const int G = p.stat_groups > 0 ? p.stat_groups : 1;
+      int bpg = grid / G;
+      if (bpg < 1) bpg = 1;
+      grid = G * bpg;
+      p.stat_slices = mdf::conv_stat_slices(bpg, p.stat_slices);
+    } else {
+      p.stat_slices = mdf::conv_stat_slices(grid, p.stat_slices);
+    }
+  }
   if (getenv("MDF_CONV_DEBUG")) {
     int nb = -1;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_lds_kernel<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW, WG, ST>, 256, kLds);
@@ -999,7 +998,7 @@ extern "C" int mdf_debug_read_stamps(unsigned long long* out8, int reset) {
 // layers the training step runs raw with epilogue sums (forward statistics / backward reductions): both variants
 #define LDS_CASE_T(ci, cim, co, kd, k, s, mt)                                                    \
   if (Cin == ci && Cin_mem == cim && Cout == co && KD == kd && KHW == k && stride == s)          \
-    return stat ? launch_lds<ci, cim, co, kd, k, s, mt, 1, 0, 1>(p, (hipStream_t)stream) : launch_lds<ci, cim, co, kd, k, s, mt>(p, (hipStream_t)stream);
+    return !stat ? launch_lds<ci, cim, co, kd, k, s, mt>(p, (hipStream_t)stream) : (stat->mode == 1 ? launch_lds<ci, cim, co, kd, k, s, mt, 1, 0, 1>(p, (hipStream_t)stream) : launch_lds<ci, cim, co, kd, k, s, mt, 1, 0, 2>(p, (hipStream_t)stream));
 
 // stream -> scheduler slot (launches on one stream are ordered, so they can share a slot; different streams must not).
 // A slot stays bound to its stream handle until mdf_release_stream(stream) gives it back (long-lived processes that
@@ -1037,19 +1036,19 @@ extern "C" int mdf_release_stream(void* stream) {
 #define LDS_CASE_RW_T(ci, cim, co, kd, k, s, mt, rw)                                             \
   if (use_rw && Cin == ci && Cin_mem == cim && Cout == co && KD == kd && KHW == k && stride == s && !res_up) { \
     p.wpack = wpack + (size_t)kd * k * k * ci * 16;                                              \
-    return stat ? launch_lds<ci, cim, co, kd, k, s, mt, rw, 0, 1>(p, (hipStream_t)stream) : launch_lds<ci, cim, co, kd, k, s, mt, rw>(p, (hipStream_t)stream); \
+    return !stat ? launch_lds<ci, cim, co, kd, k, s, mt, rw>(p, (hipStream_t)stream) : (stat->mode == 1 ? launch_lds<ci, cim, co, kd, k, s, mt, rw, 0, 1>(p, (hipStream_t)stream) : launch_lds<ci, cim, co, kd, k, s, mt, rw, 0, 2>(p, (hipStream_t)stream)); \
   }
 
 // Winograd variants read the transform-domain weights appended behind the plain (and w-phase) packing
 #define LDS_CASE_WG(ci, co)                                                                      \
   if (use_wg && KD == 3 && KHW == 3 && stride == 1 && Cin == ci && Cin_mem == ci && Cout == co && !res_up) { \
     p.wpack = wpack + (size_t)27 * ci * (((co + 15) / 16) * 16) + (co == 8 ? (size_t)36 * ci * 16 : 0); \
-    return stat ? launch_lds<ci, ci, co, 3, 3, 1, 1, 2, 1, 1>(p, (hipStream_t)stream) : launch_lds<ci, ci, co, 3, 3, 1, 1, 2, 1>(p, (hipStream_t)stream); \
+    return !stat ? launch_lds<ci, ci, co, 3, 3, 1, 1, 2, 1>(p, (hipStream_t)stream) : (stat->mode == 1 ? launch_lds<ci, ci, co, 3, 3, 1, 1, 2, 1, 1>(p, (hipStream_t)stream) : launch_lds<ci, ci, co, 3, 3, 1, 1, 2, 1, 2>(p, (hipStream_t)stream)); \
   }
 #define LDS_CASE_WG2(ci, co)                                                                     \
   if (use_wg && KD == 1 && KHW == 3 && stride == 1 && Cin == ci && Cin_mem == ci && Cout == co && !res_up && !shuffle2) { \
     p.wpack = wpack + (size_t)9 * ci * (((co + 15) / 16) * 16);                                  \
-    return stat ? launch_lds<ci, ci, co, 1, 3, 1, 1, 2, 1, 1>(p, (hipStream_t)stream) : launch_lds<ci, ci, co, 1, 3, 1, 1, 2, 1>(p, (hipStream_t)stream); \
+    return !stat ? launch_lds<ci, ci, co, 1, 3, 1, 1, 2, 1>(p, (hipStream_t)stream) : (stat->mode == 1 ? launch_lds<ci, ci, co, 1, 3, 1, 1, 2, 1, 1>(p, (hipStream_t)stream) : launch_lds<ci, ci, co, 1, 3, 1, 1, 2, 1, 2>(p, (hipStream_t)stream)); \
   }
 
 int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
@@ -1062,7 +1061,8 @@ int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha
   p.B = B; p.D = D; p.H = H; p.W = W; p.relu = relu; p.planar_in = planar_in; p.shuffle2 = shuffle2;
   if (stat) {
     if (Cout % 4 != 0 || shuffle2 || res_up) return mdf::fail(MDF_EUNSUPPORTED, "epilogue sums: Cout %% 4 == 0, no pixel-shuffle / upsample-add");
-    p.stat_mode = stat->mode; p.stat_y = stat->y; p.stat_aux = stat->aux; p.stat_out = stat->out; p.stat_group_imgs = stat->group_imgs;
+    p.stat_mode = stat->mode; p.stat_y = stat->y; p.stat_aux = stat->aux; p.stat_out = stat->out; p.stat_slices = stat->nslices;
+    p.stat_groups = (KD == 1 && stat->group_imgs > 0) ? B / stat->group_imgs : 1;
   }
   p.sched_slot = sched_slot_of(stream);
   if (p.sched_slot < 0) return mdf::fail(MDF_EUNSUPPORTED, "conv kernels support up to %d distinct HIP streams per process", kSchedSlots);

@@ -48,15 +48,15 @@ SIGNATURES = {
     "mdf_consistency_fuse_fwd": (c_int, [c_fp, c_fp, ctypes.POINTER(c_fp), c_fp, c_int, c_int, c_int, ctypes.c_float, c_int,
                                          ctypes.c_float, ctypes.c_float, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "mdf_bn_stats_fwd": (c_int, [c_fp, c_i64, c_int, c_int, c_fp, c_fp]),
-    "mdf_bn_finalize_fwd": (c_int, [c_fp, c_fp, c_fp, ctypes.c_float, ctypes.c_float, c_i64, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "mdf_bn_finalize_fwd": (c_int, [c_fp, c_fp, c_fp, ctypes.c_float, ctypes.c_float, c_i64, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp]),
     "mdf_bn_relu_apply_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_fp]),
-    "mdf_bn_finalize_apply_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, ctypes.c_float, ctypes.c_float, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_fp]),
+    "mdf_bn_finalize_apply_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, ctypes.c_float, ctypes.c_float, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_int, c_fp]),
     "mdf_bn_relu_bwd_reduce": (c_int, [c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_fp, c_fp]),
-    "mdf_bn_relu_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_fp, c_fp, c_fp, c_fp]),
+    "mdf_bn_relu_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_fp, c_fp, c_fp, c_int, c_fp]),
     "mdf_conv3d_wgrad_workspace": (c_i64, [c_int] * 6),
     "mdf_conv3d_wgrad": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp]),
-    "mdf_conv3d_train_fwd": (c_int, [c_fp] * 4 + [c_int] * 9 + [c_fp] * 4),
-    "mdf_conv2d_train_fwd": (c_int, [c_fp] * 3 + [c_int] * 9 + [c_fp] * 3 + [c_int, c_fp]),
+    "mdf_conv3d_train_fwd": (c_int, [c_fp] * 4 + [c_int] * 9 + [c_fp] * 3 + [c_int, c_fp]),
+    "mdf_conv2d_train_fwd": (c_int, [c_fp] * 3 + [c_int] * 9 + [c_fp] * 3 + [c_int, c_int, c_fp]),
     "mdf_conv2d_wgrad_workspace": (c_i64, [c_int] * 6),
     "mdf_conv2d_wgrad": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp]),
     "mdf_pack_job_bytes": (c_i64, []),

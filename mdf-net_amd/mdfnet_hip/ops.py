@@ -367,6 +367,9 @@ def conv3d_ndhwc(x, wpack, cin, cout, stride=1, transposed=False, alpha=None, be
     return y
 
 
+STAT_SLICES = 16      # copies of the epilogue sums a conv launch spreads its blocks over (the BatchNorm kernels add them up)
+
+
 def conv3d_train(x, wpack, cin, cout, stride, transposed, res, stat_mode, stat_out, stat_y=None, stat_aux=None):
     """Training: y = [res +] conv(x) raw, with per-channel sums of y accumulated into `stat_out` [2*cout] fp64 by the conv's
     epilogue (mdf_conv3d_train_fwd).  stat_mode 1: (sum y, sum y^2); 2: y is dz of the layer whose raw output is stat_y and whose
@@ -385,10 +388,11 @@ def conv3d_train(x, wpack, cin, cout, stride, transposed, res, stat_mode, stat_o
         assert res.shape == y.shape and res.is_contiguous()
     if stat_mode == 2:
         assert stat_y.shape == y.shape and stat_y.is_contiguous() and stat_aux.numel() == 4 * cout
-    assert stat_out.numel() == 2 * cout and stat_out.dtype == torch.float64
+    nslices = stat_out.numel() // (2 * cout)
+    assert stat_out.numel() == nslices * 2 * cout and stat_out.dtype == torch.float64
     _abi("mdf_conv3d_train_fwd", (x.data_ptr(), wpack.data_ptr(), None if res is None else res.data_ptr(), y.data_ptr(), b, d, h, w, cin, cout,
                                   stride, int(transposed), stat_mode, None if stat_y is None else stat_y.data_ptr(),
-                                  None if stat_aux is None else stat_aux.data_ptr(), stat_out.data_ptr(), _stream(y)),
+                                  None if stat_aux is None else stat_aux.data_ptr(), stat_out.data_ptr(), nslices, _stream(y)),
          tag=f"{cin}->{cout} {'T' if transposed else 's%d' % stride} {d}x{h}x{w} +sums{stat_mode}",
          work={"flops": 2.0 * 27 * cin * cout * b * (d * h * w if transposed else do * ho * wo),
                "bytes": 4.0 * (x.numel() + y.numel() * (1 + (res is not None) + (stat_mode == 2))), "bound": "mfma"})
@@ -408,10 +412,11 @@ def conv2d_train(x, wpack, cin, cout, ksize, stride, planar_in, stat_mode, stat_
     y = torch.empty((b, ho, wo, cout), device=x.device, dtype=torch.float32)
     if stat_mode == 2:
         assert stat_y.shape == y.shape and stat_y.is_contiguous() and stat_aux.numel() == ngroups * 4 * cout
-    assert stat_out.numel() == ngroups * 2 * cout and stat_out.dtype == torch.float64
+    nslices = stat_out.numel() // (ngroups * 2 * cout)
+    assert stat_out.numel() == nslices * ngroups * 2 * cout and stat_out.dtype == torch.float64
     _abi("mdf_conv2d_train_fwd", (x.data_ptr(), wpack.data_ptr(), y.data_ptr(), b, h, w, cin, cout, ksize, stride, int(planar_in), stat_mode,
                                   None if stat_y is None else stat_y.data_ptr(), None if stat_aux is None else stat_aux.data_ptr(),
-                                  stat_out.data_ptr(), ngroups, _stream(y)),
+                                  stat_out.data_ptr(), nslices, ngroups, _stream(y)),
          tag=f"{cin}->{cout} k{ksize}s{stride} {h}x{w}x{b} +sums{stat_mode}",
          work={"flops": 2.0 * ksize * ksize * cin * cout * b * ho * wo, "bytes": 4.0 * (x.numel() + y.numel() * (1 + (stat_mode == 2))),
                "bound": "mfma"})

@@ -57,7 +57,7 @@ def step_pool(device):
     without that reset (a slot called on its own) it simply keeps handing out fresh zeroed slices."""
     p = _STEP_POOLS.get(device)
     if p is None:
-        p = _STEP_POOLS[device] = ZeroPool(device, 1 << 16)
+        p = _STEP_POOLS[device] = ZeroPool(device, 1 << 19)     # 4 MiB: the reductions of one step (the conv epilogues' sums in STAT_SLICES copies)
     return p
 
 
@@ -77,7 +77,7 @@ def bn_finalize(sums, bn, n, c, groups=1):
     _abi("mdf_bn_finalize_fwd", (sums.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), ctypes.c_float(bn.eps), ctypes.c_float(mom),
                                  n, c, groups, aux.data_ptr(), bn.running_mean.data_ptr() if track else None,
                                  bn.running_var.data_ptr() if track else None,
-                                 bn.num_batches_tracked.data_ptr() if track else None, _stream(aux)))
+                                 bn.num_batches_tracked.data_ptr() if track else None, sums.numel() // (groups * 2 * c), _stream(aux)))
     return aux
 
 
@@ -90,7 +90,8 @@ def bn_finalize_apply(sums, bn, y, res, n, c, groups=1):
     _abi("mdf_bn_finalize_apply_fwd", (y.data_ptr(), sums.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), ctypes.c_float(bn.eps),
                                        ctypes.c_float(mom), None if res is None else res.data_ptr(), z.data_ptr(), aux.data_ptr(),
                                        bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
-                                       bn.num_batches_tracked.data_ptr() if track else None, n, c, groups, _stream(z)),
+                                       bn.num_batches_tracked.data_ptr() if track else None, n, c, groups, sums.numel() // (groups * 2 * c),
+                                       _stream(z)),
          tag=f"finalize+apply C{c} N{n}x{groups}", work={"bytes": 4.0 * n * c * groups * (3 if res is not None else 2), "bound": "hbm"})
     return z, aux
 
@@ -114,7 +115,7 @@ def bn_relu_backward(dz, y, aux, gamma, n, c, groups=1, pool=None, red=None):
     dgamma = torch.empty(c, device=y.device, dtype=torch.float32)
     dbeta = torch.empty(c, device=y.device, dtype=torch.float32)
     _abi("mdf_bn_relu_bwd", (dz.data_ptr(), y.data_ptr(), aux.data_ptr(), red.data_ptr(), gamma.data_ptr(), n, c, groups, dy.data_ptr(),
-                             dgamma.data_ptr(), dbeta.data_ptr(), _stream(y)),
+                             dgamma.data_ptr(), dbeta.data_ptr(), red.numel() // (groups * 2 * c), _stream(y)),
          tag=f"bwd C{c} N{n}x{groups}", work={"bytes": 12.0 * n * c * groups, "bound": "hbm"})
     return dy, dgamma, dbeta
 
@@ -190,7 +191,8 @@ def prob_head_backward(prob, hypos, ddepth, dprob, x_feat, weight):
 
 
 # --------------------------------------------------------------------------- regulariser: layer tape
-FUSE_BN_SUMS = True      # dev A/B (tests): False = statistics / backward sums as separate passes (mdf_bn_stats_fwd, mdf_bn_relu_bwd_reduce)
+import os as _os
+FUSE_BN_SUMS = bool(int(_os.environ.get("MDF_FUSE_BN_SUMS", "1")))      # dev A/B (tests, scripts): False = statistics / backward sums as separate passes (mdf_bn_stats_fwd, mdf_bn_relu_bwd_reduce)
 
 
 class Tape:
@@ -211,7 +213,7 @@ class Tape:
         wp = ops_pack_fwd(conv, tr)
         c = conv.out_channels
         if FUSE_BN_SUMS:
-            sums = self.pool.take(2 * c)
+            sums = self.pool.take(ops.STAT_SLICES * 2 * c)
             y = ops.conv3d_train(x, wp, conv.in_channels, c, stride, tr, None, 1, sums)                             # raw conv + statistics
         else:
             y = ops.conv3d_ndhwc(x, wp, conv.in_channels, c, stride, tr, None, None, False, None)                   # raw conv
@@ -251,7 +253,7 @@ class Tape:
                 # every other consumer of x (skip connections: later layers) has been walked: this launch's output is the COMPLETE
                 # dz of layer `prod`
                 pl = self.layers[prod]
-                stat = (pl[5], pl[6], pool.take(2 * pl[0].out_channels))
+                stat = (pl[5], pl[6], pool.take(ops.STAT_SLICES * 2 * pl[0].out_channels))
                 red_of[prod] = stat[2]
             grads[id(x)] = conv3d_dgrad(conv, tr, dy, add_to=grads.get(id(x)), stat=stat)
         return pg
@@ -486,7 +488,7 @@ class Tape2D:
         wp = cache_of_key(conv, "fwd").get((conv.weight,), lambda: ops.pack_conv2d_weight(conv.weight))
         c = conv.out_channels
         if FUSE_BN_SUMS:
-            sums = self.pool.take(self.groups * 2 * c)
+            sums = self.pool.take(ops.STAT_SLICES * self.groups * 2 * c)
             y = ops.conv2d_train(x, wp, conv.in_channels, c, k, stride, planar_in, 1, sums, self.groups)                 # raw conv + statistics
         else:
             y = ops.conv2d_nhwc(x, wp, conv.in_channels, c, k, stride, planar_in=planar_in)                            # raw conv
@@ -516,7 +518,7 @@ class Tape2D:
                     # x feeds this layer only (the pyramid outputs t2..t4 also receive a gradient from the heads and are consumed by
                     # k5-s2 layers): the launch's output is the complete dz of layer `prod`
                     pl = self.layers[prod]
-                    stat = (pl[3], pl[4], pool.take(self.groups * 2 * pl[0].out_channels))
+                    stat = (pl[3], pl[4], pool.take(ops.STAT_SLICES * self.groups * 2 * pl[0].out_channels))
                     red_of[prod] = stat[2]
                 dx = conv2d_dgrad(conv, dy, stat=stat, groups=self.groups)
                 grads[id(x)] = dx if id(x) not in grads else grads[id(x)] + dx
