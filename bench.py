@@ -249,9 +249,9 @@ def train_family(name, tag):
         return "conv3d forward + input gradients (regulariser): conv_lds_kernel / conv3d_kernel, fp32 MFMA"
     if name in ("mdf_conv2d_fwd", "mdf_conv2d_train_fwd"):
         return "conv2d forward + input gradients (feature pyramid, refine, prob partial sums): conv_lds_kernel, fp32 MFMA"
-    if name == "mdf_conv3d_wgrad":
+    if name in ("mdf_conv3d_wgrad", "mdf_conv3d_wgrad_partial", "mdf_wgrad_sum_batch"):
         return "wgrad3d: wgrad_lds_kernel / wgrad_kernel (weight gradients, split-K fp32 MFMA)"
-    if name == "mdf_conv2d_wgrad":
+    if name in ("mdf_conv2d_wgrad", "mdf_conv2d_wgrad_partial"):
         return "wgrad2d: wgrad_lds_kernel / wgrad2d_kernel (weight gradients, split-K fp32 MFMA)"
     if name.startswith("mdf_bn_"):
         return "batchnorm (apply, backward; the sums ride in the conv epilogues): bn_*_kernel"

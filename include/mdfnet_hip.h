@@ -222,6 +222,15 @@ int mdf_conv3d_wgrad(const float* small_, const float* big, float* dw, float* wo
 int64_t mdf_conv2d_wgrad_workspace(int B, int Hs, int Ws, int A, int Bc, int ksize);
 int mdf_conv2d_wgrad(const float* small_, const float* big, float* dw, float* workspace, int B, int Hs, int Ws, int A, int Bc,
                      int ksize, int stride, int accumulate, void* stream);
+/* The same in two steps, for a whole backward pass: *_partial clears dw and leaves the partial tiles in `workspace` as
+ * *nslab_out slabs of dw.numel() floats; mdf_wgrad_sum_batch adds the slabs of MANY layers into their gradient tensors in one
+ * launch (host arrays of njobs slab / dw pointers, slab counts and element counts; jobs travel by value in the kernel
+ * arguments).  The weight gradients are not needed before the optimizer, so a training step sums them once, at the end. */
+int mdf_conv3d_wgrad_partial(const float* small_, const float* big, float* dw, float* workspace, int B, int Ds, int Hs, int Ws,
+                             int A, int Bc, int stride, int* nslab_out, void* stream);
+int mdf_conv2d_wgrad_partial(const float* small_, const float* big, float* dw, float* workspace, int B, int Hs, int Ws, int A, int Bc,
+                             int ksize, int stride, int* nslab_out, void* stream);
+int mdf_wgrad_sum_batch(const float* const* slabs, float* const* outs, const int* nslabs, const int* ns, int njobs, void* stream);
 /* (input gradients of these layers are mdf_conv3d_fwd with re-packed weights: a stride-1 conv with flipped taps and
  *  swapped channels, the transposed conv for a stride-2 conv and vice versa.) */
 

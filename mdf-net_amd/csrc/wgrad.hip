@@ -386,7 +386,71 @@ __global__ void slab_sum_kernel(const float* __restrict__ slab, int nslab, int n
   unsafeAtomicAdd(&out[i], s0 + s1);
 }
 
+// The same for MANY layers in one launch: the partial tiles of a training step's ~60 weight gradients are not needed before
+// the optimizer, so their sums wait for the end of the backward pass (59 launches of ~5 us -> 1).  Jobs travel BY VALUE in the
+// kernel arguments (the slabs and gradient tensors are fresh allocations every step: no device-side table to refresh).
+constexpr int kSumJobs = 96;
+struct SumJobs {
+  const float* slab[kSumJobs];
+  float* out[kSumJobs];
+  int nslab[kSumJobs], n[kSumJobs], gys[kSumJobs];
+  int blk0[kSumJobs + 1];       // first block of job j; block = (chunk of 256 elements) * gys + slab slice
+  int njobs;
+};
+__global__ void slab_sum_batch_kernel(const SumJobs J) {
+  __shared__ int job_s;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = J.njobs - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (J.blk0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    job_s = lo;
+  }
+  __syncthreads();
+  const int j = job_s;
+  const int local = blockIdx.x - J.blk0[j];
+  const int gys = J.gys[j], ys = local % gys, chunk = local / gys;
+  const int n = J.n[j], nslab = J.nslab[j];
+  const int i = chunk * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* slab = J.slab[j];
+  float s0 = 0.f, s1 = 0.f;
+  int k = ys;
+  for (; k + gys < nslab; k += 2 * gys) {
+    s0 += slab[(long long)k * n + i];
+    s1 += slab[(long long)(k + gys) * n + i];
+  }
+  if (k < nslab) s0 += slab[(long long)k * n + i];
+  unsafeAtomicAdd(&J.out[j][i], s0 + s1);
+}
+
 }  // namespace
+
+extern "C" int mdf_wgrad_sum_batch(const float* const* slabs, float* const* outs, const int* nslabs, const int* ns, int njobs, void* stream) {
+  MDF_REQUIRE(slabs && outs && nslabs && ns, "null pointer argument");
+  MDF_REQUIRE(njobs >= 1, "no jobs");
+  for (int first = 0; first < njobs; first += kSumJobs) {
+    SumJobs J{};
+    J.njobs = (njobs - first < kSumJobs) ? njobs - first : kSumJobs;
+    int blk = 0;
+    for (int j = 0; j < J.njobs; ++j) {
+      const int g = first + j;
+      MDF_REQUIRE(slabs[g] && outs[g] && nslabs[g] >= 1 && ns[g] >= 1, "job %d: bad slab / out / counts", g);
+      J.slab[j] = slabs[g]; J.out[j] = outs[g]; J.nslab[j] = nslabs[g]; J.n[j] = ns[g];
+      int gys = nslabs[g] / 8;                  // >= 8 slabs per partial sum
+      if (gys < 1) gys = 1;
+      if (gys > 32) gys = 32;
+      J.gys[j] = gys;
+      J.blk0[j] = blk;
+      blk += ((ns[g] + 255) / 256) * gys;
+    }
+    J.blk0[J.njobs] = blk;
+    hipLaunchKernelGGL(slab_sum_batch_kernel, dim3(blk), dim3(256), 0, (hipStream_t)stream, J);
+    if (int rc = mdf::check_launch("slab_sum_batch_kernel")) return rc;
+  }
+  return MDF_OK;
+}
 
 int mdf_wgrad_lds_dispatch(const float* small_, const float* big, float* workspace, int* gx_io, int B, int Ds, int Hs, int Ws, int A, int Bc,
                            int stride, int ksize, int is3d, float* zero_out, int zero_n, void* stream);
@@ -416,8 +480,8 @@ extern "C" int64_t mdf_conv3d_wgrad_workspace(int B, int Ds, int Hs, int Ws, int
   return g * A * Bc * 27;   // floats
 }
 
-extern "C" int mdf_conv3d_wgrad(const float* small_, const float* big, float* dw, float* workspace, int B, int Ds, int Hs, int Ws,
-                                int A, int Bc, int stride, int accumulate, void* stream) {
+static int conv3d_wgrad_impl(const float* small_, const float* big, float* dw, float* workspace, int B, int Ds, int Hs, int Ws,
+                             int A, int Bc, int stride, int accumulate, int* nslab_out, void* stream) {
   MDF_REQUIRE(small_ && big && dw && workspace, "null pointer argument");
   MDF_REQUIRE(B > 0 && Ds > 0 && Hs > 0 && Ws > 0, "bad shape");
   MDF_REQUIRE(stride == 1 || stride == 2, "stride must be 1 or 2");
@@ -454,11 +518,25 @@ extern "C" int mdf_conv3d_wgrad(const float* small_, const float* big, float* dw
     }
   }
   if (int rc = mdf::check_launch("wgrad_kernel")) return rc;
+  if (nslab_out) { *nslab_out = gx_used; return MDF_OK; }      // the caller sums the partial tiles later (mdf_wgrad_sum_batch)
   int gys = gx_used / 8;                  // >= 8 slabs per partial sum
   if (gys < 1) gys = 1;
   if (gys > 32) gys = 32;
   hipLaunchKernelGGL(slab_sum_kernel, dim3((n + 255) / 256, gys), dim3(256), 0, (hipStream_t)stream, workspace, gx_used, n, dw);
   return mdf::check_launch("slab_sum_kernel");
+}
+
+extern "C" int mdf_conv3d_wgrad(const float* small_, const float* big, float* dw, float* workspace, int B, int Ds, int Hs, int Ws,
+                                int A, int Bc, int stride, int accumulate, void* stream) {
+  return conv3d_wgrad_impl(small_, big, dw, workspace, B, Ds, Hs, Ws, A, Bc, stride, accumulate, nullptr, stream);
+}
+
+// The same without the final sum: dw is cleared, the partial tiles stay in `workspace` as *nslab_out slabs of A*Bc*27 floats
+// ([A][Bc][27] each) for a later mdf_wgrad_sum_batch (one launch for all the layers of a backward pass).
+extern "C" int mdf_conv3d_wgrad_partial(const float* small_, const float* big, float* dw, float* workspace, int B, int Ds, int Hs, int Ws,
+                                        int A, int Bc, int stride, int* nslab_out, void* stream) {
+  MDF_REQUIRE(nslab_out, "nslab_out is null");
+  return conv3d_wgrad_impl(small_, big, dw, workspace, B, Ds, Hs, Ws, A, Bc, stride, 0, nslab_out, stream);
 }
 
 static long long wgrad2d_grid(int B, int Hs, int Ws, int A, int Bc, int ksize, int* split_out, int* gy_out) {
@@ -481,8 +559,8 @@ extern "C" int64_t mdf_conv2d_wgrad_workspace(int B, int Hs, int Ws, int A, int 
   return wgrad2d_grid(B, Hs, Ws, A, Bc, ksize, nullptr, nullptr) * A * Bc * ksize * ksize;
 }
 
-extern "C" int mdf_conv2d_wgrad(const float* small_, const float* big, float* dw, float* workspace, int B, int Hs, int Ws, int A, int Bc,
-                                int ksize, int stride, int accumulate, void* stream) {
+static int conv2d_wgrad_impl(const float* small_, const float* big, float* dw, float* workspace, int B, int Hs, int Ws, int A, int Bc,
+                             int ksize, int stride, int accumulate, int* nslab_out, void* stream) {
   MDF_REQUIRE(small_ && big && dw && workspace, "null pointer argument");
   MDF_REQUIRE(B > 0 && Hs > 0 && Ws > 0, "bad shape");
   MDF_REQUIRE(stride == 1 || stride == 2, "stride must be 1 or 2");
@@ -516,9 +594,22 @@ extern "C" int mdf_conv2d_wgrad(const float* small_, const float* big, float* dw
     else hipLaunchKernelGGL(wgrad2d_kernel<5>, grid, dim3(256), 0, st, p);
     if (int rc = mdf::check_launch("wgrad2d_kernel")) return rc;
   }
+  if (nslab_out) { *nslab_out = gx_used; return MDF_OK; }
   int gys = gx_used / 8;
   if (gys < 1) gys = 1;
   if (gys > 32) gys = 32;
   hipLaunchKernelGGL(slab_sum_kernel, dim3((n + 255) / 256, gys), dim3(256), 0, st, workspace, gx_used, n, dw);
   return mdf::check_launch("slab_sum_kernel");
 }
+
+extern "C" int mdf_conv2d_wgrad(const float* small_, const float* big, float* dw, float* workspace, int B, int Hs, int Ws, int A, int Bc,
+                                int ksize, int stride, int accumulate, void* stream) {
+  return conv2d_wgrad_impl(small_, big, dw, workspace, B, Hs, Ws, A, Bc, ksize, stride, accumulate, nullptr, stream);
+}
+
+extern "C" int mdf_conv2d_wgrad_partial(const float* small_, const float* big, float* dw, float* workspace, int B, int Hs, int Ws, int A, int Bc,
+                                        int ksize, int stride, int* nslab_out, void* stream) {
+  MDF_REQUIRE(nslab_out, "nslab_out is null");
+  return conv2d_wgrad_impl(small_, big, dw, workspace, B, Hs, Ws, A, Bc, ksize, stride, 0, nslab_out, stream);
+}
+

@@ -10,6 +10,7 @@
 PyTorch is plumbing (memory, streams, the autograd graph between the slots); no op here falls back to ATen compute.
 """
 import ctypes
+import os as _os
 
 import torch
 
@@ -121,7 +122,46 @@ def bn_relu_backward(dz, y, aux, gamma, n, c, groups=1, pool=None, red=None):
 
 
 # --------------------------------------------------------------------------- conv weight / input gradients
-def conv3d_wgrad(small, big, stride, out_shape):
+# The partial tiles of a weight gradient are summed into its tensor LATER: nothing reads a weight gradient before the optimizer, so
+# the sums of all the layers of a backward pass are ONE launch (mdf_wgrad_sum_batch) issued when the autograd engine has finished
+# the pass -- still inside loss.backward(), so every .grad is complete when it returns.  Two conditions, else the sum is issued at
+# once: (a) we are inside a backward pass, (b) the parameter's .grad is None, so that AccumulateGrad merely takes the tensor over
+# (it would ADD an unfinished gradient into an existing .grad).  The pending list holds the gradient's ADDRESS, not the tensor: a
+# second reference would make AccumulateGrad clone it instead of taking it (59 copies per step, and of unfinished data).
+DEFER_WGRAD_SUMS = bool(int(_os.environ.get("MDF_WGRAD_DEFER", "1")))      # dev A/B
+_PENDING_SUMS = {}          # device index -> [stream, [(work, dw, nslab, n), ...]]
+
+
+def _flush_wgrad_sums(dev_index):
+    ent = _PENDING_SUMS.pop(dev_index, None)
+    if not ent or not ent[1]:
+        return
+    st, jobs = ent
+    k = len(jobs)
+    slabs = (ctypes.c_void_p * k)(*[j[0].data_ptr() for j in jobs])
+    outs = (ctypes.c_void_p * k)(*[j[1] for j in jobs])
+    nsl = (ctypes.c_int * k)(*[j[2] for j in jobs])
+    ns = (ctypes.c_int * k)(*[j[3] for j in jobs])
+    with torch.cuda.stream(st):
+        _abi("mdf_wgrad_sum_batch", (slabs, outs, nsl, ns, k, _stream(jobs[0][0])), tag=f"{k} weight gradients",
+             work={"bytes": 4.0 * sum(j[2] * j[3] for j in jobs), "bound": "hbm"})
+
+
+def _sum_later(work, dw, nslab, n, param):
+    dev = dw.device.index
+    defer = (DEFER_WGRAD_SUMS and param is not None and param.grad is None
+             and getattr(torch._C, "_current_graph_task_id", lambda: -1)() != -1)
+    ent = _PENDING_SUMS.get(dev)
+    if ent is None:
+        ent = _PENDING_SUMS[dev] = [torch.cuda.current_stream(dw.device), []]
+        if defer:
+            torch.autograd.Variable._execution_engine.queue_callback(lambda d=dev: _flush_wgrad_sums(d))
+    ent[1].append((work, dw.data_ptr(), nslab, n))
+    if not defer:
+        _flush_wgrad_sums(dev)
+
+
+def conv3d_wgrad(small, big, stride, out_shape, param=None):
     """dw[a][b][27] = sum_o small[o][a] * big[stride*o + tap - 1][b]; small [B,Ds,Hs,Ws,A], big [B,s*Ds,..,Bc] NDHWC."""
     _need_gpu(small, big)
     b, ds, hs, ws, a = small.shape
@@ -132,9 +172,11 @@ def conv3d_wgrad(small, big, stride, out_shape):
     work = torch.empty(n, device=small.device, dtype=torch.float32)
     dw = torch.empty(out_shape, device=small.device, dtype=torch.float32)
     assert dw.numel() == a * bc * 27
-    _abi("mdf_conv3d_wgrad", (small.data_ptr(), big.data_ptr(), dw.data_ptr(), work.data_ptr(), b, ds, hs, ws, a, bc, stride, 0,
-                              _stream(dw)), tag=f"wgrad {a}x{bc} s{stride} {ds}x{hs}x{ws}",
+    nslab = ctypes.c_int(0)
+    _abi("mdf_conv3d_wgrad_partial", (small.data_ptr(), big.data_ptr(), dw.data_ptr(), work.data_ptr(), b, ds, hs, ws, a, bc, stride,
+                                      ctypes.byref(nslab), _stream(dw)), tag=f"wgrad {a}x{bc} s{stride} {ds}x{hs}x{ws}",
          work={"flops": 2.0 * 27 * a * bc * b * ds * hs * ws, "bytes": 4.0 * (small.numel() + big.numel()), "bound": "mfma"})
+    _sum_later(work, dw, nslab.value, dw.numel(), param)
     return dw
 
 
@@ -186,12 +228,11 @@ def prob_head_backward(prob, hypos, ddepth, dprob, x_feat, weight):
     dx = torch.empty_like(x_feat)
     _abi("mdf_prob_conv_dgrad", (dlogit.data_ptr(), _f32c(weight.detach()).data_ptr(), dx.data_ptr(), b, d, h, w, c, _stream(dx)),
          tag=f"1->{c} dgrad {d}x{h}x{w}", work={"bytes": 4.0 * (dlogit.numel() + dx.numel()), "bound": "hbm"})
-    dw = conv3d_wgrad(dlogit.view(b, d, h, w, 1), x_feat, 1, tuple(weight.shape))
+    dw = conv3d_wgrad(dlogit.view(b, d, h, w, 1), x_feat, 1, tuple(weight.shape), weight if isinstance(weight, torch.nn.Parameter) else None)
     return dx, dw
 
 
 # --------------------------------------------------------------------------- regulariser: layer tape
-import os as _os
 FUSE_BN_SUMS = bool(int(_os.environ.get("MDF_FUSE_BN_SUMS", "1")))      # dev A/B (tests, scripts): False = statistics / backward sums as separate passes (mdf_bn_stats_fwd, mdf_bn_relu_bwd_reduce)
 
 
@@ -243,9 +284,9 @@ class Tape:
             n = y.numel() // c
             dy, pg[bn.weight], pg[bn.bias] = bn_relu_backward(dz, y, aux, bn.weight, n, c, pool=pool, red=red_of.pop(li, None))
             if tr:      # ConvTranspose3d: small = x (input), big = dy (twice the size)
-                pg[conv.weight] = conv3d_wgrad(x, dy, 2, tuple(conv.weight.shape))
+                pg[conv.weight] = conv3d_wgrad(x, dy, 2, tuple(conv.weight.shape), conv.weight)
             else:
-                pg[conv.weight] = conv3d_wgrad(dy, x, stride, tuple(conv.weight.shape))
+                pg[conv.weight] = conv3d_wgrad(dy, x, stride, tuple(conv.weight.shape), conv.weight)
             pending[id(x)] -= 1
             prod = self.producer.get(id(x))
             stat = None
@@ -409,7 +450,7 @@ def aggregate_train(module, features, proj, hypos):
 
 
 # --------------------------------------------------------------------------- feature-pyramid trunk (2-D) in training mode
-def conv2d_wgrad(small, big, ksize, stride, out_shape):
+def conv2d_wgrad(small, big, ksize, stride, out_shape, param=None):
     """dw[a][b][kh][kw] = sum_o small[o][a] * big[stride*o + (kh,kw) - pad][b]; small [B,Hs,Ws,A], big [B,s*Hs,s*Ws,Bc] NHWC."""
     _need_gpu(small, big)
     b, hs, ws, a = small.shape
@@ -419,9 +460,13 @@ def conv2d_wgrad(small, big, ksize, stride, out_shape):
     n = lib().mdf_conv2d_wgrad_workspace(b, hs, ws, a, bc, ksize)
     work = torch.empty(n, device=small.device, dtype=torch.float32)
     dw = torch.empty((a, bc, ksize, ksize), device=small.device, dtype=torch.float32)
-    _abi("mdf_conv2d_wgrad", (small.data_ptr(), big.data_ptr(), dw.data_ptr(), work.data_ptr(), b, hs, ws, a, bc, ksize, stride, 0,
-                              _stream(dw)), tag=f"wgrad2d {a}x{bc} k{ksize}s{stride} {hs}x{ws}x{b}",
+    nslab = ctypes.c_int(0)
+    _abi("mdf_conv2d_wgrad_partial", (small.data_ptr(), big.data_ptr(), dw.data_ptr(), work.data_ptr(), b, hs, ws, a, bc, ksize, stride,
+                                      ctypes.byref(nslab), _stream(dw)), tag=f"wgrad2d {a}x{bc} k{ksize}s{stride} {hs}x{ws}x{b}",
          work={"flops": 2.0 * ksize * ksize * a * bc * b * hs * ws, "bytes": 4.0 * (small.numel() + big.numel()), "bound": "mfma"})
+    _sum_later(work, dw, nslab.value, dw.numel(), param if tuple(out_shape) == tuple(dw.shape) else None)
+    if tuple(out_shape) != tuple(dw.shape):
+        pass     # (the image layer's weight gradient is computed over 4 padded input channels: summed at once, sliced below)
     return dw if tuple(out_shape) == tuple(dw.shape) else dw[:, :out_shape[1]].contiguous()
 
 
@@ -510,7 +555,7 @@ class Tape2D:
             n = y.numel() // c // self.groups
             dy, pg[bn.weight], pg[bn.bias] = bn_relu_backward(dz.contiguous(), y, aux, bn.weight, n, c, self.groups, pool=pool,
                                                                red=red_of.pop(li, None))
-            pg[conv.weight] = conv2d_wgrad(dy, x, conv.kernel_size[0], conv.stride[0], tuple(conv.weight.shape))
+            pg[conv.weight] = conv2d_wgrad(dy, x, conv.kernel_size[0], conv.stride[0], tuple(conv.weight.shape), conv.weight)
             if not is_input:
                 prod = self.producer.get(id(x))
                 stat = None
@@ -744,8 +789,8 @@ class FPNHeadsTrainFn(torch.autograd.Function):
         d_up3 = None
         if dy2 is not None:
             d_up2 = _conv1x1(m.out2, dy2, transposed=True)
-            pg[m.out2.weight] = conv2d_wgrad(dy2, up2, 1, 1, tuple(m.out2.weight.shape))
-            pg[m.lat2.weight] = conv2d_wgrad(d_up2, t2n, 1, 1, tuple(m.lat2.weight.shape))
+            pg[m.out2.weight] = conv2d_wgrad(dy2, up2, 1, 1, tuple(m.out2.weight.shape), m.out2.weight)
+            pg[m.lat2.weight] = conv2d_wgrad(d_up2, t2n, 1, 1, tuple(m.lat2.weight.shape), m.lat2.weight)
             pg[m.lat2.bias] = bias_grad(d_up2)
             dt2 = _conv1x1(m.lat2, d_up2, transposed=True)
             d_up3 = upsample2_backward(d_up2)
@@ -753,12 +798,12 @@ class FPNHeadsTrainFn(torch.autograd.Function):
             dt2 = torch.zeros_like(t2n)
         if dy3 is not None:
             g3 = _conv1x1(m.out3, dy3, transposed=True)
-            pg[m.out3.weight] = conv2d_wgrad(dy3, up3, 1, 1, tuple(m.out3.weight.shape))
+            pg[m.out3.weight] = conv2d_wgrad(dy3, up3, 1, 1, tuple(m.out3.weight.shape), m.out3.weight)
             d_up3 = g3 if d_up3 is None else d_up3.add_(g3)
         dt4 = _conv1x1(m.out4, dy4, transposed=True)
-        pg[m.out4.weight] = conv2d_wgrad(dy4, t4n, 1, 1, tuple(m.out4.weight.shape))
+        pg[m.out4.weight] = conv2d_wgrad(dy4, t4n, 1, 1, tuple(m.out4.weight.shape), m.out4.weight)
         if d_up3 is not None:
-            pg[m.lat3.weight] = conv2d_wgrad(d_up3, t3n, 1, 1, tuple(m.lat3.weight.shape))
+            pg[m.lat3.weight] = conv2d_wgrad(d_up3, t3n, 1, 1, tuple(m.lat3.weight.shape), m.lat3.weight)
             pg[m.lat3.bias] = bias_grad(d_up3)
             dt3 = _conv1x1(m.lat3, d_up3, transposed=True)
             upsample2_backward(d_up3, dt4)
@@ -815,7 +860,7 @@ class RefineTrainFn(torch.autograd.Function):
         pg = {}
 
         def wg(conv, small, big):
-            pg[conv.weight] = conv2d_wgrad(small, big, 3, 1, tuple(conv.weight.shape))
+            pg[conv.weight] = conv2d_wgrad(small, big, 3, 1, tuple(conv.weight.shape), conv.weight)
         do = (dout.unsqueeze(1) * ctx.span).permute(0, 2, 3, 1).contiguous()                       # [B,2h,2w,1]
         wg(m.conv2[2], do, s_)
         ds = _conv3x3(m.conv2[2], do, transposed=True)                                              # [B,2h,2w,8]

@@ -457,7 +457,7 @@ def test_training_step_on_gpu_vs_reference_golden(golden, seeded_sd):
         loss.backward()
     finally:
         train_ops._abi = orig
-    assert {"mdf_warp_aggregate_vec_train", "mdf_conv3d_wgrad", "mdf_bn_relu_bwd", "mdf_prob_conv_dgrad"} <= set(used)
+    assert {"mdf_warp_aggregate_vec_train", "mdf_conv3d_wgrad_partial", "mdf_wgrad_sum_batch", "mdf_bn_relu_bwd", "mdf_prob_conv_dgrad"} <= set(used)
     bucket.allreduce_gradients()
     for i, d in enumerate(out["depth"]):
         err = np.abs(d.detach().cpu().numpy() - g[f"depth{i}"])
