@@ -474,8 +474,11 @@ extern "C" int64_t mdf_conv3d_wgrad_workspace(int B, int Ds, int Hs, int Ws, int
   // enough blocks to fill the chip several times over (3 depth taps x gy pair groups x g), at least `split` chunks each
   long long g = wgrad_target_blocks() / (3 * gy);
   if (g > items / split) g = items / split;
-  const long long slab_cap = (8ll << 20) / ((long long)A * Bc * 27 * 4);   // <= 8 MiB of partial tiles: the slab is written and read once
-  if (g > slab_cap && slab_cap >= 16 && items / slab_cap <= 8) g = slab_cap;   // tiny volumes only: there the slab round trip dominates
+  // every block writes a partial tile set (A*Bc*27 floats: 442 KB for 64 x 64 channels) that is read again by the sum: <= 16 MiB of
+  // them per launch (r03 sweep, scripts/diag_wgrad_sweep.sh: 64 x 64 @12x18x24 45 -> 37 us, 32 x 32 @24x36x48 50 -> 44 us with
+  // half the blocks; the 16 x 16 layers are not touched by the cap)
+  const long long slab_cap = (16ll << 20) / ((long long)A * Bc * 27 * 4);
+  if (g > slab_cap && slab_cap >= 16) g = slab_cap;
   if (g < 1) g = 1;
   return g * A * Bc * 27;   // floats
 }
@@ -546,8 +549,8 @@ static long long wgrad2d_grid(int B, int Hs, int Ws, int A, int Bc, int ksize, i
   const int gy = (pairs * split + 3) / 4;
   long long g = wgrad_target_blocks() / (ksize * gy);
   if (g > items / split) g = items / split;
-  const long long slab_cap = (8ll << 20) / ((long long)A * Bc * ksize * ksize * 4);
-  if (g > slab_cap && slab_cap >= 16 && items / slab_cap <= 8) g = slab_cap;
+  const long long slab_cap = (16ll << 20) / ((long long)A * Bc * ksize * ksize * 4);
+  if (g > slab_cap && slab_cap >= 16) g = slab_cap;
   if (g < 1) g = 1;
   if (split_out) *split_out = split;
   if (gy_out) *gy_out = gy;

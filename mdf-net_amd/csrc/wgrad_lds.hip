@@ -23,7 +23,8 @@ struct WgradLdsParams {
   int B, Ds, Hs, Ws, Db, Hb, Wb, A, Bc, stride;
   int AS, BS;            // padded voxel strides in LDS (floats)
   int wtiles;            // ceil(Ws/tv)
-  long long n_tiles;     // rows * wtiles
+  int htiles;            // ceil(Hs/TH): a tile is TH consecutive rows of one (n, od) plane x tv voxels
+  long long n_tiles;     // B * Ds * htiles * wtiles
   int NB, split;
   int ntaps_total;       // 27 (3-D) or KS*KS (2-D)
   int pad;               // spatial padding of the taps inside a row (and of the z tap)
@@ -42,9 +43,15 @@ struct WgradLdsParams {
 // so ONE chain of MFMAs yields the taps t .. t + R, R = (pa-1) + (pb-1): all three kw taps for 8 x 8 (R = 2; the (1,0) block
 // duplicates (0,1) and is not stored), two steps t = 0, 2 for 8 x 16 / 16 x 8 (R = 1).  The row sum of a shifted block runs over
 // v - sa, so `small` is staged with pa-1 voxels of left halo and the tiles cover Ws + pa - 1 voxels (zero beyond the row).
-template <int KH, int KW, bool MODE3D, int R>
+//
+// TH > 1: a tile is TH consecutive output rows.  The volumes of a cfg3-sized step have SHORT rows (96, 48, 24 voxels): one row
+// is 54-108 MFMAs per wave between two barriers and a commit, and its 6 chunks split unevenly over 4 waves.  TH rows share their
+// staged `big` rows (3-D, stride 1: TH + 2 rows of a depth plane serve the 3 kernel rows of TH output rows instead of 3 TH) and
+// amortise the per-tile fixed cost TH times.
+template <int KH, int KW, bool MODE3D, int R, int TH>
 __global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) {
   constexpr int NT = (R == 0) ? KW : (R == 1 ? 2 : 1);     // MFMA chains (accumulators) per kernel row
+  constexpr int NBR = MODE3D ? TH + KH - 1 : TH;           // staged rows of `big` (3-D with TH > 1: stride 1 only, host-checked)
   constexpr int TSTEP = (R == 0) ? 1 : R + 1;              // first tap of chain ts: ts * TSTEP
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if (p.zero_out) {
@@ -55,8 +62,8 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) 
   const int s = p.stride;
   const int WB = p.tv * s + KW - 1;              // voxels of `big` per staged row
   const int hal = (R > 0) ? p.pa - 1 : 0;        // left halo of the staged `small` segment
-  float* sm_small = lds;                         // [hal + tv][AS]
-  float* sm_big = lds + (p.tv + hal) * p.AS;     // [KH][WB][BS] (+ one voxel of slack: the discarded tap t + sa + sb = 3 reads it)
+  float* sm_small = lds;                              // [TH][hal + tv][AS]
+  float* sm_big = lds + TH * (p.tv + hal) * p.AS;     // [NBR][WB][BS] (+ one voxel of slack: the discarded tap t + sa + sb = 3 reads it)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, c16 = lane & 15;
@@ -78,9 +85,9 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) 
   // Register staging of the next tile in 16-byte pieces.  A row segment is CONTIGUOUS in memory (NHWC / NDHWC), so piece i of a
   // row is `row4[first + i]`: no per-piece index arithmetic beyond a bound check; its LDS slot (voxel i >> log2(C/4), channel
   // quad i & (C/4 - 1), padded voxel stride) does not depend on the tile and is computed once.
-  constexpr int NS = 4;                          // small: tv * A/4 <= 1024 pieces (host-checked)
-  constexpr int NPR = MODE3D ? 4 : 5;            // big: pieces per staged row and thread (host checks WB * Bc/4 <= 256 * NPR)
-  float4 st_small[NS], st_big[KH][NPR];
+  constexpr int NS = (TH == 1) ? 4 : 2;                                  // small: pieces per staged row and thread ((tv + hal) * A/4 <= 256 * NS, host-checked)
+  constexpr int NPR = (TH == 1) ? (MODE3D ? 4 : 5) : (TH == 2 ? 4 : 2);  // big: likewise (WB * Bc/4 <= 256 * NPR)
+  float4 st_small[TH][NS], st_big[NBR][NPR];
   const int c4a = p.A >> 2, c4b = p.Bc >> 2;
   const int la2 = 31 - __clz(c4a), lb2 = 31 - __clz(c4b);
   const int small_pieces = (p.tv + hal) * c4a, row_pieces = WB * c4b;
@@ -90,10 +97,10 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) 
 #pragma unroll
   for (int k = 0; k < NPR; ++k) { const int i = threadIdx.x + 256 * k; lds_big[k] = (i >> lb2) * p.BS + 4 * (i & (c4b - 1)); }
 
-  auto decode = [&](long long tile, int& n, int& od, int& oh, int& ow0) {
+  auto decode = [&](long long tile, int& n, int& od, int& oh, int& ow0) {      // oh = first of the tile's TH rows
     const int wt = (int)(tile % p.wtiles);
     long long r = tile / p.wtiles;
-    oh = (int)(r % p.Hs); r /= p.Hs;
+    oh = (int)(r % p.htiles) * TH; r /= p.htiles;
     od = (int)(r % p.Ds);
     n = (int)(r / p.Ds);
     ow0 = wt * p.tv;
@@ -101,42 +108,51 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) 
   auto stage = [&](long long tile) {          // global -> registers (zero for out-of-range voxels / rows)
     int n, od, oh, ow0;
     decode(tile, n, od, oh, ow0);             // wave-uniform (scalar unit)
-    const float4* srow = reinterpret_cast<const float4*>(p.small_) + ((((long long)n * p.Ds + od) * p.Hs + oh) * p.Ws + (ow0 - hal)) * c4a;
     const int s_lo = max(0, hal - ow0) * c4a, s_hi = min(p.tv + hal, p.Ws - ow0 + hal) * c4a;     // staged slot 0 = voxel ow0 - hal
 #pragma unroll
-    for (int k = 0; k < NS; ++k) {
-      const int i = threadIdx.x + 256 * k;
-      st_small[k] = (i >= s_lo && i < s_hi) ? srow[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < TH; ++r) {
+      const bool srow_ok = (oh + r) < p.Hs;                                                      // wave-uniform
+      const float4* srow = reinterpret_cast<const float4*>(p.small_) + ((((long long)n * p.Ds + od) * p.Hs + (oh + r)) * p.Ws + (ow0 - hal)) * c4a;
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        st_small[r][k] = (srow_ok && i >= s_lo && i < s_hi) ? srow[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
     const int id = MODE3D ? od * s + z - p.pad : 0;
     const int v_first = ow0 * s - p.pad;                                  // big voxel of staged slot 0
     const int b_lo = max(0, -v_first) * c4b, b_hi = min(WB, p.Wb - v_first) * c4b;
 #pragma unroll
-    for (int kh = 0; kh < KH; ++kh) {
-      const int ih = MODE3D ? oh * s + kh - p.pad : oh * s + z - p.pad;
+    for (int br = 0; br < NBR; ++br) {
+      // 3-D: staged row br holds big row oh*s + br - pad (kernel row kh of output row r reads staged row r*s + kh; TH > 1 has s = 1)
+      // 2-D: staged row br = output row br, big row (oh + br)*s + z - pad
+      const int ih = MODE3D ? oh * s + br - p.pad : (oh + br) * s + z - p.pad;
       const bool row_ok = (!MODE3D || (id >= 0 && id < p.Db)) && ih >= 0 && ih < p.Hb;      // wave-uniform
       const long long row = MODE3D ? (((long long)n * p.Db + id) * p.Hb + ih) : ((long long)n * p.Hb + ih);
       const float4* brow = reinterpret_cast<const float4*>(p.big) + (row * p.Wb + v_first) * c4b;
 #pragma unroll
       for (int k = 0; k < NPR; ++k) {
         const int i = threadIdx.x + 256 * k;
-        st_big[kh][k] = (row_ok && i >= b_lo && i < b_hi) ? brow[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        st_big[br][k] = (row_ok && i >= b_lo && i < b_hi) ? brow[i] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
   };
   auto commit = [&]() {                        // registers -> LDS
 #pragma unroll
-    for (int k = 0; k < NS; ++k)
-      if (threadIdx.x + 256 * k < small_pieces) *reinterpret_cast<float4*>(sm_small + lds_small[k]) = st_small[k];
+    for (int r = 0; r < TH; ++r)
 #pragma unroll
-    for (int kh = 0; kh < KH; ++kh)
+      for (int k = 0; k < NS; ++k)
+        if (threadIdx.x + 256 * k < small_pieces) *reinterpret_cast<float4*>(sm_small + r * (p.tv + hal) * p.AS + lds_small[k]) = st_small[r][k];
+#pragma unroll
+    for (int br = 0; br < NBR; ++br)
 #pragma unroll
       for (int k = 0; k < NPR; ++k)
-        if (threadIdx.x + 256 * k < row_pieces) *reinterpret_cast<float4*>(sm_big + kh * WB * p.BS + lds_big[k]) = st_big[kh][k];
+        if (threadIdx.x + 256 * k < row_pieces) *reinterpret_cast<float4*>(sm_big + br * WB * p.BS + lds_big[k]) = st_big[br][k];
   };
 
   // chunks of the tile this wave multiplies: the `split` waves that share a pair take every split-th chunk
-  const int nchunk = (p.tv / 16 - part + p.split - 1) / p.split;     // tv is any multiple of 16: the first waves may take one chunk more
+  const int cpr = p.tv / 16;                                           // chunks per row
+  const int nchunk = (TH * cpr - part + p.split - 1) / p.split;        // tv is any multiple of 16: the first waves may take one chunk more
   const float* la = sm_small + (q + hal - sa) * p.AS + ac;
   const float* lb = sm_big + (q * s + sb) * p.BS + bc;
 
@@ -148,17 +164,21 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) 
     const long long next = tile + gridDim.x;
     if (next < p.n_tiles) stage(next);         // in flight during the MFMAs below
     for (int cq = 0; cq < nchunk; ++cq) {
-      const int v0 = (part + cq * p.split) * 16;   // first voxel of the chunk inside the tile
+      const int c = part + cq * p.split;
+      const int r = (TH == 1) ? 0 : c / cpr;        // row of the tile
+      const int v0 = (c - r * cpr) * 16;            // first voxel of the chunk inside the row
+      const float* lar = la + r * (p.tv + hal) * p.AS;
+      const float* lbr = lb + (MODE3D ? r * s : r) * WB * p.BS;
       float af[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) af[j] = la[(v0 + 4 * j) * p.AS];
+      for (int j = 0; j < 4; ++j) af[j] = lar[(v0 + 4 * j) * p.AS];
 #pragma unroll
       for (int kh = 0; kh < KH; ++kh) {
 #pragma unroll
         for (int ts = 0; ts < NT; ++ts) {
           float bf[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) bf[j] = lb[(kh * WB + (v0 + 4 * j) * s + ts * TSTEP) * p.BS];
+          for (int j = 0; j < 4; ++j) bf[j] = lbr[(kh * WB + (v0 + 4 * j) * s + ts * TSTEP) * p.BS];
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[kh * NT + ts] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[j], acc[kh * NT + ts], 0, 0, 0);
         }
@@ -258,50 +278,68 @@ int mdf_wgrad_lds_dispatch(const float* small_, const float* big, float* workspa
     if (Bc <= 8) p.pb = 2;
   }
   const int R = (p.pa - 1) + (p.pb - 1), hal = p.pa - 1;
-  // tile width along w: a multiple of 16*split voxels, as wide as the register staging and ~64 KiB of LDS allow (more MFMAs per
-  // barrier pair), chosen to waste the fewest voxels of the row's last tile
-  const int npr = is3d ? 4 : 5;
-  int best_tv = 0;
+  // tile = TH rows x tv voxels.  tv: a multiple of 16 voxels, as wide as the register staging and ~72 KiB of LDS allow (more MFMAs
+  // per barrier pair), chosen to waste the fewest voxels of the row's last tile; TH in {1, 2, 4} rows where rows are short
+  // (3-D with TH > 1: stride 1 only -- the staged `big` rows of neighbouring output rows must be neighbours).
+  static const int th_max = [] { const char* e = getenv("MDF_WGRAD_TH"); return (e && atoi(e) > 0) ? atoi(e) : 2; }();   // dev A/B (4 rows measured slower than 2 on every cfg3 shape: fewer, fatter tiles starve the chip)
+  int best_tv = 0, best_th = 1;
   long long best_cost = 0;
   size_t best_lds = 0;
-  // (unpacked layers: multiples of 16*split up to 256, every wave the same number of chunks -- the A/B-tuned choice; packed layers
-  // need Ws + 1 voxels covered, which would cost a whole extra tile at those widths: any multiple of 16 up to 512)
-  for (int tv = 16 * p.split; tv <= (R > 0 ? 512 : 256); tv += (R > 0 ? 16 : 16 * p.split)) {
-    const int WB = tv * stride + KW - 1;
-    if ((tv + hal) * (A / 4) > 4 * 256 || WB * (Bc / 4) > npr * 256) break;    // register staging capacity
-    const size_t lds = (size_t)((tv + hal) * p.AS + (KH * WB + 1) * p.BS) * sizeof(float);
-    if (lds > 72 * 1024) break;
-    const int rounds = (tv / 16 + p.split - 1) / p.split;                       // chunks of the busiest wave
-    const long long cost = (long long)((Ws + hal + tv - 1) / tv) * (rounds * p.split * 16 + 24);    // + ~24 voxel-times of fixed cost per tile
-    if (best_tv == 0 || cost <= best_cost) { best_tv = tv; best_cost = cost; best_lds = lds; }
+  for (int th = 1; th <= th_max; th *= 2) {
+    if (th > 1 && (!is3d || stride != 1)) break;     // (2-D: two rows share no staged data, and measured slower on every trunk shape)
+    if (th > 1 && th > Hs) break;
+    const int ns = (th == 1) ? 4 : 2, npr = (th == 1) ? (is3d ? 4 : 5) : (th == 2 ? 4 : 2);
+    const int nbr = is3d ? th + KH - 1 : th;
+    // (unpacked layers: multiples of 16*split up to 256, every wave the same number of chunks -- the A/B-tuned choice; packed layers
+    // need Ws + 1 voxels covered, which would cost a whole extra tile at those widths: any multiple of 16 up to 512)
+    const int step = (R > 0 || th > 1) ? 16 : 16 * p.split;
+    for (int tv = step; tv <= (R > 0 ? 512 : 256); tv += step) {
+      const int WB = tv * stride + KW - 1;
+      if ((tv + hal) * (A / 4) > ns * 256 || WB * (Bc / 4) > npr * 256) break;    // register staging capacity
+      const size_t lds = (size_t)(th * (tv + hal) * p.AS + (nbr * WB + 1) * p.BS) * sizeof(float);
+      if (lds > (th == 1 ? 72 : 80) * 1024) break;   // two blocks per CU
+      const int rounds = (th * (tv / 16) + p.split - 1) / p.split;                 // chunks of the busiest wave
+      const long long tiles = (long long)((Hs + th - 1) / th) * ((Ws + hal + tv - 1) / tv);
+      const long long cost = tiles * (rounds * p.split * 16 + 24);                 // + ~24 voxel-times of fixed cost per tile
+      if (best_tv == 0 || cost < best_cost || (cost == best_cost && th == best_th)) { best_tv = tv; best_th = th; best_cost = cost; best_lds = lds; }
+    }
   }
   if (best_tv == 0) return MDF_EUNSUPPORTED;
   p.tv = best_tv;
+  const int TH = best_th;
   p.wtiles = (Ws + hal + p.tv - 1) / p.tv;      // (packed rows sum over v - sa: the tiles reach pa-1 voxels past the row)
-  p.n_tiles = (long long)B * p.Ds * Hs * p.wtiles;
+  p.htiles = (Hs + TH - 1) / TH;
+  p.n_tiles = (long long)B * p.Ds * p.htiles * p.wtiles;
   size_t lds = best_lds;
   const size_t red = (size_t)2 * KH * KW * 4 * 64 * sizeof(float);
   if (lds < red) lds = red;
   if (lds > 150 * 1024) return MDF_EUNSUPPORTED;
   int gx = *gx_io;                               // in: slabs the workspace holds; out: blocks launched (= slabs written)
   if (gx > p.n_tiles) gx = (int)p.n_tiles;
+  if (gx > p.n_tiles / 2 && p.n_tiles / 2 >= 64) gx = (int)(p.n_tiles / 2);     // >= 2 tiles per block: the second tile's loads fly during the first one's MFMAs
   if (gx < 1) gx = 1;
   *gx_io = gx;
   const dim3 grid(gx, gy, is3d ? 3 : ksize);
   hipStream_t st = (hipStream_t)stream;
-#define WG_LAUNCH(KHv, KWv, M3, Rv)                                                                                        \
+#define WG_LAUNCH_TH(KHv, KWv, M3, Rv, THv)                                                                               \
   {                                                                                                                        \
     static bool attr_done[64] = {};                                                                                        \
     int dev_id = 0;                                                                                                        \
     (void)hipGetDevice(&dev_id);                                                                                           \
     if (dev_id < 0 || dev_id >= 64 || !attr_done[dev_id]) {                                                                \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lds_kernel<KHv, KWv, M3, Rv>),               \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lds_kernel<KHv, KWv, M3, Rv, THv>),          \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);                          \
       if (e != hipSuccess) return mdf::fail(MDF_EHIP, "hipFuncSetAttribute(dynamic LDS): %s", hipGetErrorString(e));       \
       if (dev_id >= 0 && dev_id < 64) attr_done[dev_id] = true;                                                            \
     }                                                                                                                      \
-    hipLaunchKernelGGL((wgrad_lds_kernel<KHv, KWv, M3, Rv>), grid, dim3(256), lds, st, p);                                  \
+    hipLaunchKernelGGL((wgrad_lds_kernel<KHv, KWv, M3, Rv, THv>), grid, dim3(256), lds, st, p);                             \
     return mdf::check_launch("wgrad_lds_kernel");                                                                          \
+  }
+#define WG_LAUNCH(KHv, KWv, M3, Rv)                  \
+  {                                                  \
+    if (TH == 4) WG_LAUNCH_TH(KHv, KWv, M3, Rv, 4)   \
+    if (TH == 2) WG_LAUNCH_TH(KHv, KWv, M3, Rv, 2)   \
+    WG_LAUNCH_TH(KHv, KWv, M3, Rv, 1)                \
   }
   if (is3d && ksize == 3 && R == 2) WG_LAUNCH(3, 3, true, 2)
   if (is3d && ksize == 3 && R == 1) WG_LAUNCH(3, 3, true, 1)
@@ -311,6 +349,7 @@ int mdf_wgrad_lds_dispatch(const float* small_, const float* big, float* workspa
   if (!is3d && ksize == 3) WG_LAUNCH(1, 3, false, 0)
   if (!is3d && ksize == 5) WG_LAUNCH(1, 5, false, 0)
   if (!is3d && ksize == 1) WG_LAUNCH(1, 1, false, 0)
+#undef WG_LAUNCH_TH
 #undef WG_LAUNCH
   return MDF_EUNSUPPORTED;
 }
