@@ -142,6 +142,11 @@ int mdf_depth_regress_fwd(const float* prob, const float* hypos, int hypos_per_p
 /* ---- a10 confidence_regress (net/unit/regress.py:9-25), n=4, pad=(1,2) ------------------------
  *   conf [B,h,w] = sum prob[idx-1..idx+2], idx = (int64) trunc(sum_d prob_d*d); idx_out int64 or NULL */
 int mdf_confidence_fwd(const float* prob, float* conf, int64_t* idx_out, int B, int D, int h, int w, void* stream);
+/* the same with the nearest x2 upsampling of net/core.py:76 folded in: conf2 [B,2h,2w]                            */
+int mdf_confidence_up2_fwd(const float* prob, float* conf2, int B, int D, int h, int w, void* stream);
+/* range mapping around the refinement net (net/unit/refine.py:29,44), per batch item b over n elements:
+ *   mode 0: y = (x - lo[b]) / span[b]      mode 1: y = lo[b] + x * span[b]     (torch's separate roundings kept)   */
+int mdf_range_affine_fwd(const float* x, const float* lo, const float* span, int mode, float* y, int B, long long n, void* stream);
 
 /* ---- a3  HyposByFit.forward (net/unit/depthhypos.py:27-76) -------------------------------------
  * mode 1 = gauss1 (depthhypos.py:169-215) with hypotheses shared by all pixels: `fit_row` is

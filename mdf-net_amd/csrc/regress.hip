@@ -44,6 +44,39 @@ __global__ void confidence_kernel(const float* __restrict__ prob, float* __restr
   }
 }
 
+// the same with the nearest-neighbour x2 upsampling of core.py:76 (F.interpolate(conf, scale_factor=2, mode="nearest")) folded in:
+// every value goes to its 2x2 output pixels
+__global__ void confidence_up2_kernel(const float* __restrict__ prob, float* __restrict__ conf2, int B, int D, int h, int w) {
+  const int hw = h * w;
+  const size_t n = (size_t)B * hw;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / hw, pix = i % hw;
+    const float* p = prob + b * D * hw + pix;
+    mdf::CascadeSum ex;
+    for (int d = 0; d < D; ++d) ex.add(p[(size_t)d * hw] * (float)d);
+    long long idx = (long long)ex.result();
+    idx = idx < 0 ? 0 : (idx > D - 1 ? D - 1 : idx);
+    float s = 0.0f;
+    for (int k = (int)idx - 1; k <= (int)idx + 2; ++k) s += (k >= 0 && k < D) ? p[(size_t)k * hw] : 0.0f;
+    const int y = (int)(pix / w), x = (int)(pix % w);
+    float* o = conf2 + (b * 2 * h + 2 * y) * (size_t)(2 * w) + 2 * x;
+    *reinterpret_cast<float2*>(o) = make_float2(s, s);
+    *reinterpret_cast<float2*>(o + 2 * w) = make_float2(s, s);
+  }
+}
+
+// Range mapping around the refinement net (refine.py:29,44), one launch each instead of two or three ATen ones; the separate
+// roundings of torch's op sequence are kept: mode 0: y = (x - lo[b]) / span[b];  mode 1: y = lo[b] + x * span[b]
+__global__ void range_affine_kernel(const float* __restrict__ x, const float* __restrict__ lo, const float* __restrict__ span, int mode,
+                                    float* __restrict__ y, int B, size_t n) {
+  const size_t total = (size_t)B * n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / n;
+    const float l = lo[b], sp = span[b], v = x[i];
+    y[i] = (mode == 0) ? __fdiv_rn(__fsub_rn(v, l), sp) : __fadd_rn(l, __fmul_rn(v, sp));
+  }
+}
+
 // mode 1: s = |-1 / sum_d row[b,d] * ln(max(p,1e-40))|          depthhypos.py:194-212
 // mode 2: s = 1 / |sum(x*y)/sum(x*x)|, x = |hyp - depth|          depthhypos.py:116-123
 __global__ void hypos_fit_kernel(int mode, const float* __restrict__ prob, const float* __restrict__ depth,
@@ -163,6 +196,20 @@ extern "C" int mdf_confidence_fwd(const float* prob, float* conf, int64_t* idx_o
   hipLaunchKernelGGL(confidence_kernel, dim3(grid_for((size_t)B * h * w)), dim3(kThreads), 0, (hipStream_t)stream, prob,
                      conf, idx_out, B, D, h * w);
   return mdf::check_launch("confidence_kernel");
+}
+
+extern "C" int mdf_confidence_up2_fwd(const float* prob, float* conf2, int B, int D, int h, int w, void* stream) {
+  MDF_REQUIRE(prob && conf2, "null pointer argument");
+  MDF_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, "bad shape");
+  hipLaunchKernelGGL(confidence_up2_kernel, dim3(grid_for((size_t)B * h * w)), dim3(kThreads), 0, (hipStream_t)stream, prob, conf2, B, D, h, w);
+  return mdf::check_launch("confidence_up2_kernel");
+}
+
+extern "C" int mdf_range_affine_fwd(const float* x, const float* lo, const float* span, int mode, float* y, int B, long long n, void* stream) {
+  MDF_REQUIRE(x && lo && span && y, "null pointer argument");
+  MDF_REQUIRE(B > 0 && n > 0 && (mode == 0 || mode == 1), "bad shape / mode");
+  hipLaunchKernelGGL(range_affine_kernel, dim3(grid_for((size_t)B * n)), dim3(kThreads), 0, (hipStream_t)stream, x, lo, span, mode, y, B, (size_t)n);
+  return mdf::check_launch("range_affine_kernel");
 }
 
 extern "C" int mdf_hypos_fit_fwd(int mode, const float* prob, const float* depth, const float* hypos,

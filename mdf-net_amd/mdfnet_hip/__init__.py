@@ -44,6 +44,8 @@ SIGNATURES = {
     "mdf_prob_from_partials_fwd": (c_int, [c_fp, c_fp, c_int, c_fp, c_fp] + [c_int] * 4 + [c_fp]),
     "mdf_depth_regress_fwd": (c_int, [c_fp, c_fp, c_int, c_fp] + [c_int] * 4 + [c_fp]),
     "mdf_confidence_fwd": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 4 + [c_fp]),
+    "mdf_confidence_up2_fwd": (c_int, [c_fp, c_fp] + [c_int] * 4 + [c_fp]),
+    "mdf_range_affine_fwd": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp, c_int, c_i64, c_fp]),
     "mdf_hypos_fit_fwd": (c_int, [c_int, c_fp, c_fp, c_fp, c_int, c_fp, c_fp] + [c_int] * 4 + [c_fp]),
     "mdf_consistency_fuse_fwd": (c_int, [c_fp, c_fp, ctypes.POINTER(c_fp), c_fp, c_int, c_int, c_int, ctypes.c_float, c_int,
                                          ctypes.c_float, ctypes.c_float, c_fp, c_fp, c_fp, c_fp, c_fp]),

@@ -265,6 +265,26 @@ def confidence(prob, return_index=False):
     return (out, idx) if return_index else out
 
 
+def confidence_up2(prob):
+    """regress.py:9-25 followed by F.interpolate(scale_factor=2, mode="nearest") (core.py:75-76) as one launch -> [B,2h,2w]."""
+    _need_gpu(prob)
+    b, d, h, w = prob.shape
+    prob = _f32c(prob)
+    out = torch.empty((b, 2 * h, 2 * w), device=prob.device, dtype=torch.float32)
+    _abi("mdf_confidence_up2_fwd", (prob.data_ptr(), out.data_ptr(), b, d, h, w, _stream(out),))
+    return out
+
+
+def range_affine(x, lo, span, mode):
+    """mode 0: (x - lo[b]) / span[b]; mode 1: lo[b] + x * span[b]   (refine.py:29,44), x [B,...]."""
+    _need_gpu(x, lo, span)
+    x = _f32c(x)
+    y = torch.empty_like(x)
+    b = x.shape[0]
+    _abi("mdf_range_affine_fwd", (x.data_ptr(), _f32c(lo).data_ptr(), _f32c(span).data_ptr(), mode, y.data_ptr(), b, x.numel() // b, _stream(y),))
+    return y
+
+
 _fit_row_cache = {}
 
 

@@ -2,7 +2,7 @@
 dicts and state_dict keys; the stage loop runs on one HIP stream with the hot operators as fused kernels."""
 import torch
 
-from mdfnet_hip import hostmirror, layers
+from mdfnet_hip import controlplane, hostmirror, layers, ops
 
 
 class CoreNet(torch.nn.Module):
@@ -20,7 +20,14 @@ class CoreNet(torch.nn.Module):
         `feature_cache` and per-view hashable `view_keys` [V] (batch 1) -- feature pyramids are then computed once per
         image and reused while it serves as a source view of other items; results are identical."""
         with layers.model_mode(self.training):
-            return self._forward(origin_imgs, extrinsics, intrinsics, depth_range, feature_cache, view_keys)
+            plan = None
+            if origin_imgs.is_cuda:
+                # one device->host hop for the control-plane tensors (cameras, range) when the caller has not registered host
+                # mirrors; then every slot's few dozen host-computed floats go up in ONE packed copy (mdfnet_hip/controlplane.py)
+                hostmirror.ensure((extrinsics, intrinsics, depth_range))
+                plan = controlplane.prepare(self, intrinsics, extrinsics, depth_range)
+            with controlplane.active(plan):
+                return self._forward(origin_imgs, extrinsics, intrinsics, depth_range, feature_cache, view_keys)
 
     def _pyramids(self, imgs, feature_cache, view_keys):
         nb, nv = imgs.shape[:2]
@@ -87,6 +94,9 @@ class CoreNet(torch.nn.Module):
         depths.append(depth)
         if self.training:
             return {"depth": depths}
-        conf = self.Confidence_regress(prob)
-        conf = torch.nn.functional.interpolate(conf.unsqueeze(1), scale_factor=2, mode="nearest").squeeze(1)
+        if getattr(self.Confidence_regress, "mdf_builtin", False) and prob.is_cuda:
+            conf = ops.confidence_up2(prob.detach())          # regress.py:9-25 + the nearest x2 of core.py:76 in one launch
+        else:
+            conf = self.Confidence_regress(prob)
+            conf = torch.nn.functional.interpolate(conf.unsqueeze(1), scale_factor=2, mode="nearest").squeeze(1)
         return {"depth": depth, "confidence": conf}

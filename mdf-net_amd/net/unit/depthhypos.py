@@ -2,7 +2,7 @@
 import torch
 import torch.nn as nn
 
-from mdfnet_hip import hostmirror, layers, ops, stockops
+from mdfnet_hip import controlplane, hostmirror, layers, ops, stockops
 
 _MODES = {"gauss1": 1, "laplace": 2}
 
@@ -16,13 +16,19 @@ class HyposByFit(nn.Module):
         self.ndepths, self.curve_calss = ndepths, curve_calss
         self.prob_thresh = torch.tensor(prob_thresh)
 
-    def _uniform(self, depth_range):
-        """depthhypos.py:31-38 on the host (B*D floats; GPU `tensor / int` rounds differently)."""
+    def uniform_host(self, depth_range):
+        """depthhypos.py:31-38 on the host (B*D floats; GPU `tensor / int` rounds differently) -> [B,D,1,1] CPU."""
         dr = hostmirror.get(depth_range)
         b = dr.shape[0]
         lo = dr[:, 0].float().reshape(b, 1)
         step = (dr[:, 1].float().reshape(b, 1) - lo) / (self.ndepths - 1)
-        host = (lo + torch.arange(0, self.ndepths).reshape(1, -1) * step).reshape(b, self.ndepths, 1, 1).contiguous()
+        return (lo + torch.arange(0, self.ndepths).reshape(1, -1) * step).reshape(b, self.ndepths, 1, 1).contiguous()
+
+    def _uniform(self, depth_range):
+        plan = controlplane.for_range(depth_range)
+        if plan is not None and plan.hyp0 is not None and plan.hyp0.shape[1] == self.ndepths:
+            return plan.hyp0                                  # uploaded with the rest of the forward's control plane
+        host = self.uniform_host(depth_range)
         if depth_range.is_cuda:
             return hostmirror.put(host.to(depth_range.device, non_blocking=True), host)
         return host
@@ -41,12 +47,16 @@ class HyposByFit(nn.Module):
             raise NotImplementedError(f"HyposByFit curve '{self.curve_calss}' is not built (gauss1, laplace are)")
         with torch.no_grad():
             row = None
+            plan = controlplane.for_range(depth_range)
             if mode == 1:
                 if depth_hypos.shape[-1] != 1:
                     raise NotImplementedError("gauss1 fit needs hypotheses shared by all pixels ([B,D,1,1])")
-                row = ops.gauss1_fit_row(hostmirror.get(depth_hypos)).to(depth.device, non_blocking=True)
+                if plan is not None and plan.fit_row is not None and depth_hypos is plan.hyp0:
+                    row = plan.fit_row
+                else:
+                    row = ops.gauss1_fit_row(hostmirror.get(depth_hypos)).to(depth.device, non_blocking=True)
             s = ops.hypos_fit(mode, prob_volume, depth, depth_hypos, row)
-            rng = hostmirror.get(depth_range).float().contiguous().to(depth.device, non_blocking=True)
+            rng = plan.rng if plan is not None else hostmirror.get(depth_range).float().contiguous().to(depth.device, non_blocking=True)
             log_thr = ops.recorded("log_thresh", mode)
             if log_thr is None:
                 log_thr = float(torch.log(self.prob_thresh))

@@ -4,7 +4,7 @@ PyTorch modules."""
 import torch
 import torch.nn as nn
 
-from mdfnet_hip import layers, ops
+from mdfnet_hip import controlplane, layers, ops
 
 from .base import Res
 
@@ -21,11 +21,16 @@ class RefineNet2(nn.Module):
     def forward(self, depth: torch.Tensor, depth_range: torch.Tensor) -> torch.Tensor:
         """depth [B,h,w] (detached), range [B,2] -> [B,2h,2w]: work in [0,1] then map back to the range."""
         b = depth.shape[0]
-        lo = depth_range[:, 0].float().view(b, 1, 1, 1)
-        span = depth_range[:, 1].float().view(b, 1, 1, 1) - lo
+        plan = controlplane.for_range(depth_range) if depth.is_cuda else None
+        if plan is not None:                                   # (lo, span) came up with the forward's control plane
+            lo, span = plan.lo.view(b, 1, 1, 1), plan.span.view(b, 1, 1, 1)
+        else:
+            lo = depth_range[:, 0].float().view(b, 1, 1, 1)
+            span = depth_range[:, 1].float().view(b, 1, 1, 1) - lo
         if layers.hip_eval(self, depth):
             with torch.no_grad():
-                x = ((depth.detach().unsqueeze(1) - lo) / span).permute(0, 2, 3, 1).contiguous()   # [B,h,w,1]
+                # (depth - lo) / span and lo + y * span: one launch each, torch's roundings (mdf_range_affine_fwd)
+                x = ops.range_affine(depth.detach(), lo.reshape(b), span.reshape(b), 0).unsqueeze(-1)   # [B,h,w,1]
                 x0 = layers.conv2d_layer(self.conv0, None, x)
                 y = x0
                 for blk in self.ress:                                                               # x + 0.1*conv(relu(conv(x)))
@@ -34,7 +39,7 @@ class RefineNet2(nn.Module):
                 y = layers.conv2d_layer(self.conv1, None, y, res=x0)                               # x0 + conv1(y)
                 y = layers.conv2d_layer(self.conv2[0], None, y, pixel_shuffle2=True)               # conv + PixelShuffle(2): [B,2h,2w,8]
                 y = layers.conv2d_layer(self.conv2[2], None, y)                                    # [B,2h,2w,1]
-                return (lo + y.permute(0, 3, 1, 2) * span).squeeze(1)
+                return ops.range_affine(y.squeeze(-1), lo.reshape(b), span.reshape(b), 1)
         if layers.hip_train(self, depth):
             from mdfnet_hip import train_ops
             return train_ops.refine_train(self, depth, lo, span)

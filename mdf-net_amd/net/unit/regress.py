@@ -18,3 +18,6 @@ def confidence_regress(prob_volume, last_confidence=None, n=4, pad=(0, 0, 0, 0, 
     if last_confidence is not None or n != 4 or tuple(pad) != (0, 0, 0, 0, 1, 2):
         raise NotImplementedError("confidence_regress: only n=4, pad=(0,0,0,0,1,2), last_confidence=None is built")
     return ops.confidence(prob_volume.detach())
+
+
+confidence_regress.mdf_builtin = True   # lets CoreNet fold the nearest x2 upsampling of core.py:76 into the same launch
