@@ -77,6 +77,7 @@ __global__ __launch_bounds__(kThreads) void warp_kernel(const Params p) {
     }
   }
   const size_t map_stride = (size_t)hw * C;
+  const unsigned lane_b = 16u * (unsigned)sub;      // byte offset of this lane's 4 channels inside a texel
 
   for (int d0 = 0; d0 < p.D; d0 += p.dchunk) {
     const int nd = min(p.dchunk, p.D - d0);
@@ -110,11 +111,14 @@ __global__ __launch_bounds__(kThreads) void warp_kernel(const Params p) {
       }
       for (int v = 0; v < p.n_src; ++v) {
         const TapEntry t = tab[(dd * p.n_src + v) * PPB + pl];
-        const float* sp = p.src[v] + (size_t)b * map_stride + 4 * sub;
-        const float4 nw = *reinterpret_cast<const float4*>(sp + t.off[0]);
-        const float4 ne = *reinterpret_cast<const float4*>(sp + t.off[1]);
-        const float4 sw = *reinterpret_cast<const float4*>(sp + t.off[2]);
-        const float4 se = *reinterpret_cast<const float4*>(sp + t.off[3]);
+        // uniform base (SGPR pair) + 32-bit byte offset per lane: `global_load_dwordx4 v, v_off, s[base]`.  With per-lane 64-bit
+        // pointers the four gathers cost 13 VALU instructions of address arithmetic per (plane, view) -- a fifth of this loop,
+        // which is VALU-bound (r03, ISA of warp_kernel<32,kVec>)
+        const char* sb = reinterpret_cast<const char*>(p.src[v] + (size_t)b * map_stride);
+        const float4 nw = *reinterpret_cast<const float4*>(sb + ((unsigned)t.off[0] * 4u + lane_b));
+        const float4 ne = *reinterpret_cast<const float4*>(sb + ((unsigned)t.off[1] * 4u + lane_b));
+        const float4 sw = *reinterpret_cast<const float4*>(sb + ((unsigned)t.off[2] * 4u + lane_b));
+        const float4 se = *reinterpret_cast<const float4*>(sb + ((unsigned)t.off[3] * 4u + lane_b));
         float val[4];
         // ATen tap order: nw*w + ne*w + sw*w + se*w, each step one fma
         val[0] = __fmaf_rn(se.x, t.wt[3], __fmaf_rn(sw.x, t.wt[2], __fmaf_rn(ne.x, t.wt[1], __fmul_rn(nw.x, t.wt[0]))));
@@ -408,7 +412,7 @@ int check_common(const void* a, const void* b, const void* c, const void* d, int
                  int w) {
   MDF_REQUIRE(a && b && c && d, "null pointer argument");
   MDF_REQUIRE(B > 0 && D > 0 && h > 1 && w > 1, "bad shape B=%d D=%d h=%d w=%d", B, D, h, w);
-  MDF_REQUIRE((long long)h * w * C < (1ll << 31), "feature map too large for 32-bit tap offsets");
+  MDF_REQUIRE((long long)h * w * C < (1ll << 30), "feature map too large for 32-bit byte offsets");
   if (fea_layout != MDF_FEA_NHWC)
     return mdf::fail(MDF_EUNSUPPORTED, "feature layout %d not supported (kernels gather NHWC taps)", fea_layout);
   if (C != 16 && C != 32 && C != 64)

@@ -82,6 +82,7 @@ __global__ __launch_bounds__(kThreads) void warp_train_kernel(const TrainParams 
   const float w2 = p.par[G], b2 = p.par[G + 1];
   const float* vpar = p.par + G + 4;
   const size_t map_stride = (size_t)hw * C;
+  const unsigned lane_b = 16u * (unsigned)sub;      // byte offset of this lane's 4 channels inside a texel
   const int nred = (PASS == kStats) ? 2 * p.n_src : 2 * p.n_src + 2;
   double total = 0.0;                 // thread k < nred: block total of reduction slot k
 
@@ -111,13 +112,13 @@ __global__ __launch_bounds__(kThreads) void warp_train_kernel(const TrainParams 
       float a3 = 0.f, a4 = 0.f;
       for (int v = 0; v < p.n_src; ++v) {
         float s1 = 0.f, s2 = 0.f;
-        const float* sp = p.src[v] + (size_t)b * map_stride + 4 * sub;
+        const char* sb = reinterpret_cast<const char*>(p.src[v] + (size_t)b * map_stride);     // uniform base + 32-bit lane offsets
         for (int dd = 0; dd < nd; ++dd) {
           const TapEntry t = tab[(dd * p.n_src + v) * PPB + pl];
-          const float4 nw = *reinterpret_cast<const float4*>(sp + t.off[0]);
-          const float4 ne = *reinterpret_cast<const float4*>(sp + t.off[1]);
-          const float4 sw = *reinterpret_cast<const float4*>(sp + t.off[2]);
-          const float4 se = *reinterpret_cast<const float4*>(sp + t.off[3]);
+          const float4 nw = *reinterpret_cast<const float4*>(sb + ((unsigned)t.off[0] * 4u + lane_b));
+          const float4 ne = *reinterpret_cast<const float4*>(sb + ((unsigned)t.off[1] * 4u + lane_b));
+          const float4 sw = *reinterpret_cast<const float4*>(sb + ((unsigned)t.off[2] * 4u + lane_b));
+          const float4 se = *reinterpret_cast<const float4*>(sb + ((unsigned)t.off[3] * 4u + lane_b));
           const float v0 = __fmaf_rn(se.x, t.wt[3], __fmaf_rn(sw.x, t.wt[2], __fmaf_rn(ne.x, t.wt[1], __fmul_rn(nw.x, t.wt[0]))));
           const float v1 = __fmaf_rn(se.y, t.wt[3], __fmaf_rn(sw.y, t.wt[2], __fmaf_rn(ne.y, t.wt[1], __fmul_rn(nw.y, t.wt[0]))));
           const float v2 = __fmaf_rn(se.z, t.wt[3], __fmaf_rn(sw.z, t.wt[2], __fmaf_rn(ne.z, t.wt[1], __fmul_rn(nw.z, t.wt[0]))));
@@ -164,11 +165,11 @@ __global__ __launch_bounds__(kThreads) void warp_train_kernel(const TrainParams 
         float acc0 = 0.f, acc1 = 0.f, wsum = 0.f;
         for (int v = 0; v < p.n_src; ++v) {
           const TapEntry t = tab[(dd * p.n_src + v) * PPB + pl];
-          const float* sp = p.src[v] + (size_t)b * map_stride + 4 * sub;
-          const float4 nw = *reinterpret_cast<const float4*>(sp + t.off[0]);
-          const float4 ne = *reinterpret_cast<const float4*>(sp + t.off[1]);
-          const float4 sw = *reinterpret_cast<const float4*>(sp + t.off[2]);
-          const float4 se = *reinterpret_cast<const float4*>(sp + t.off[3]);
+          const char* sb = reinterpret_cast<const char*>(p.src[v] + (size_t)b * map_stride);
+          const float4 nw = *reinterpret_cast<const float4*>(sb + ((unsigned)t.off[0] * 4u + lane_b));
+          const float4 ne = *reinterpret_cast<const float4*>(sb + ((unsigned)t.off[1] * 4u + lane_b));
+          const float4 sw = *reinterpret_cast<const float4*>(sb + ((unsigned)t.off[2] * 4u + lane_b));
+          const float4 se = *reinterpret_cast<const float4*>(sb + ((unsigned)t.off[3] * 4u + lane_b));
           const float v0 = __fmaf_rn(se.x, t.wt[3], __fmaf_rn(sw.x, t.wt[2], __fmaf_rn(ne.x, t.wt[1], __fmul_rn(nw.x, t.wt[0]))));
           const float v1 = __fmaf_rn(se.y, t.wt[3], __fmaf_rn(sw.y, t.wt[2], __fmaf_rn(ne.y, t.wt[1], __fmul_rn(nw.y, t.wt[0]))));
           const float v2 = __fmaf_rn(se.z, t.wt[3], __fmaf_rn(sw.z, t.wt[2], __fmaf_rn(ne.z, t.wt[1], __fmul_rn(nw.z, t.wt[0]))));
@@ -318,7 +319,8 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
         for (int i = tid; i < ww * wh * G; i += kThreads) win[i] = 0.0f;
         __syncthreads();
       }
-      const float* sp = p.src[v] + (size_t)b * map_stride + 4 * sub;
+      const char* sb = reinterpret_cast<const char*>(p.src[v] + (size_t)b * map_stride);     // uniform base + 32-bit lane offsets
+      const unsigned lane_b = 16u * (unsigned)sub;
       float* gp = p.dsrc[v] + (size_t)b * gmap_stride + 2 * sub;
       const float4* ax = p.aux + (size_t)v * nvox;
       const float s1n = (float)p.red_in[2 * v] * inv_n, s2n = (float)p.red_in[2 * v + 1] * inv_n;
@@ -375,10 +377,10 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
       for (int dd = 0; dd < nd; ++dd) {
         const TapXY t = tab[(dd * nv + (v - v_lo)) * PPB + pl];
         const int o0 = (t.ya * W + t.xa), o1 = (t.ya * W + t.xb), o2 = (t.yb * W + t.xa), o3 = (t.yb * W + t.xb);
-        const float4 nw = *reinterpret_cast<const float4*>(sp + (size_t)o0 * C);
-        const float4 ne = *reinterpret_cast<const float4*>(sp + (size_t)o1 * C);
-        const float4 sw = *reinterpret_cast<const float4*>(sp + (size_t)o2 * C);
-        const float4 se = *reinterpret_cast<const float4*>(sp + (size_t)o3 * C);
+        const float4 nw = *reinterpret_cast<const float4*>(sb + ((unsigned)o0 * (4u * C) + lane_b));
+        const float4 ne = *reinterpret_cast<const float4*>(sb + ((unsigned)o1 * (4u * C) + lane_b));
+        const float4 sw = *reinterpret_cast<const float4*>(sb + ((unsigned)o2 * (4u * C) + lane_b));
+        const float4 se = *reinterpret_cast<const float4*>(sb + ((unsigned)o3 * (4u * C) + lane_b));
         const size_t vox = ((size_t)b * p.D + d0 + dd) * hw + pix;
         const float4 sc = ax[vox];                                   // (w_v, dz_v, t_v, -)
         const float2 dc = *reinterpret_cast<const float2*>(p.dcost + vox * G + 2 * sub);
@@ -576,7 +578,7 @@ extern "C" int mdf_warp_aggregate_vec_train(int pass, const float* ref_fea, cons
   MDF_REQUIRE(ref_fea && src_feas && proj && hypos && par, "null pointer argument");
   MDF_REQUIRE(pass >= 0 && pass <= 3, "pass=%d not in 0..3", pass);
   MDF_REQUIRE(B > 0 && D > 0 && h > 1 && w > 1, "bad shape B=%d D=%d h=%d w=%d", B, D, h, w);
-  MDF_REQUIRE((long long)h * w * C < (1ll << 31), "feature map too large for 32-bit tap offsets");
+  MDF_REQUIRE((long long)h * w * C < (1ll << 30), "feature map too large for 32-bit byte offsets");
   MDF_REQUIRE(n_src >= 1 && n_src <= MDF_MAX_SRC_VIEWS, "n_src=%d out of range [1,%d]", n_src, MDF_MAX_SRC_VIEWS);
   if (G * 2 != C) return mdf::fail(MDF_EUNSUPPORTED, "only C/G == 2 is built (C=%d, G=%d)", C, G);
   TrainParams p{};

@@ -13,7 +13,7 @@ import threading
 import torch  # noqa: F401
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libmdfnet_hip.so")
+LIB_PATH = os.environ.get("MDF_HIP_LIB") or os.path.join(_PKG, "libmdfnet_hip.so")     # (MDF_HIP_LIB: dev A/B of two builds on one box)
 ABI_VERSION = 1
 
 _lib = None

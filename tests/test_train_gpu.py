@@ -401,9 +401,11 @@ def test_regulariser_training_forward_backward(stage, weights, seeded_sd):
     prob, depth = reg(cd, hyp.to(DEV))
     depth.backward(dd.to(DEV))
 
-    def closer(name, hip, cpu32, f64):
+    def closer(name, hip, cpu32, f64, floor=4e-5):
         e_hip, e_cpu = _l2(hip, f64), _l2(cpu32, f64)
-        assert e_hip <= max(factor * e_cpu, 4e-5), (name, e_hip, e_cpu)      # (floor: fp32 partial sums meet in a run-dependent order)
+        # (floor: fp32 partial sums meet in a run-dependent order; the CPU's own error differs from host to host -- 0.6-1.6e-5 on the
+        # parameter gradients of this test across the boxes of one pool)
+        assert e_hip <= max(factor * e_cpu, floor), (name, e_hip, e_cpu)
         return e_hip, e_cpu
     e = closer("prob", prob, prob_ref, prob64)
     e2 = closer("depth", depth, depth_ref, depth64)
@@ -414,7 +416,7 @@ def test_regulariser_training_forward_backward(stage, weights, seeded_sd):
     worst = 0.0
     for (k, pa), (_, pr), (_, p64) in zip(reg.named_parameters(), reg_ref.named_parameters(), reg64.named_parameters()):
         assert pa.grad is not None, k
-        eh, _ = closer(k, pa.grad, pr.grad, p64.grad)
+        eh, _ = closer(k, pa.grad, pr.grad, p64.grad, floor=1e-4)     # sums over 1e5..1e6 voxels
         worst = max(worst, eh)
         assert _l2(pa.grad, pr.grad) < 2e-2, (k, _l2(pa.grad, pr.grad))
     for (k, ba), (_, br) in zip(reg.named_buffers(), reg_ref.named_buffers()):
