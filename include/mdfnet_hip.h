@@ -135,6 +135,13 @@ int mdf_prob_softmax_regress_fwd(const float* x, const float* w, const float* hy
 int mdf_prob_from_partials_fwd(const float* partials, const float* hypos, int hypos_per_pixel, float* prob, float* depth,
                                int B, int D, int h, int wd, void* stream);
 
+/* ---- the two full-resolution layers of the feature pyramid as one launch (net/unit/backbone.py:28, eval):
+ *      y = relu(bn2(conv2(relu(bn1(conv1(x))))))   Conv2d(3,8,k3,p1) -> Conv2d(8,8,k3,p1), BatchNorm folded to (alpha, beta);
+ *      x planar [N,3,H,W] as the loader hands it over, y NHWC [N,H,W,8]; w1pack / w2pack = mdf_conv_pack_weights of the two
+ *      layers.  Bit-identical to the two mdf_conv2d_fwd launches; the 8-channel map between them never reaches memory.    */
+int mdf_conv2d_pair_fwd(const float* x, const float* w1pack, const float* alpha1, const float* beta1, const float* w2pack,
+                        const float* alpha2, const float* beta2, float* y, int N, int H, int W, void* stream);
+
 /* ---- a9  depth_regression (net/unit/regress.py:5-7): depth = sum_d prob*hypos ----------------- */
 int mdf_depth_regress_fwd(const float* prob, const float* hypos, int hypos_per_pixel, float* depth, int B, int D,
                           int h, int w, void* stream);

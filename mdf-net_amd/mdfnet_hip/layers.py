@@ -109,6 +109,28 @@ def use_hip(mod, *tensors):
     return True
 
 
+def _folded(conv, bn):
+    """(packed weights, alpha, beta) of a Conv2d [+ BatchNorm2d eval], cached per layer."""
+    tensors = [conv.weight, conv.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
+
+    def build():
+        wp = ops.pack_conv2d_weight(conv.weight)
+        if bn is not None:
+            alpha, beta = ops.fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+            if conv.bias is not None:
+                beta = (beta + conv.bias.float() * alpha).contiguous()
+            return wp, alpha, beta
+        return wp, None, (None if conv.bias is None else conv.bias.detach().float().contiguous())
+    return cache_of(conv).get(tensors, build)
+
+
+def conv2d_pair(block0, block1, x):
+    """The feature pyramid's two full-resolution ConvBNReLU layers (3 -> 8 -> 8, k3) on the planar images as one launch."""
+    w1, a1, b1 = _folded(block0.conv, block0.bn)
+    w2, a2, b2 = _folded(block1.conv, block1.bn)
+    return ops.conv2d_pair_planar(x, w1, a1, b1, w2, a2, b2)
+
+
 def conv2d_layer(conv, bn, x, relu=False, res=None, res_scale=1.0, res_up=None, planar_in=False, pixel_shuffle2=False):
     """Conv2d [+ BatchNorm2d eval] [+ ReLU] [+ residual / upsample-add] [+ PixelShuffle(2)] as one kernel.  x, res: [B,H,W,C] NHWC."""
     assert not (pixel_shuffle2 and (bn is not None or conv.bias is not None))

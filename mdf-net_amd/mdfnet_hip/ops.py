@@ -522,6 +522,19 @@ def conv2d_nhwc(x, wpack, cin, cout, ksize, stride=1, alpha=None, beta=None, rel
     return y
 
 
+def conv2d_pair_planar(x, w1pack, a1, b1, w2pack, a2, b2):
+    """relu(bn(conv3x3(relu(bn(conv3x3(x)))))) for the 3 -> 8 -> 8 head of the feature pyramid as ONE launch (conv_pair.hip).
+    x planar [N,3,H,W] -> [N,H,W,8] NHWC.  Bit-identical to two conv2d_nhwc launches."""
+    _need_gpu(x, w1pack, w2pack)
+    n, c, h, w = x.shape
+    assert c == 3 and x.is_contiguous() and x.dtype == torch.float32
+    y = torch.empty((n, h, w, 8), device=x.device, dtype=torch.float32)
+    _abi("mdf_conv2d_pair_fwd", (x.data_ptr(), w1pack.data_ptr(), a1.data_ptr(), b1.data_ptr(), w2pack.data_ptr(), a2.data_ptr(), b2.data_ptr(),
+                                 y.data_ptr(), n, h, w, _stream(y)), tag=f"3->8->8 k3 {h}x{w}x{n}",
+         work={"flops": 2.0 * 9 * (3 * 8 + 8 * 8) * n * h * w, "bytes": 4.0 * (x.numel() + y.numel()), "bound": "mfma"})
+    return y
+
+
 def shuffle2_rows(weight):
     """Reorder the output channels of a Conv2d that feeds nn.PixelShuffle(2): torch channel oc*4 + sub -> row sub*Cq + oc
     (Cq = Cout/4), the order mdf_conv2d_fwd(pixel_shuffle2=1) expects."""

@@ -12,6 +12,10 @@ from mdfnet_hip import layers, ops
 from .base import ConvBNReLU
 
 
+import os as _os
+_PAIR = bool(int(_os.environ.get("MDF_CONV_PAIR", "1")))      # dev A/B: 0 = the two full-resolution layers as separate launches
+
+
 def _stage(cin, cout, first_k, first_s):
     return nn.Sequential(ConvBNReLU(cin, cout, first_k, first_s, (first_k - 1) // 2), ConvBNReLU(cout, cout, 3, 1, 1),
                          ConvBNReLU(cout, cout, 3, 1, 1))
@@ -64,9 +68,14 @@ class FPN_4Scales(nn.Module):
             return ops.conv2d_nhwc(t, wp, cin, cout, 1, 1, None, bias, False, None, 1.0, res_up)
         with torch.no_grad():
             # the first conv reads the planar NCHW images as they arrive (no 113 MB layout copy at cfg2)
-            first = self.conv01[0]
-            t1 = layers.conv2d_layer(first.conv, first.bn, x.float().contiguous(), relu=True, planar_in=True)
-            t2 = seq(self.conv12, seq(self.conv01[1:], t1))
+            first, second = self.conv01[0], self.conv01[1]
+            xin = x.float().contiguous()
+            if _PAIR and first.conv.in_channels == 3 and first.conv.out_channels == 8 and second.conv.out_channels == 8 and len(self.conv01) == 2:
+                t1 = layers.conv2d_pair(first, second, xin)        # both full-resolution layers in one launch (conv_pair.hip)
+            else:
+                t1 = layers.conv2d_layer(first.conv, first.bn, xin, relu=True, planar_in=True)
+                t1 = seq(self.conv01[1:], t1)
+            t2 = seq(self.conv12, t1)
             t3 = seq(self.conv23, t2)
             t4 = seq(self.conv34, t3)
             hd = self._composed_heads()

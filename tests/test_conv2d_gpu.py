@@ -80,3 +80,28 @@ def test_conv_with_fused_pixel_shuffle(shape):
     y = ops.conv2d_nhwc(ops.to_nhwc(x.to(DEV)), wp, 8, 32, 3, 1, pixel_shuffle2=True)
     assert y.shape == (b, 2 * h, 2 * w, 8)
     np.testing.assert_allclose(y.permute(0, 3, 1, 2).cpu().numpy(), exp.numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [(1, 8, 16), (2, 13, 37), (1, 40, 136), (3, 9, 131), (2, 64, 62), (1, 65, 63), (1, 200, 190), (5, 296, 400)])
+def test_conv2d_pair_equals_the_two_layers(shape):
+    """mdf_conv2d_pair_fwd (conv_pair.hip: FPN_4Scales.conv01, both full-resolution ConvBNReLU layers in one launch with rolling
+    LDS windows) against the two single-layer launches it replaces: same packed weights, tap order and epilogue arithmetic, so
+    BIT-IDENTICAL -- strips narrower / wider than 62 pixels, row counts around the 8-row steps and the segment boundaries -- and
+    against torch on the CPU."""
+    n, h, w = shape
+    rng = np.random.RandomState(n * 100 + h + w)
+    x = T(rng.rand(n, 3, h, w).astype(np.float32))
+    w1 = T((rng.randn(8, 3, 3, 3) / np.sqrt(27)).astype(np.float32))
+    w2 = T((rng.randn(8, 8, 3, 3) / np.sqrt(72)).astype(np.float32))
+    a1, b1 = T(rng.uniform(0.5, 1.5, 8).astype(np.float32)), T(rng.uniform(-0.3, 0.3, 8).astype(np.float32))
+    a2, b2 = T(rng.uniform(0.5, 1.5, 8).astype(np.float32)), T(rng.uniform(-0.3, 0.3, 8).astype(np.float32))
+    xd = x.to(DEV)
+    wp1, wp2 = ops.pack_conv2d_weight(w1.to(DEV)), ops.pack_conv2d_weight(w2.to(DEV))
+    t1 = ops.conv2d_nhwc(xd, wp1, 3, 8, 3, 1, a1.to(DEV), b1.to(DEV), True, planar_in=True)
+    two = ops.conv2d_nhwc(t1, wp2, 8, 8, 3, 1, a2.to(DEV), b2.to(DEV), True)
+    one = ops.conv2d_pair_planar(xd, wp1, a1.to(DEV), b1.to(DEV), wp2, a2.to(DEV), b2.to(DEV))
+    assert one.shape == two.shape == (n, h, w, 8)
+    assert torch.equal(one, two), float((one - two).abs().max())
+    m1 = F.relu(F.conv2d(x, w1, None, 1, 1) * a1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1))
+    exp = F.relu(F.conv2d(m1, w2, None, 1, 1) * a2.view(1, -1, 1, 1) + b2.view(1, -1, 1, 1))
+    np.testing.assert_allclose(ops.from_nhwc(one).cpu().numpy(), exp.numpy(), rtol=1e-4, atol=2e-5)
