@@ -16,13 +16,13 @@ def family(name):
         return "aggregate_train_passes"
     if "bn_" in name:
         return "batchnorm_train"
-    if "conv_lds_kernel" in name or "conv3d_kernel" in name:
+    if "conv_lds_kernel" in name or "conv3d_kernel" in name or "conv_pair_kernel" in name:
         return "mfma_conv"
     if "warp_kernel" in name:
         return "warp_aggregate"
     if "prob_head" in name or "prob_from_partials" in name:
         return "prob_head"
-    if any(k in name for k in ("regress_kernel", "confidence_kernel", "hypos_")):
+    if any(k in name for k in ("regress_kernel", "confidence_kernel", "confidence_up2", "range_affine", "hypos_")):
         return "heads"
     return None
 
