@@ -1088,6 +1088,7 @@ int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha
   LDS_CASE(4, 3, 8, 1, 3, 1, 4) LDS_CASE(8, 8, 8, 1, 3, 1, 4) LDS_CASE(16, 16, 16, 1, 3, 1, 4) LDS_CASE(32, 32, 32, 1, 3, 1, 2)
   LDS_CASE(64, 64, 64, 1, 3, 1, 1)
   LDS_CASE_T(8, 8, 16, 1, 5, 2, 2) LDS_CASE_T(16, 16, 32, 1, 5, 2, 2) LDS_CASE_T(32, 32, 64, 1, 5, 2, 1)
+  LDS_CASE(16, 16, 32, 1, 1, 1, 4)      // composed FPN heads, training backward (B3^T)
   LDS_CASE(16, 16, 64, 1, 1, 1, 4) LDS_CASE(32, 32, 64, 1, 1, 1, 2) LDS_CASE(64, 64, 16, 1, 1, 1, 1) LDS_CASE(64, 64, 32, 1, 1, 1, 1)
   LDS_CASE(64, 64, 64, 1, 1, 1, 1)
   LDS_CASE(32, 32, 32, 1, 1, 1, 2) LDS_CASE(32, 32, 16, 1, 1, 1, 2) LDS_CASE(16, 16, 16, 1, 1, 1, 4)   // composed FPN heads

@@ -336,7 +336,7 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
         bool plain = false;
         const unsigned m = lm;
         lm = 0;
-        if (use_win && !p.all_atomic) {
+        if (use_win && !(p.all_atomic & 1)) {
           const int slot = min(max((ya - ymin) * ww + (xa - xmin), 0), kWinFloats / 8 - 1);   // the window texel of (xa,ya): no false sharing
           my_claim[slot] = (unsigned char)pl;
           plain = (my_claim[slot] == (unsigned char)pl) && (xb == xa + 1) && (yb == ya + 1);
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
           const float* wrow = win + wy * ww * G;
           for (int j = tid; j < ww * G; j += kThreads) {
             const float val = wrow[j];
-            if (val != 0.0f) unsafeAtomicAdd(grow + j, val);
+            if (val != 0.0f && !(p.all_atomic & 2)) unsafeAtomicAdd(grow + j, val);     // (bit 1: timing experiment, flush dropped)
           }
         }
         __syncthreads();
@@ -485,7 +485,7 @@ int launch_bwd(TrainParams& p, int C, hipStream_t st) {
   const int nz = depth_slices(p, dch);
   p.dchunk = dch;
   const char* dbg = getenv("MDF_WARP_BWD_ATOMIC");      // read per call: tests flip it inside one process
-  p.all_atomic = (dbg && atoi(dbg) > 0) ? 1 : 0;
+  p.all_atomic = (dbg && atoi(dbg) > 0) ? atoi(dbg) : 0;     // bit 0: all-atomic window updates; bit 1: timing experiment without the flush
   const size_t lds = (size_t)dch * p.n_src * ppb * sizeof(TapXY) + (size_t)kWinFloats * sizeof(float);
   dim3 grid(p.nblk_x, p.B, nz), block(kThreads);
   switch (C) {

@@ -813,9 +813,108 @@ class FPNHeadsTrainFn(torch.autograd.Function):
         return (None, ops.from_nhwc(dt2), ops.from_nhwc(dt3), ops.from_nhwc(dt4)) + tuple(pg.get(p) for p in ctx.params)
 
 
+COMPOSE_FPN_HEADS = bool(int(_os.environ.get("MDF_FPN_COMPOSED", "1")))      # dev A/B: 0 = the 64-channel 1/2- and 1/4-resolution tensors are formed
+
+
+class FPNHeadsComposedFn(torch.autograd.Function):
+    """The same heads through their ALGEBRA (backbone.py:59-63; the eval path's `_composed_heads`, now with a backward): 1x1 convs and
+    bilinear upsampling are linear and commute, so
+        y4 = O4 t4,   y3 = up(O3 t4) + (O3 L3) t3 + O3 b3,   y2 = up(up(O2 t4) + (O2 L3) t3 + O2 b3) + (O2 L2) t2 + O2 b2
+    and the 64-channel 1/4- and 1/2-resolution tensors (141 MB at cfg3, written and re-read five times per step forward and
+    backward) are never formed: every large-resolution operand has 16 or 32 channels.  Backward: the gradients of the composed
+    matrices (A2 = O2 L2, B3 = O2 L3, A3 = O3 L3) and bias vectors are 1x1 weight gradients / column sums over small-channel
+    maps, mapped back onto the seven parameters by a dozen tiny matrix products."""
+
+    @staticmethod
+    def forward(ctx, m, t2, t3, t4, *params):
+        t2n, t3n, t4n = ops.to_nhwc(t2.detach()), ops.to_nhwc(t3.detach()), ops.to_nhwc(t4.detach())
+        with torch.no_grad():
+            O2, O3, O4 = (c.weight.detach().reshape(c.out_channels, c.in_channels) for c in (m.out2, m.out3, m.out4))
+            L2, L3 = (c.weight.detach().reshape(c.out_channels, c.in_channels) for c in (m.lat2, m.lat3))
+            b2, b3 = m.lat2.bias.detach(), m.lat3.bias.detach()
+            A2, B3, A3 = O2 @ L2, O2 @ L3, O3 @ L3                    # [16,16], [16,32], [32,32]
+            e2, e3, f3 = O2 @ b2, O2 @ b3, O3 @ b3
+
+            def pk(w):
+                return ops.pack_conv2d_weight(w.reshape(w.shape[0], w.shape[1], 1, 1).contiguous())
+
+            def c1(x, w, bias=None, res_up=None, res=None):
+                return ops.conv2d_nhwc(x, pk(w), w.shape[1], w.shape[0], 1, 1, None, bias, False, res, 1.0, res_up)
+            y4 = c1(t4n, O4)
+            y3 = c1(t3n, A3, f3.contiguous(), res_up=c1(t4n, O3))
+            c3 = c1(t3n, B3, e3.contiguous(), res_up=c1(t4n, O2))
+            y2 = c1(t2n, A2, e2.contiguous(), res_up=c3)
+        ctx.m, ctx.saved, ctx.params = m, (t2n, t3n, t4n, O2, O3, O4, L2, L3, b2, b3, A2, B3, A3), params
+        ctx.set_materialize_grads(False)
+        return ops.from_nhwc(y4), ops.from_nhwc(y3), ops.from_nhwc(y2)
+
+    @staticmethod
+    def backward(ctx, g4, g3, g2):
+        m = ctx.m
+        t2n, t3n, t4n, O2, O3, O4, L2, L3, b2, b3, A2, B3, A3 = ctx.saved
+        pool = step_pool(t2n.device)
+
+        def pk(w):
+            return ops.pack_conv2d_weight(w.reshape(w.shape[0], w.shape[1], 1, 1).contiguous())
+
+        def c1t(g, w, res=None):       # w^T g: [.., out] -> [.., in]
+            wt = w.t()
+            return ops.conv2d_nhwc(g, pk(wt), wt.shape[1], wt.shape[0], 1, 1, None, None, False, res, 1.0, None)
+
+        def colsum(g):
+            c = g.shape[-1]
+            return bn_stats(g, g.numel() // c, c, pool=pool)[:c].float()
+
+        def wg(g, t):                  # sum_pixels g (x) t -> [g channels, t channels]
+            return conv2d_wgrad(g, t, 1, 1, (g.shape[-1], t.shape[-1], 1, 1)).reshape(g.shape[-1], t.shape[-1])
+        dO2 = torch.zeros_like(O2); dO3 = torch.zeros_like(O3)
+        dL2 = torch.zeros_like(L2); dL3 = torch.zeros_like(L3)
+        db2 = torch.zeros_like(b2); db3 = torch.zeros_like(b3)
+        dt4 = None
+        if g2 is not None:
+            g2n = ops.to_nhwc(g2)
+            dA2, s2 = wg(g2n, t2n), colsum(g2n)
+            dt2 = c1t(g2n, A2)
+            gc3 = upsample2_backward(g2n)                          # [.,h/4,w/4,16]
+            dB3, sc3 = wg(gc3, t3n), colsum(gc3)
+            dt3 = c1t(gc3, B3)
+            gc4 = upsample2_backward(gc3)                          # [.,h/8,w/8,16]
+            dO2 += wg(gc4, t4n) + dA2 @ L2.t() + torch.outer(s2, b2) + dB3 @ L3.t() + torch.outer(sc3, b3)
+            dL2 += O2.t() @ dA2
+            dL3 += O2.t() @ dB3
+            db2 += O2.t() @ s2
+            db3 += O2.t() @ sc3
+            dt4 = c1t(gc4, O2)
+        else:
+            dt2, dt3 = torch.zeros_like(t2n), None
+        if g3 is not None:
+            g3n = ops.to_nhwc(g3)
+            dA3, s3 = wg(g3n, t3n), colsum(g3n)
+            dt3 = c1t(g3n, A3, res=dt3)
+            ga4 = upsample2_backward(g3n)                          # [.,h/8,w/8,32]
+            dO3 += wg(ga4, t4n) + dA3 @ L3.t() + torch.outer(s3, b3)
+            dL3 += O3.t() @ dA3
+            db3 += O3.t() @ s3
+            dt4 = c1t(ga4, O3, res=dt4)
+        if dt3 is None:
+            dt3 = torch.zeros_like(t3n)
+        pg = {m.out2.weight: dO2.reshape(m.out2.weight.shape), m.out3.weight: dO3.reshape(m.out3.weight.shape),
+              m.lat2.weight: dL2.reshape(m.lat2.weight.shape), m.lat3.weight: dL3.reshape(m.lat3.weight.shape),
+              m.lat2.bias: db2, m.lat3.bias: db3}
+        if g4 is not None:
+            g4n = ops.to_nhwc(g4)
+            pg[m.out4.weight] = wg(g4n, t4n).reshape(m.out4.weight.shape)
+            dt4 = c1t(g4n, O4, res=dt4)
+        if dt4 is None:
+            dt4 = torch.zeros_like(t4n)
+        ctx.saved = None
+        return (None, ops.from_nhwc(dt2), ops.from_nhwc(dt3), ops.from_nhwc(dt4)) + tuple(pg.get(p) for p in ctx.params)
+
+
 def fpn_heads_train(module, t2, t3, t4):
     params = tuple(p for mod in (module.lat2, module.lat3, module.out2, module.out3, module.out4) for p in mod.parameters())
-    return FPNHeadsTrainFn.apply(module, t2, t3, t4, *params)
+    fn = FPNHeadsComposedFn if (COMPOSE_FPN_HEADS and module.lat2.bias is not None and module.out2.bias is None) else FPNHeadsTrainFn
+    return fn.apply(module, t2, t3, t4, *params)
 
 
 # --------------------------------------------------------------------------- refinement net in training mode
