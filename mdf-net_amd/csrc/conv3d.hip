@@ -471,6 +471,29 @@ __device__ __forceinline__ float pack_wino_elem(const WSrc& src, int i, int Cin,
   return v;
 }
 
+// Depth-pair Winograd weights (conv_lds.hip, Cfg::RD = 2; 3-D layers with 8 output channels): GEMM row m = r*8 + c is channel c of
+// output plane d + r (r = 0, 1), so the 16 MFMA rows are all live; input plane j = 0..3 of a step (depth d - 1 + j) meets tap kd = j - r.
+// [j][chunk][ab][lane = q*16+m][s], cin = chunk*CK + KPL*q + s.
+__device__ __forceinline__ float pack_wd_elem(const WSrc& src, int i, int Cin) {
+  const int KPL = (Cin >= 16) ? 4 : 2, CK = 4 * KPL, NCH = Cin / CK;
+  const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+  int r = i;
+  const int s = r % KPL; r /= KPL;
+  const int m = r % 16; r /= 16;
+  const int qq = r % 4; r /= 4;
+  const int ab = r % 16; r /= 16;
+  const int ch = r % NCH; r /= NCH;
+  const int j = r;
+  const int a = ab >> 2, b = ab & 3;
+  const int cout = m & 7, kd = j - (m >> 3), cin = ch * CK + KPL * qq + s;
+  float v = 0.f;
+  if (kd >= 0 && kd < 3) {
+    for (int y = 0; y < 3; ++y)
+      for (int x = 0; x < 3; ++x) v += G[a][y] * G[b][x] * src.at(cout, cin, kd * 9 + y * 3 + x);
+  }
+  return v;
+}
+
 // ConvTranspose3d weights [Cin][Cout][3][3][3] -> wpack[tap' = (kd*3+kh)*2+ow][chunk][nt][q][n][s] with GEMM row
 // r = nt*16+n = pw*Cout + cout and kernel tap kw(pw, ow): (0,0)->1, (1,0)->2, (1,1)->0, (0,1)-> structurally zero.
 __device__ __forceinline__ int pack_tr_total(int Cin, int Cout) {
@@ -497,21 +520,23 @@ __device__ __forceinline__ float pack_tr_elem(const WSrc& src, int i, int Cin, i
 __host__ __device__ inline int rw_of(int Cout) { return Cout == 8 ? 2 : (Cout == 4 ? 4 : 0); }   // w-phase factor of a stride-1 k3 layer (0 = none)
 __host__ __device__ inline bool wino_built(int Cin, int Cout) { return ((Cout == 16 || Cout == 32) && (Cin == 16 || Cin == 32) && Cout <= Cin) || (Cin == 16 && Cout == 8); }   // 3-D
 __host__ __device__ inline bool wino2d_built(int Cin, int Cout) { return (Cin == 16 && Cout == 16) || (Cin == 32 && Cout == 32) || (Cin == 64 && Cout == 64); }
+__host__ __device__ inline bool wd_built(int Cin, int Cout) { return Cout == 8 && (Cin == 8 || Cin == 16); }   // 3-D, depth-pair Winograd
 __host__ __device__ inline int padded_cin(int c) { return c <= 4 ? 4 : c; }
 
 // One complete packed weight set, as mdf_conv3d_pack_weights / mdf_conv_pack_weights lay it out: the plain fragments, then
-// (Cout 8 / 4, 3x3 taps) the w-phase fragments, then (where a Winograd kernel exists) the transform-domain fragments; or the
-// transposed-conv fragments alone.
+// (Cout 8 / 4, 3x3 taps) the w-phase fragments, then (where a Winograd kernel exists) the transform-domain fragments, then (3-D,
+// Cout 8) the depth-pair Winograd fragments; or the transposed-conv fragments alone.
 struct PackJob {
   const float* src;
   float* dst;
   int mode, transposed, is3d, Cin_mem, Cout, ntaps, a0, a1;
   int blk0, nblk;
 };
-__host__ __device__ inline void pack_segments(int is3d, int transposed, int Cin_mem, int Cout, int ntaps, long long* plain, long long* rw, long long* wino) {
+__host__ __device__ inline void pack_segments(int is3d, int transposed, int Cin_mem, int Cout, int ntaps, long long* plain, long long* rw, long long* wino,
+                                              long long* wd) {
   const int Cin = padded_cin(Cin_mem);
   const int KPL = (Cin >= 16) ? 4 : (Cin == 8 ? 2 : 1), NCH = Cin / (4 * KPL);
-  *rw = 0; *wino = 0;
+  *rw = 0; *wino = 0; *wd = 0;
   if (transposed) {
     const int K2 = (Cin >= 16) ? 4 : 2;
     *plain = 18ll * (Cin / (4 * K2)) * ((2 * Cout + 15) / 16) * 64 * K2;
@@ -521,25 +546,27 @@ __host__ __device__ inline void pack_segments(int is3d, int transposed, int Cin_
   const bool k3 = is3d ? (ntaps == 27) : (ntaps == 9);
   if (k3 && rw_of(Cout)) *rw = (long long)(is3d ? 9 : 3) * (3 + rw_of(Cout) - 1) * NCH * 64 * KPL;
   if (k3 && (is3d ? wino_built(Cin_mem, Cout) : wino2d_built(Cin_mem, Cout))) *wino = (long long)(is3d ? 3 : 1) * (Cin / 16) * 16 * ((Cout + 15) / 16) * 64 * 4;
+  if (k3 && is3d && wd_built(Cin_mem, Cout)) *wd = 4ll * NCH * 16 * 64 * KPL;
 }
 __device__ __forceinline__ void pack_job_elem(const PackJob& j, long long i) {
   const int Cin = padded_cin(j.Cin_mem);
   WSrc src{j.src, j.transposed ? kSrcSwap : j.mode, j.Cout, j.Cin_mem, j.ntaps, j.a0, j.a1};
-  long long plain, rw, wino;
-  pack_segments(j.is3d, j.transposed, j.Cin_mem, j.Cout, j.ntaps, &plain, &rw, &wino);
-  if (i >= plain + rw + wino) return;
+  long long plain, rw, wino, wd;
+  pack_segments(j.is3d, j.transposed, j.Cin_mem, j.Cout, j.ntaps, &plain, &rw, &wino, &wd);
+  if (i >= plain + rw + wino + wd) return;
   float v;
   if (j.transposed) v = pack_tr_elem(src, (int)i, Cin, j.Cout);
   else if (i < plain) v = pack_plain_elem(src, (int)i, Cin, j.Cin_mem, j.Cout);
   else if (i < plain + rw) v = pack_rw_elem(src, (int)(i - plain), Cin, j.Cin_mem, j.Cout, 3, rw_of(j.Cout));
-  else v = pack_wino_elem(src, (int)(i - plain - rw), Cin, j.Cout, j.is3d ? 3 : 1);
+  else if (i < plain + rw + wino) v = pack_wino_elem(src, (int)(i - plain - rw), Cin, j.Cout, j.is3d ? 3 : 1);
+  else v = pack_wd_elem(src, (int)(i - plain - rw - wino), Cin);
   j.dst[i] = v;
 }
 
 __global__ void pack_weights_kernel(PackJob j) {
-  long long plain, rw, wino;
-  pack_segments(j.is3d, j.transposed, j.Cin_mem, j.Cout, j.ntaps, &plain, &rw, &wino);
-  const long long total = plain + rw + wino;
+  long long plain, rw, wino, wd;
+  pack_segments(j.is3d, j.transposed, j.Cin_mem, j.Cout, j.ntaps, &plain, &rw, &wino, &wd);
+  const long long total = plain + rw + wino + wd;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) pack_job_elem(j, i);
 }
 
@@ -583,9 +610,9 @@ int launch_conv_mt(ConvParams& p, hipStream_t st) {
 }  // namespace
 
 static int64_t pack_total(int is3d, int transposed, int Cin_mem, int Cout, int ntaps) {
-  long long plain, rw, wino;
-  pack_segments(is3d, transposed, Cin_mem, Cout, ntaps, &plain, &rw, &wino);
-  return plain + rw + wino;
+  long long plain, rw, wino, wd;
+  pack_segments(is3d, transposed, Cin_mem, Cout, ntaps, &plain, &rw, &wino, &wd);
+  return plain + rw + wino + wd;
 }
 
 extern "C" int64_t mdf_conv3d_packed_size(int Cin, int Cout) {

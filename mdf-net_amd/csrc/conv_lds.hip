@@ -9,8 +9,8 @@
 // conflict-free ds_read_b128/b64 with immediate offsets (all taps unrolled), the next plane is prefetched into
 // registers while the current one is multiplied, and only the small packed-weight fragments stream through L1.
 //
-// LDS image of one plane:  [cin / KPL][S] vectors of KPL floats, S = plane-tile voxels rounded to 16 (mod 32), so
-// the lane groups of ds_read_b128 (and the two halves of ds_read_b64) fall on disjoint banks for every tap shift.
+// LDS image of one plane:  [cin / KPL][S] vectors of KPL floats, S = plane-tile voxels rounded up to the residue (round_s)
+// that puts the lane groups of ds_read_b128 (and the two halves of ds_read_b64) on disjoint banks for every tap shift.
 // GEMM orientation and weight packing are those of conv3d.hip:  D[cout][voxel] = W[cout][k] * X[k][voxel].
 #include <cstdlib>
 #include <mutex>
@@ -111,9 +111,19 @@ __device__ unsigned long long g_stamps[8];   // sched, prologue, compute, refill
 #define STAMP() __builtin_readcyclecounter()
 #endif
 
-constexpr int round_s(int n) {  // smallest s >= n with s % 32 == 16
-  int s = (n + 15) / 16 * 16;
-  return (s % 32 == 16) ? s : s + 16;
+// Plane stride S (in KPL-float vectors per cin group) such that the B-fragment reads of a lane group fall on distinct banks
+// (MI355X LDS: ds_read_b128 is served in 16-lane groups that mix two q rows, ds_read_b64/b32 in 32-lane halves = two q rows;
+// bank = dword address mod 64, mod 32 for b32 and all stores).  A lane reads vector q*S + n16*SW (+ tap shift):
+//  SW = 1: the two q rows of a group must land 16 vectors (KPL 4) / 32 dwords (KPL 2) apart: S % 32 == 16;
+//  SW = 2 (stride-2 layers, w-phase RW = 2, Winograd): each row covers the even slots, so the neighbour row needs an odd S --
+//          with S % 32 == 16 every one of those reads was a 2-way conflict.  Among the odd residues the fill stores (cin group
+//          fastest over 4 groups: vectors g*S + v) are conflict-free for S % 8 == 3 (KPL 4) and nearly so for S % 16 == 5 (KPL 2);
+//  SW = 4 (w-phase RW = 4): a row alone is 2-way (n16 and n16 + 4/8 share banks); S % 4 == 2 keeps the two rows apart (was 4-way).
+constexpr int round_up_mod(int n, int m, int r) { return n + ((r - n % m) + m) % m; }
+constexpr int round_s(int n, int kpl, int sw) {
+  if (sw == 1) return round_up_mod(n, 32, 16);
+  if (sw % 4 == 0) return round_up_mod(n, 4, 2);
+  return kpl == 4 ? round_up_mod(n, 8, 3) : (kpl == 2 ? round_up_mod(n, 16, 5) : round_up_mod(n, 2, 1));
 }
 
 #ifndef EARLY2_MAX_REGS
@@ -131,17 +141,26 @@ constexpr int round_s(int n) {  // smallest s >= n with s % 32 == 16
 // 16 x 3 instead of 9 x 4 x 3 MFMAs per 4 outputs: 2.25x fewer.  fp32 Winograd F(2,3) costs no accuracy here: single-layer
 // error vs fp64 1.1e-6 (direct 1.8e-6), end-to-end depth deviation 3.9-4.4e-4 mm = the floor of any fp32 re-ordering
 // (scripts/study_winograd.py).  Geometry: RW = 2 supplies the w bookkeeping (4-wide patch, stride 2); a wave owns 2 rows.
+//
+// WG = 2 (depth-pair Winograd, 3-D layers with 8 output channels): with Cout = 8 the Winograd GEMMs would fill only half of
+// the 16 MFMA rows.  Here a step produces TWO output planes d, d+1: GEMM row r*8 + c is channel c of plane d + r, and the four
+// input planes d-1 .. d+2 of the step (ring of 4) each meet tap kd = j - r (zero rows where that is outside 0..2).  Every
+// transformed patch feeds both planes: 4 x 16 instead of 2 x 3 x 16 MFMA groups (and 4 instead of 6 patch transforms) per
+// pair of planes, 2.25x fewer MFMAs than the w-phase form.  Also for Cin = 8 (two k-steps per group).
 template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT, int RW = 1, int WG = 0>
 struct Cfg {
-  static_assert(RW == 1 || WG == 1 || (SHW == 1 && COUT * RW <= 16 && COUT % 4 == 0), "w-phase form: stride 1, RW*Cout <= 16, Cout % 4 == 0");
-  static_assert(WG == 0 || ((KD == 3 || KD == 1) && KHW == 3 && SHW == 1 && RW == 2 && MT == 1 && CIN % 16 == 0 && COUT % 4 == 0), "Winograd form: 3x3(x3) stride 1, RW = 2, MT = 1");
-  static constexpr bool WINO = (WG == 1);
+  static_assert(RW == 1 || WG != 0 || (SHW == 1 && COUT * RW <= 16 && COUT % 4 == 0), "w-phase form: stride 1, RW*Cout <= 16, Cout % 4 == 0");
+  static_assert(WG == 0 || ((KD == 3 || KD == 1) && KHW == 3 && SHW == 1 && RW == 2 && MT == 1 && CIN % (WG == 2 ? 8 : 16) == 0 && COUT % 4 == 0), "Winograd form: 3x3(x3) stride 1, RW = 2, MT = 1");
+  static_assert(WG != 2 || (KD == 3 && COUT == 8), "depth-pair Winograd form: 3-D, Cout = 8");
+  static constexpr bool WINO = (WG != 0);
+  static constexpr int RD = (WG == 2) ? 2 : 1;    // output planes per depth step
+  static constexpr int NPL = KD + RD - 1;         // input planes a depth step reads
   static constexpr int NTP = ((COUT + 15) / 16 > 2) ? 2 : (COUT + 15) / 16;   // Winograd: n-tiles per pass over K (16 accumulators each)
   static constexpr int CIN_ = CIN;
   static constexpr int RWF = RW;
   static constexpr int KW = KHW + RW - 1;       // taps along w
   static constexpr int SW = SHW * RW;           // input step along w between neighbouring MFMA columns
-  static constexpr int ROWS = WINO ? COUT : COUT * RW;        // GEMM rows
+  static constexpr int ROWS = WINO ? COUT * RD : COUT * RW;   // GEMM rows
   static constexpr int KPL = (CIN >= 16) ? 4 : (CIN == 8 ? 2 : 1);
   static constexpr int CK = 4 * KPL;
   static constexpr int NCH = CIN / CK;
@@ -152,13 +171,13 @@ struct Cfg {
   static constexpr int TWO = TW * RW;
   static constexpr int PAD = (KHW - 1) / 2, PD = (KD - 1) / 2;
   static constexpr int PH = WINO ? TH + 2 : (TH - 1) * SHW + KHW, PW = (TW - 1) * SW + KW;
-  static constexpr int S = round_s(PH * PW);
+  static constexpr int S = round_s(PH * PW, KPL, SW);
   static constexpr int PLANE = CIN * S;  // floats
   static constexpr int NFILL = (NG * PH * PW + 255) / 256;
   // 3-D: rolling window of KD planes; 2-D: double-buffered tiles -- except the 64-channel Winograd form, whose 10x34 tile
   // (87 KB) fits once: single buffer, the next tile's loads wait in registers during the (long) compute
-  static constexpr int RING = (KD > 1) ? KD : ((WINO && CIN >= 64) ? 1 : 2);
-  static constexpr int NSTEP = WINO ? KD * 16 * NCH : KD * KHW * KW * NCH;   // MFMA pipeline steps per output row-tile (tap x cin chunk)
+  static constexpr int RING = (KD > 1) ? NPL : ((WINO && CIN >= 64) ? 1 : 2);
+  static constexpr int NSTEP = WINO ? NPL * 16 * NCH : KD * KHW * KW * NCH;   // MFMA pipeline steps per output row-tile (tap x cin chunk)
   // small layers keep ALL their weight fragments in registers for the whole kernel (<= 40 VGPRs; beyond that occupancy drops and it is a loss, measured) instead of re-fetching
   // them from L1 for every tile: with 8-16 MFMAs per step there is nothing to hide that round trip behind
   static constexpr bool WREG = (KD == 1) && !WINO && (NSTEP * NT * KPL <= 40);
@@ -365,8 +384,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 // Weight fragments (pack_weights_wino_kernel, conv3d.hip): [kd][chunk][ab = a*4+b][nt][lane][4], U = G g_kd G^T.
 template <typename C, int COUT, int NKD, int ST = 0>
 __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __amdgpu_buffer_rsrc_t wres, int wvoff, const LdsConvParams& p,
-                                          int b, int d, int h, int w0, int q, int n16, const float (&wfirst)[2][C::NT][C::KPL]) {
-  constexpr int NCH = C::NCH, NTALL = C::NT, NT = C::NTP, S = C::S, PW = C::PW;
+                                          int b, int d, int d_lim, int h, int w0, int q, int n16, const float (&wfirst)[2][C::NT][C::KPL]) {
+  constexpr int NCH = C::NCH, NTALL = C::NT, NT = C::NTP, S = C::S, PW = C::PW, KPL = C::KPL;
+  typedef typename VecT<KPL>::type vec_t;
   extern __shared__ __attribute__((aligned(16))) float lds_base_[];
   const float* epi_tab = lds_base_ + C::EPI_OFF;
   // Cout > 32: two passes over K with 2 n-tiles each (16 accumulators x 4 n-tiles would be the whole register file); the
@@ -383,10 +403,10 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __a
 #define MDF_WG_AHEAD 2
 #endif
   constexpr int AHEAD = MDF_WG_AHEAD, NA = AHEAD + 1;
-  float af[NA][NT][4];
+  float af[NA][NT][KPL];
   auto load_a = [&](int i, int buf) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) buf_load_to<4>(wres, wvoff, (i * NTALL + pass * NT + nt) * (64 * 4 * 4), af[buf][nt]);
+    for (int nt = 0; nt < NT; ++nt) buf_load_to<KPL>(wres, wvoff, (i * NTALL + pass * NT + nt) * (64 * KPL * 4), af[buf][nt]);
   };
 #pragma unroll
   for (int i = 0; i < AHEAD; ++i) {
@@ -394,7 +414,7 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __a
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) af[i % NA][nt][k] = wfirst[i][nt][k];
+        for (int k = 0; k < KPL; ++k) af[i % NA][nt][k] = wfirst[i][nt][k];
     } else {
       load_a(i, i % NA);
     }
@@ -404,23 +424,27 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __a
   // wave's LDS latency and transform arithmetic: software-pipeline them into the MFMA loop instead -- while group g
   // multiplies, the patch of group g+1 is read (one element per ab step), its row pass runs column by column as the reads
   // land, and its column pass runs row by row right before the four MFMA steps that need that row.
-  constexpr bool PIPE = (C::CIN_ >= 32 && C::CIN_ < 64);   // (64 channels: two passes x 128 accumulator registers leave no room for the second patch buffer)
-  auto read_elem = [&](f32x2_t (&v)[16][2], int kd, int ch, int e) {     // e = j*4 + i: column-major so a column completes every 4 reads
+  // (64 channels: two passes x 128 accumulator registers leave no room for the second patch buffer; the 16-channel depth-pair
+  // form keeps a ring of 4 planes = 94 KB, one block per CU as well)
+  constexpr bool PIPE = (C::CIN_ >= 32 && C::CIN_ < 64) || (C::RD == 2 && C::CIN_ >= 16);
+  constexpr int NV = KPL / 2;                                              // packed pairs of input channels per lane
+  auto read_elem = [&](f32x2_t (&v)[16][NV], int kd, int ch, int e) {     // e = j*4 + i: column-major so a column completes every 4 reads
     const int i = e & 3, j = e >> 2;
-    const float4 t = *reinterpret_cast<const float4*>(planes[kd] + ((ch * 4) * S + i * PW + j) * 4);
-    v[i * 4 + j][0] = (f32x2_t){t.x, t.y};
-    v[i * 4 + j][1] = (f32x2_t){t.z, t.w};
-  };
-  auto row_pass = [&](f32x2_t (&v)[16][2], int j) {                      // B^T d : over the patch rows, column j
+    float t[KPL];
+    vec_to<KPL>(*reinterpret_cast<const vec_t*>(planes[kd] + ((ch * 4) * S + i * PW + j) * KPL), t);
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < NV; ++c) v[i * 4 + j][c] = (f32x2_t){t[2 * c], t[2 * c + 1]};
+  };
+  auto row_pass = [&](f32x2_t (&v)[16][NV], int j) {                      // B^T d : over the patch rows, column j
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
       const f32x2_t d0 = v[j][c], d1 = v[4 + j][c], d2 = v[8 + j][c], d3 = v[12 + j][c];
       v[j][c] = d0 - d2; v[4 + j][c] = d1 + d2; v[8 + j][c] = d2 - d1; v[12 + j][c] = d1 - d3;
     }
   };
-  auto col_pass = [&](f32x2_t (&v)[16][2], int a) {                      // (B^T d) B : over the columns, row a
+  auto col_pass = [&](f32x2_t (&v)[16][NV], int a) {                      // (B^T d) B : over the columns, row a
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < NV; ++c) {
       const f32x2_t e0 = v[a * 4][c], e1 = v[a * 4 + 1][c], e2 = v[a * 4 + 2][c], e3 = v[a * 4 + 3][c];
       v[a * 4][c] = e0 - e2; v[a * 4 + 1][c] = e1 + e2; v[a * 4 + 2][c] = e2 - e1; v[a * 4 + 3][c] = e1 - e3;
     }
@@ -429,7 +453,7 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __a
     static_for<0, NG_>([&](auto gc) {
       constexpr int g = decltype(gc)::value;
       constexpr int kd = g / NCH, ch = g % NCH;
-      f32x2_t v[16][2];
+      f32x2_t v[16][NV];
 #pragma unroll
       for (int e = 0; e < 16; ++e) read_elem(v, kd, ch, e);
 #pragma unroll
@@ -442,7 +466,7 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __a
         if constexpr (i + AHEAD < NF) load_a(i + AHEAD, (i + AHEAD) % NA);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int sidx = 0; sidx < 4; ++sidx)
+        for (int sidx = 0; sidx < KPL; ++sidx)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
             acc[ab][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i % NA][nt][sidx], v[ab][sidx >> 1][sidx & 1], acc[ab][nt], 0, 0, 0);
@@ -450,7 +474,7 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __a
       });
     });
   } else {
-    f32x2_t vbuf[2][16][2];
+    f32x2_t vbuf[2][16][NV];
 #pragma unroll
     for (int e = 0; e < 16; ++e) read_elem(vbuf[0], 0, 0, e);
 #pragma unroll
@@ -469,7 +493,7 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __a
         if constexpr ((ab & 3) == 0) col_pass(vbuf[cur], ab >> 2);                    // row a of the current group, just in time
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int sidx = 0; sidx < 4; ++sidx)
+        for (int sidx = 0; sidx < KPL; ++sidx)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
             acc[ab][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i % NA][nt][sidx], vbuf[cur][ab][sidx >> 1][sidx & 1], acc[ab][nt], 0, 0, 0);
@@ -481,8 +505,10 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __a
   // epilogue: Y = A^T M A per cout, A^T = [1 1 1 0; 0 1 -1 -1]; outputs (h + pr, w0 + 2*n16 + r)
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int c0 = (pass * NT + nt) * 16 + 4 * q;
-    if (c0 >= COUT) continue;
+    const int row0 = (pass * NT + nt) * 16 + 4 * q;
+    const int c0 = (C::RD == 2) ? (row0 & 7) : row0;        // depth-pair form: rows 8..15 are the 8 channels of plane d + 1
+    const int dd = (C::RD == 2) ? d + (row0 >> 3) : d;
+    if (C::RD == 1 && c0 >= COUT) continue;
     float y[2][2][4];
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {          // two couts per packed instruction
@@ -511,8 +537,8 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __a
     float ps[4] = {0.f, 0.f, 0.f, 0.f}, pq[4] = {0.f, 0.f, 0.f, 0.f};   // ST: this lane's sums over its 2x2 outputs
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
-      if (h + pr >= p.Ho) continue;
-      const size_t row_vox = (((size_t)b * p.D + d) * p.Ho + (h + pr)) * p.Wo;
+      if (h + pr >= p.Ho || dd >= d_lim) continue;
+      const size_t row_vox = (((size_t)b * p.D + dd) * p.Ho + (h + pr)) * p.Wo;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int ow = w0 + 2 * n16 + r;
@@ -546,8 +572,11 @@ template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT, int 
 // (Winograd form with 32+ input channels: its 141 KB of LDS allow one block per CU anyway, so it may use the whole register file)
 // (ST variants of the HBM-bound 2-D layers: the ~10 registers of the epilogue sums would cost an occupancy step -- 16->16 Winograd 26 -> 43 us,
 // 3->8 40 -> 58 us by rocprof -- so those keep their residency and spill a few registers instead)
-__global__ __launch_bounds__(256, (ST != 0 && KD == 1 && WG == 1 && CIN == 16) ? 3 : (ST != 0 && KD == 1 && CIN == 4) ? 4 :
-                                  ((COUT <= 16 && !(WG == 1 && CIN >= 32)) ? 2 : 1)) void conv_lds_kernel(const LdsConvParams p) {
+#ifndef MDF_WD8_BLOCKS
+#define MDF_WD8_BLOCKS 2
+#endif
+__global__ __launch_bounds__(256, (WG == 2 && CIN == 8) ? MDF_WD8_BLOCKS : (ST != 0 && KD == 1 && WG == 1 && CIN == 16) ? 3 : (ST != 0 && KD == 1 && CIN == 4) ? 4 :
+                                  ((COUT <= 16 && !(WG == 1 && CIN >= 32) && !(WG == 2 && CIN >= 16)) ? 2 : 1)) void conv_lds_kernel(const LdsConvParams p) {
   typedef Cfg<CIN, CIN_MEM, COUT, KD, KHW, SHW, MT, RW, WG> C;
   constexpr int KPL = C::KPL, NG = C::NG, S = C::S, PW = C::PW, PH = C::PH;
   typedef typename VecT<KPL>::type vec_t;
@@ -726,7 +755,7 @@ __global__ __launch_bounds__(256, (ST != 0 && KD == 1 && WG == 1 && CIN == 16) ?
           const float* planes[1] = {lds + slot * C::PLANE + lane_lds};
           const size_t row_vox = ((size_t)cb * p.Ho + (ch0 + wave)) * p.Wo;
           if constexpr (C::WINO) {
-            step_wino<C, COUT, 1, ST>(planes, wres, wvoff, p, cb, 0, ch0 + 2 * wave, cw0, q, n16, wfirst);
+            step_wino<C, COUT, 1, ST>(planes, wres, wvoff, p, cb, 0, 1, ch0 + 2 * wave, cw0, q, n16, wfirst);
           } else {
             switch (mt_live2) {
               case 1: step<C, KD, KHW, SHW, COUT, 1, ST>(planes, wres, wvoff, p, row_vox, cw0, q, n16, wr, al, be, wfirst); break;
@@ -800,22 +829,23 @@ __global__ __launch_bounds__(256, (ST != 0 && KD == 1 && WG == 1 && CIN == 16) ?
         *reinterpret_cast<vec_t*>(lds + slot * C::PLANE + (g * S + v) * KPL) = val;
       }
     };
-    auto slot_of = [](int dz) { return (KD == 1) ? 0 : ((dz % KD) + KD) % KD; };
+    constexpr int NPL = C::NPL, RD = C::RD;
+    auto slot_of = [](int dz) { return (KD == 1) ? 0 : ((dz % C::RING) + C::RING) % C::RING; };
 
-    // prologue: planes d0-PD .. d0+PD
+    // prologue: the planes of the first depth step, d0-PD .. d0-PD+NPL-1
     if constexpr (CIN <= 16 || (C::WINO && CIN >= 32)) {   // (the one-block-per-CU Winograd kernels have the registers for it)
-      vec_t pro[KD][C::NFILL];   // all KD planes in flight at once: one memory latency instead of KD
+      vec_t pro[NPL][C::NFILL];   // all planes in flight at once: one memory latency instead of NPL
 #pragma unroll
-      for (int j = 0; j < KD; ++j)
+      for (int j = 0; j < NPL; ++j)
 #pragma unroll
         for (int k = 0; k < C::NFILL; ++k) pro[j][k] = load_elem(tid + k * 256, d0 - C::PD + j);
 #pragma unroll
-      for (int j = 0; j < KD; ++j)
+      for (int j = 0; j < NPL; ++j)
 #pragma unroll
         for (int k = 0; k < C::NFILL; ++k) store_elem(tid + k * 256, slot_of(d0 - C::PD + j), pro[j][k]);
     } else {                     // CIN = 32: 84 more live registers make the kernel spill (measured), so plane by plane
 #pragma unroll 1
-      for (int dz = d0 - C::PD; dz < d0 - C::PD + KD; ++dz) {
+      for (int dz = d0 - C::PD; dz < d0 - C::PD + NPL; ++dz) {
 #pragma unroll
         for (int k = 0; k < C::NFILL; ++k) store_elem(tid + k * 256, slot_of(dz), load_elem(tid + k * 256, dz));
       }
@@ -825,24 +855,26 @@ __global__ __launch_bounds__(256, (ST != 0 && KD == 1 && WG == 1 && CIN == 16) ?
     t_pro += STAMP() - ts1;
 #endif
 
-    for (int d = d0; d < d1; ++d) {
+    for (int d = d0; d < d1; d += RD) {
 #ifdef MDF_STAMPS
       const unsigned long long tc0 = STAMP();
 #endif
-      const bool more = (KD > 1) && (d + 1 < d1);
-      // fetch the plane the next step needs (d+1+PD) into registers; consumed after this step's MFMAs
-      vec_t pf[C::NFILL];
+      const bool more = (KD > 1) && (d + RD < d1);
+      // fetch the RD planes the next step needs (from d-PD+NPL on) into registers; consumed after this step's MFMAs
+      vec_t pf[RD][C::NFILL];
       if (more && p.prefetch_early) {
 #pragma unroll
-        for (int k = 0; k < C::NFILL; ++k) pf[k] = load_elem(tid + k * 256, d + KD - C::PD);
+        for (int j = 0; j < RD; ++j)
+#pragma unroll
+          for (int k = 0; k < C::NFILL; ++k) pf[j][k] = load_elem(tid + k * 256, d + NPL - C::PD + j);
       }
       if (mt_live > 0) {
-        const float* planes[KD];
+        const float* planes[NPL];
 #pragma unroll
-        for (int kd = 0; kd < KD; ++kd) planes[kd] = lds + slot_of(d + kd - C::PD) * C::PLANE + lane_lds;
+        for (int kd = 0; kd < NPL; ++kd) planes[kd] = lds + slot_of(d + kd - C::PD) * C::PLANE + lane_lds;
         const size_t row_vox = (((size_t)b * p.D + d) * p.Ho + (h0 + wave)) * p.Wo;
         if constexpr (C::WINO) {
-          step_wino<C, COUT, 3, ST>(planes, wres, wvoff, p, b, d, h0 + 2 * wave, w0, q, n16, wfirst);
+          step_wino<C, COUT, NPL, ST>(planes, wres, wvoff, p, b, d, d1, h0 + 2 * wave, w0, q, n16, wfirst);
         } else {
           switch (mt_live) {
             case 1: step<C, KD, KHW, SHW, COUT, 1, ST>(planes, wres, wvoff, p, row_vox, w0, q, n16, wr, al, be, wfirst); break;
@@ -858,12 +890,16 @@ __global__ __launch_bounds__(256, (ST != 0 && KD == 1 && WG == 1 && CIN == 16) ?
 #endif
       if (more && !p.prefetch_early) {
 #pragma unroll
-        for (int k = 0; k < C::NFILL; ++k) pf[k] = load_elem(tid + k * 256, d + KD - C::PD);
+        for (int j = 0; j < RD; ++j)
+#pragma unroll
+          for (int k = 0; k < C::NFILL; ++k) pf[j][k] = load_elem(tid + k * 256, d + NPL - C::PD + j);
       }
       if (more) {
-        __syncthreads();  // all waves finished reading plane d-PD: its slot is free
+        __syncthreads();  // all waves finished reading planes d-PD .. d-PD+RD-1: their slots are free
 #pragma unroll
-        for (int k = 0; k < C::NFILL; ++k) store_elem(tid + k * 256, slot_of(d + KD - C::PD), pf[k]);
+        for (int j = 0; j < RD; ++j)
+#pragma unroll
+          for (int k = 0; k < C::NFILL; ++k) store_elem(tid + k * 256, slot_of(d + NPL - C::PD + j), pf[j][k]);
         __syncthreads();
       }
 #ifdef MDF_STAMPS
@@ -919,6 +955,7 @@ int launch_lds(LdsConvParams& p, hipStream_t st) {
     if (want > p.D / 3) want = p.D / 3;
     if (want < 1) want = 1;
     int dch = (int)((p.D + want - 1) / want);
+    if (C::RD == 2 && (dch & 1)) ++dch;   // depth-pair form: whole pairs per chunk (an odd tail pair computes a plane it does not store)
     p.dch = dch;
     p.dchunks = (p.D + dch - 1) / dch;
     const long long items = tiles * p.dchunks;
@@ -1051,9 +1088,17 @@ extern "C" int mdf_release_stream(void* stream) {
     return !stat ? launch_lds<ci, ci, co, 1, 3, 1, 1, 2, 1>(p, (hipStream_t)stream) : (stat->mode == 1 ? launch_lds<ci, ci, co, 1, 3, 1, 1, 2, 1, 1>(p, (hipStream_t)stream) : launch_lds<ci, ci, co, 1, 3, 1, 1, 2, 1, 2>(p, (hipStream_t)stream)); \
   }
 
+// depth-pair Winograd (3-D, Cout 8): its fragments follow the plain, w-phase and (Cin 16) Winograd ones
+#define LDS_CASE_WD(ci)                                                                          \
+  if (use_wd && KD == 3 && KHW == 3 && stride == 1 && Cin == ci && Cin_mem == ci && Cout == 8 && !res_up && D >= 2) { \
+    p.wpack = wpack + (size_t)27 * ci * 16 + (size_t)36 * ci * 16 + (ci == 16 ? (size_t)3 * 16 * 64 * 4 : 0); \
+    return !stat ? launch_lds<ci, ci, 8, 3, 3, 1, 1, 2, 2>(p, (hipStream_t)stream) : (stat->mode == 1 ? launch_lds<ci, ci, 8, 3, 3, 1, 1, 2, 2, 1>(p, (hipStream_t)stream) : launch_lds<ci, ci, 8, 3, 3, 1, 1, 2, 2, 2>(p, (hipStream_t)stream)); \
+  }
+
 int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
                           float res_scale, const float* res_up, float* y, int B, int D, int H, int W, int Cin, int Cin_mem, int Cout, int KD,
                           int KHW, int stride, int relu, void* stream, int planar_in, int shuffle2, const mdf::ConvStat* stat) {
+  const int wd_mask = [] { const char* e = getenv("MDF_CONV_WD"); return e ? atoi(e) : 3; }();   // dev A/B (read per call): bit 0 Cin 8, bit 1 Cin 16
   static const bool use_wg = [] { const char* e = getenv("MDF_CONV_WINOGRAD"); return e ? atoi(e) != 0 : true; }();   // dev A/B
   static const bool use_rw = [] { const char* e = getenv("MDF_CONV_RW"); return e ? atoi(e) != 0 : true; }();   // dev A/B
   LdsConvParams p{};
@@ -1073,6 +1118,9 @@ int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha
   const int pad = (KHW - 1) / 2;
   p.Ho = (H + 2 * pad - KHW) / stride + 1;
   p.Wo = (W + 2 * pad - KHW) / stride + 1;
+  // 3-D stride-1 layers with 8 output channels: depth-pair Winograd
+  { const bool use_wd = use_wg && (wd_mask & 1); LDS_CASE_WD(8) }
+  { const bool use_wd = use_wg && (wd_mask & 2); LDS_CASE_WD(16) }
   // 3-D stride-1 layers with 16 output channels: Winograd F(2x2,3x3) in (h,w)
   LDS_CASE_WG(16, 16) LDS_CASE_WG(32, 16) LDS_CASE_WG(32, 32) LDS_CASE_WG(16, 8)
   LDS_CASE_WG2(16, 16) LDS_CASE_WG2(32, 32) LDS_CASE_WG2(64, 64)
