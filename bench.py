@@ -50,7 +50,7 @@ def family(name, tag):
     if name == "mdf_conv3d_fwd":
         return "conv3d (regulariser): conv_lds_kernel / conv3d_kernel, fp32 MFMA implicit GEMM"
     if name in ("mdf_conv2d_fwd", "mdf_conv2d_pair_fwd"):
-        return "conv2d (feature pyramid + refine + prob-head partial sums): conv_lds_kernel / conv_pair_kernel, fp32 MFMA implicit GEMM"
+        return "conv2d (feature pyramid + refine + prob-head partial sums): conv_lds_kernel / conv_pair_kernel / conv1x1_kernel, fp32 MFMA implicit GEMM"
     if name == "mdf_warp_aggregate_vec_fwd":
         return "warp_kernel<kVec> (fused warp+aggregate)"
     if name == "mdf_prob_softmax_regress_fwd":

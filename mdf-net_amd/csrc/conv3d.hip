@@ -679,6 +679,9 @@ int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha
                           float res_scale, const float* res_up, float* y, int B, int D, int H, int W, int Cin, int Cin_mem, int Cout, int KD,
                           int KHW, int stride, int relu, void* stream, int planar_in, int shuffle2, const ConvStat* stat);
 
+int mdf_conv1x1_dispatch(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res, float res_scale,
+                         const float* res_up, float* y, int B, int H, int W, int Cin, int Cout, int relu, void* stream);
+
 static int conv2d_entry(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
                         float res_scale, const float* res_up, float* y, int B, int H, int W, int Cin_mem, int Cout, int ksize, int stride,
                         int relu, int planar_in, int pixel_shuffle2, void* stream, const ConvStat* stat) {
@@ -689,6 +692,10 @@ static int conv2d_entry(const float* x, const float* wpack, const float* alpha, 
               "res_up needs stride 1, even H and W, Cout %% 4 == 0");
   MDF_REQUIRE(!planar_in || Cin_mem < 4, "planar (NCHW) input is supported for Cin < 4 only (the image layer)");
   MDF_REQUIRE(!pixel_shuffle2 || (Cout == 32 && stride == 1 && !res && !res_up), "pixel_shuffle2 output is built for Cout = 32, stride 1, no residual");
+  if (ksize == 1 && stride == 1 && !stat && !planar_in && !pixel_shuffle2) {   // 1x1 layers: streaming kernel (conv1x1.hip)
+    const int rc1 = mdf_conv1x1_dispatch(x, wpack, alpha, beta, res, res_scale, res_up, y, B, H, W, Cin_mem, Cout, relu, stream);
+    if (rc1 != MDF_EUNSUPPORTED) return rc1;
+  }
   const int rc = mdf_conv_lds_dispatch(x, wpack, alpha, beta, res, res_scale, res_up, y, B, 1, H, W, padded_cin(Cin_mem), Cin_mem, Cout, 1,
                                        ksize, stride, relu, stream, planar_in, pixel_shuffle2, stat);
   if (rc == MDF_EUNSUPPORTED)

@@ -948,7 +948,7 @@ int launch_lds(LdsConvParams& p, hipStream_t st) {
     // 1-plane tail chunk (D = 4 -> 3 + 1) costs a whole prologue for a third of the work: 93 -> 77 us on 16->16 @4x296x400.
     // (A makespan model "rounds x (chunk + prologue)" was tried and is wrong here: two resident blocks share one MFMA pipe,
     // so fewer, longer items do not finish sooner.)
-    long long ipb = 6;
+    long long ipb = (C::RD == 2 && blocks_per_cu == 1) ? 3 : 6;   // (one resident block and long pair steps: 179 -> 172 us on 16->8 @24x296x400)
     if (const char* e = getenv("MDF_CONV_ITEMS_PER_BLOCK")) { if (atoi(e) > 0) ipb = atoi(e); }   // dev A/B
     long long want = (ipb * max_grid + tiles - 1) / tiles;
     if (want < 1) want = 1;
@@ -1098,7 +1098,7 @@ extern "C" int mdf_release_stream(void* stream) {
 int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
                           float res_scale, const float* res_up, float* y, int B, int D, int H, int W, int Cin, int Cin_mem, int Cout, int KD,
                           int KHW, int stride, int relu, void* stream, int planar_in, int shuffle2, const mdf::ConvStat* stat) {
-  const int wd_mask = [] { const char* e = getenv("MDF_CONV_WD"); return e ? atoi(e) : 3; }();   // dev A/B (read per call): bit 0 Cin 8, bit 1 Cin 16
+  static const int wd_mask = [] { const char* e = getenv("MDF_CONV_WD"); return e ? atoi(e) : 3; }();   // dev A/B: bit 0 Cin 8, bit 1 Cin 16
   static const bool use_wg = [] { const char* e = getenv("MDF_CONV_WINOGRAD"); return e ? atoi(e) != 0 : true; }();   // dev A/B
   static const bool use_rw = [] { const char* e = getenv("MDF_CONV_RW"); return e ? atoi(e) != 0 : true; }();   // dev A/B
   LdsConvParams p{};

@@ -6,7 +6,11 @@ from mdfnet_hip import ops
 L = [("refine 8->8", 8, 8, 3, 1, 1, 592, 800), ("refine 1->8", 1, 8, 3, 1, 1, 592, 800), ("refine 8->1", 8, 1, 3, 1, 1, 1184, 1600),
      ("bb 8->8", 8, 8, 3, 1, 5, 1184, 1600), ("bb 3->8", 3, 8, 3, 1, 5, 1184, 1600), ("head 16->16 k1", 16, 16, 1, 1, 5, 592, 800),
      ("bb 8->16 k5s2", 8, 16, 5, 2, 5, 1184, 1600), ("bb 16->16", 16, 16, 3, 1, 5, 592, 800), ("bb 16->32 k5s2", 16, 32, 5, 2, 5, 592, 800),
-     ("bb 32->32", 32, 32, 3, 1, 5, 296, 400), ("bb 32->64 k5s2", 32, 64, 5, 2, 5, 296, 400), ("bb 64->64", 64, 64, 3, 1, 5, 148, 200)]
+     ("bb 32->32", 32, 32, 3, 1, 5, 296, 400), ("bb 32->64 k5s2", 32, 64, 5, 2, 5, 296, 400), ("bb 64->64", 64, 64, 3, 1, 5, 148, 200),
+     ("head 64->64 k1", 64, 64, 1, 1, 5, 148, 200), ("head 64->32 k1", 64, 32, 1, 1, 5, 148, 200), ("head 32->32 k1", 32, 32, 1, 1, 5, 296, 400),
+     ("head 64->16 k1", 64, 16, 1, 1, 5, 148, 200), ("head 32->16 k1", 32, 16, 1, 1, 5, 296, 400)]
+if len(sys.argv) > 1:
+    L = [l for l in L if sys.argv[1] in l[0]]
 dev = "cuda:0"
 ab = os.environ.get("MDF_AB"); vals = os.environ.get("MDF_AB_VALS", "0").split(",")
 for name, ci, co, k, st, b, h, w in L:

@@ -52,6 +52,26 @@ def test_lateral_conv_with_fused_upsample_add():
     np.testing.assert_allclose(ops.from_nhwc(y).cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 16), (32, 32), (32, 64), (16, 32)])
+def test_streaming_1x1_kernel_equals_the_lds_kernel(cin, cout, monkeypatch):
+    """conv1x1.hip against the LDS-tiled kernel for the same layer (MDF_CONV1X1=0): same MFMA order and epilogue, so
+    bit for bit; ragged pixel count (the last run of tiles is partly empty), upsample-add, scale/shift/ReLU, residual."""
+    rng = np.random.RandomState(cin + cout)
+    b, h, w = 3, 26, 42                                              # 3276 pixels: not a multiple of a run (128 / 64 / 32 px)
+    x = ops.to_nhwc(T(rng.randn(b, cin, h, w).astype(np.float32)).to(DEV))
+    top = ops.to_nhwc(T(rng.randn(b, cout, h // 2, w // 2).astype(np.float32)).to(DEV))
+    res = ops.to_nhwc(T(rng.randn(b, cout, h, w).astype(np.float32)).to(DEV))
+    wp = ops.pack_conv2d_weight(T((rng.randn(cout, cin, 1, 1) / np.sqrt(cin)).astype(np.float32)).to(DEV))
+    al, be = T(rng.uniform(0.5, 1.5, cout).astype(np.float32)).to(DEV), T(rng.randn(cout).astype(np.float32)).to(DEV)
+    cases = [dict(alpha=None, beta=be, res_up=top), dict(alpha=al, beta=be, relu=True, res=res, res_scale=0.1), dict()]
+    for kw in cases:
+        monkeypatch.setenv("MDF_CONV1X1", "1")
+        got = ops.conv2d_nhwc(x, wp, cin, cout, 1, 1, **kw)
+        monkeypatch.setenv("MDF_CONV1X1", "0")
+        exp = ops.conv2d_nhwc(x, wp, cin, cout, 1, 1, **kw)
+        assert torch.equal(got, exp), kw.keys()
+
+
 def test_backbone_and_refine_vs_reference_golden(golden, seeded_sd):
     g = golden("ops.npz")
     m = build_model()
