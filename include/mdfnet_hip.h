@@ -134,6 +134,12 @@ int mdf_prob_softmax_regress_fwd(const float* x, const float* w, const float* hy
  * soft-argmin.  D <= 96.  partials 16-byte aligned.                                                               */
 int mdf_prob_from_partials_fwd(const float* partials, const float* hypos, int hypos_per_pixel, float* prob, float* depth,
                                int B, int D, int h, int wd, void* stream);
+/* The partial-sum form in ONE launch: a block owns a 4 x 64 pixel tile, walks the depth axis with the MFMA step of that 2-D conv
+ * and keeps the partials in registers (they never reach memory).  wpack = mdf_conv_pack_weights of the 4-channel 2-D weight above
+ * (Cin_mem = Cin, Cout = 4, 9 taps).  Cin in {8,16}.  Bit-identical to mdf_conv2d_fwd + mdf_prob_from_partials_fwd; parallel over
+ * pixels only, so for maps that fill the chip (B*ceil(h/4)*ceil(wd/64) blocks).                                            */
+int mdf_prob_fused_fwd(const float* x, const float* wpack, const float* hypos, int hypos_per_pixel, float* prob, float* depth,
+                       int B, int D, int h, int wd, int Cin, void* stream);
 
 /* ---- the two full-resolution layers of the feature pyramid as one launch (net/unit/backbone.py:28, eval):
  *      y = relu(bn2(conv2(relu(bn1(conv1(x))))))   Conv2d(3,8,k3,p1) -> Conv2d(8,8,k3,p1), BatchNorm folded to (alpha, beta);

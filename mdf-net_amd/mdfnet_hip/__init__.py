@@ -43,6 +43,7 @@ SIGNATURES = {
     "mdf_conv_pack_weights": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp]),
     "mdf_prob_softmax_regress_fwd": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp, c_fp] + [c_int] * 5 + [c_fp]),
     "mdf_prob_from_partials_fwd": (c_int, [c_fp, c_fp, c_int, c_fp, c_fp] + [c_int] * 4 + [c_fp]),
+    "mdf_prob_fused_fwd": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp, c_fp] + [c_int] * 5 + [c_fp]),
     "mdf_depth_regress_fwd": (c_int, [c_fp, c_fp, c_int, c_fp] + [c_int] * 4 + [c_fp]),
     "mdf_confidence_fwd": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 4 + [c_fp]),
     "mdf_confidence_up2_fwd": (c_int, [c_fp, c_fp] + [c_int] * 4 + [c_fp]),

@@ -4,6 +4,7 @@ PyTorch is plumbing here: it owns device memory and the stream; every operator b
 (or a few) hand-written HIP kernels.  No fallback: tensors must live on a HIP device.
 """
 import ctypes
+import os
 import threading
 
 import torch
@@ -452,11 +453,17 @@ def pack_prob_weight(weight):
     return pack_conv2d_weight(w2)
 
 
+# The one-launch partial-sum route is parallel over pixels only (one block per 4 x 64 tile): used once that fills the chip.
+PROB_FUSED = os.environ.get("MDF_PROB_FUSED", "1") != "0"              # dev A/B
+PROB_FUSED_MIN_TILES = int(os.environ.get("MDF_PROB_FUSED_MIN_TILES", "400"))
+
+
 def prob_head(x, weight, depth_hypos=None, direct=False, wpack=None):
     """Conv3d(Cin->1,k3,p1) + softmax over D [+ soft-argmin].  x [B,D,h,w,Cin] -> prob [B,D,h,w] (, depth).
     Default route: per-plane partial sums on the MFMA conv kernel + a light combine/softmax kernel (`wpack` = cached
-    pack_prob_weight(weight), packed here when absent); `direct` (or a shape the partial-sum kernels are not built for)
-    uses the self-contained direct kernel."""
+    pack_prob_weight(weight), packed here when absent) -- as ONE launch that keeps the partials in registers when the map is
+    large enough to fill the chip with one block per 4 x 64 pixel tile, otherwise as two; `direct` (or a shape the partial-sum
+    kernels are not built for) uses the self-contained direct kernel."""
     _need_gpu(x, weight)
     b, d, h, w, c = x.shape
     prob = torch.empty((b, d, h, w), device=x.device, dtype=torch.float32)
@@ -464,6 +471,15 @@ def prob_head(x, weight, depth_hypos=None, direct=False, wpack=None):
     if depth_hypos is not None:
         hyp, pp = _hypos_arg(depth_hypos, h, w)
         depth = torch.empty((b, h, w), device=x.device, dtype=torch.float32)
+    fused_lds = 2 * c * 398 * 4 + d * 1024          # bytes: two plane tiles + the logits of the block's 256 pixels
+    if (not direct and c in (8, 16) and x.is_contiguous() and PROB_FUSED and fused_lds <= 160 * 1024
+            and b * ((h + 3) // 4) * ((w + 63) // 64) >= PROB_FUSED_MIN_TILES):
+        wp = pack_prob_weight(weight) if wpack is None else wpack
+        _abi("mdf_prob_fused_fwd", (x.data_ptr(), wp.data_ptr(), None if hyp is None else hyp.data_ptr(), pp, prob.data_ptr(),
+                                    None if depth is None else depth.data_ptr(), b, d, h, w, c, _stream(prob),),
+             tag=f"{c}->1 {d}x{h}x{w}", work={"flops": 2.0 * 27 * c * b * d * h * w,
+                                              "bytes": 4.0 * (x.numel() + prob.numel()), "bound": "hbm"})
+        return prob if depth is None else (prob, depth)
     if not direct and c in (8, 16) and d <= 96 and x.is_contiguous():
         part = conv2d_nhwc(x.view(b * d, h, w, c), pack_prob_weight(weight) if wpack is None else wpack, c, 4, 3, 1,
                            useful_cout=3)

@@ -170,3 +170,25 @@ def test_prob_head_routes_agree_with_conv3d_softmax(cin, D, h, w):
         np.testing.assert_allclose(p.cpu().numpy(), ref_p.numpy(), rtol=2e-4, atol=1e-7, err_msg=f"direct={direct}")
         np.testing.assert_allclose(d.cpu().numpy(), ref_d.numpy(), rtol=1e-5, err_msg=f"direct={direct}")
         assert torch.allclose(p.sum(1), torch.ones_like(p[:, 0]), atol=1e-5)
+
+
+@pytest.mark.parametrize("cin,D,h,w", [(8, 8, 37, 53), (16, 24, 21, 130), (8, 1, 5, 7), (16, 3, 9, 65), (8, 60, 6, 70)])
+def test_prob_head_in_one_launch_equals_the_two_launch_route(cin, D, h, w, monkeypatch):
+    """mdf_prob_fused_fwd (partials kept in registers while the block walks the depth axis) against mdf_conv2d_fwd +
+    mdf_prob_from_partials_fwd: same MFMA step, same combine / softmax / soft-argmin order, so bit for bit -- ragged tiles,
+    D = 1 / 3 / > 48, per-pixel and per-plane hypotheses, with and without the depth output."""
+    g = torch.Generator().manual_seed(cin * 77 + D)
+    x = torch.randn(2, D, h, w, cin, generator=g).to(DEV)
+    wt = (torch.randn(1, cin, 3, 3, 3, generator=g) * 0.3).to(DEV)
+    hyps = [torch.sort(torch.rand(2, D, h, w, generator=g) * 500 + 400, dim=1)[0].to(DEV), (torch.rand(2, D, 1, 1, generator=g) * 500 + 400).to(DEV), None]
+    for hyp in hyps:
+        monkeypatch.setattr(ops, "PROB_FUSED_MIN_TILES", 0)
+        ops.count_begin()
+        got = ops.prob_head(x, wt, hyp)
+        assert ops.count_end().get("mdf_prob_fused_fwd", 0) == 1
+        monkeypatch.setattr(ops, "PROB_FUSED_MIN_TILES", 1 << 30)
+        exp = ops.prob_head(x, wt, hyp)
+        if hyp is None:
+            assert torch.equal(got, exp)
+        else:
+            assert torch.equal(got[0], exp[0]) and torch.equal(got[1], exp[1])
