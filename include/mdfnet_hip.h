@@ -141,6 +141,14 @@ int mdf_prob_from_partials_fwd(const float* partials, const float* hypos, int hy
 int mdf_prob_fused_fwd(const float* x, const float* wpack, const float* hypos, int hypos_per_pixel, float* prob, float* depth,
                        int B, int D, int h, int wd, int Cin, void* stream);
 
+/* ---- tail of the refinement net as one launch (net/unit/refine.py:18-20,42-44):
+ *      y = [lo +] conv2(PixelShuffle(2)(conv1(x))) [* span]     Conv2d(8,32,k3,p1,no bias) -> PixelShuffle(2) -> Conv2d(8,1,k3,p1,no bias)
+ *      x NHWC [B,H,W,8]; w1pack = mdf_conv_pack_weights of conv1's weight with its output rows in PixelShuffle order
+ *      (row sub*8 + oc <- channel oc*4 + sub); w2 = conv2's weight [1,8,3,3]; lo / span [B] or both NULL (the range mapping
+ *      lo + y * span with torch's roundings); y [B,2H,2W].  The 8-channel map at twice the resolution never reaches memory.   */
+int mdf_refine_tail_fwd(const float* x, const float* w1pack, const float* w2, const float* lo, const float* span, float* y,
+                        int B, int H, int W, void* stream);
+
 /* ---- the two full-resolution layers of the feature pyramid as one launch (net/unit/backbone.py:28, eval):
  *      y = relu(bn2(conv2(relu(bn1(conv1(x))))))   Conv2d(3,8,k3,p1) -> Conv2d(8,8,k3,p1), BatchNorm folded to (alpha, beta);
  *      x planar [N,3,H,W] as the loader hands it over, y NHWC [N,H,W,8]; w1pack / w2pack = mdf_conv_pack_weights of the two

@@ -131,6 +131,13 @@ def conv2d_pair(block0, block1, x):
     return ops.conv2d_pair_planar(x, w1, a1, b1, w2, a2, b2)
 
 
+def refine_tail(conv_a, conv_b, x, lo, span):
+    """RefineNet2.conv2 (Conv2d(8,32) -> PixelShuffle(2) -> Conv2d(8,1), no bias) + the mapping lo + y*span as one launch."""
+    assert conv_a.bias is None and conv_b.bias is None
+    wp, _, _ = cache_of(conv_a).get([conv_a.weight, conv_a.bias], lambda: (ops.pack_conv2d_weight(ops.shuffle2_rows(conv_a.weight)), None, None))
+    return ops.refine_tail(x, wp, conv_b.weight, lo, span)
+
+
 def conv2d_layer(conv, bn, x, relu=False, res=None, res_scale=1.0, res_up=None, planar_in=False, pixel_shuffle2=False):
     """Conv2d [+ BatchNorm2d eval] [+ ReLU] [+ residual / upsample-add] [+ PixelShuffle(2)] as one kernel.  x, res: [B,H,W,C] NHWC."""
     assert not (pixel_shuffle2 and (bn is not None or conv.bias is not None))

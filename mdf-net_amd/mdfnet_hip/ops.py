@@ -495,6 +495,19 @@ def prob_head(x, weight, depth_hypos=None, direct=False, wpack=None):
     return prob if depth is None else (prob, depth)
 
 
+def refine_tail(x, w1pack, w2, lo=None, span=None):
+    """[lo +] Conv2d(8,1,k3)(PixelShuffle(2)(Conv2d(8,32,k3)(x))) [* span] in one launch.  x [B,h,w,8] NHWC; w1pack =
+    pack_conv2d_weight(shuffle2_rows(weight)); w2 [1,8,3,3]; lo, span [B] -> [B,2h,2w]."""
+    _need_gpu(x, w1pack, w2)
+    b, h, w, c = x.shape
+    assert c == 8 and x.is_contiguous() and tuple(w2.shape) == (1, 8, 3, 3)
+    y = torch.empty((b, 2 * h, 2 * w), device=x.device, dtype=torch.float32)
+    _abi("mdf_refine_tail_fwd", (x.data_ptr(), w1pack.data_ptr(), _f32c(w2.detach()).data_ptr(), None if lo is None else _f32c(lo).data_ptr(),
+                                 None if span is None else _f32c(span).data_ptr(), y.data_ptr(), b, h, w, _stream(y),),
+         tag=f"8->32->1 {h}x{w}x{b}", work={"flops": 2.0 * 72 * (32 + 4) * b * h * w, "bytes": 4.0 * (x.numel() + y.numel()), "bound": "mfma"})
+    return y
+
+
 def fold_bn(bn_weight, bn_bias, running_mean, running_var, eps=1e-5):
     """Eval BatchNorm as ATen folds it: alpha = gamma/sqrt(var+eps), beta = bias - mean*alpha."""
     invstd = 1.0 / torch.sqrt(running_var.float() + eps)

@@ -1,12 +1,16 @@
 """Depth refinement / x2 upsampling (reference: net/unit/refine.py:8-46).  Eval on a GPU: fused implicit-GEMM conv
 kernels (NHWC) with the Res-block update x + 0.1*conv(...) and the skip add in the conv epilogues; training / CPU: stock
 PyTorch modules."""
+import os
+
 import torch
 import torch.nn as nn
 
 from mdfnet_hip import controlplane, layers, ops
 
 from .base import Res
+
+_TAIL = os.environ.get("MDF_REFINE_TAIL", "1") != "0"      # dev A/B: the last three stages as three launches
 
 
 class RefineNet2(nn.Module):
@@ -37,6 +41,8 @@ class RefineNet2(nn.Module):
                     t = layers.conv2d_layer(blk.conv[0], None, y, relu=True)
                     y = layers.conv2d_layer(blk.conv[2], None, t, res=y, res_scale=0.1)
                 y = layers.conv2d_layer(self.conv1, None, y, res=x0)                               # x0 + conv1(y)
+                if _TAIL:                                                                          # conv2 + the range mapping in one launch
+                    return layers.refine_tail(self.conv2[0], self.conv2[2], y, lo.reshape(b), span.reshape(b))
                 y = layers.conv2d_layer(self.conv2[0], None, y, pixel_shuffle2=True)               # conv + PixelShuffle(2): [B,2h,2w,8]
                 y = layers.conv2d_layer(self.conv2[2], None, y)                                    # [B,2h,2w,1]
                 return ops.range_affine(y.squeeze(-1), lo.reshape(b), span.reshape(b), 1)

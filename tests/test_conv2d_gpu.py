@@ -72,6 +72,31 @@ def test_streaming_1x1_kernel_equals_the_lds_kernel(cin, cout, monkeypatch):
         assert torch.equal(got, exp), kw.keys()
 
 
+@pytest.mark.parametrize("shape", [(2, 21, 47), (1, 8, 30), (1, 5, 3), (3, 16, 61), (1, 64, 90)])
+def test_refine_tail_in_one_launch(shape):
+    """Conv2d(8,32) -> PixelShuffle(2) -> Conv2d(8,1) -> lo + y*span (refine.py:18-20,42-44) as mdf_refine_tail_fwd against torch on
+    the CPU and against the three-launch route; tiles of 8 x 30 low-resolution pixels: exact, ragged and smaller-than-a-tile maps."""
+    b, h, w = shape
+    rng = np.random.RandomState(h * 100 + w)
+    x = T(rng.randn(b, 8, h, w).astype(np.float32))
+    w1 = T((rng.randn(32, 8, 3, 3) / np.sqrt(72)).astype(np.float32))
+    w2 = T((rng.randn(1, 8, 3, 3) / np.sqrt(72)).astype(np.float32))
+    lo = T(rng.uniform(400, 500, b).astype(np.float32))
+    span = T(rng.uniform(300, 600, b).astype(np.float32))
+    raw = F.conv2d(F.pixel_shuffle(F.conv2d(x, w1, None, 1, 1), 2), w2, None, 1, 1).squeeze(1)
+    exp = lo.view(b, 1, 1) + raw * span.view(b, 1, 1)
+    xd = ops.to_nhwc(x.to(DEV))
+    wp = ops.pack_conv2d_weight(ops.shuffle2_rows(w1.to(DEV)))
+    got = ops.refine_tail(xd, wp, w2.to(DEV), lo.to(DEV), span.to(DEV))
+    assert got.shape == exp.shape
+    np.testing.assert_allclose(got.cpu().numpy(), exp.numpy(), rtol=0, atol=span.max().item() * 4e-6)
+    got_raw = ops.refine_tail(xd, wp, w2.to(DEV))
+    np.testing.assert_allclose(got_raw.cpu().numpy(), raw.numpy(), rtol=0, atol=4e-6)
+    mid = ops.conv2d_nhwc(xd, wp, 8, 32, 3, 1, pixel_shuffle2=True)                       # the three-launch route
+    two = ops.conv2d_nhwc(mid, ops.pack_conv2d_weight(w2.to(DEV)), 8, 1, 3, 1).squeeze(-1)
+    np.testing.assert_allclose(got_raw.cpu().numpy(), two.cpu().numpy(), rtol=0, atol=4e-6)
+
+
 def test_backbone_and_refine_vs_reference_golden(golden, seeded_sd):
     g = golden("ops.npz")
     m = build_model()
