@@ -375,6 +375,133 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
   }
 }
 
+// ---- ConvTranspose3d(k3,s2,p1,op1) on large volumes: all four (pd, ph) output parity classes from one pass over the input -----
+// conv3d_kernel<kTr> runs one block per class: every class walks its own 2-8 taps, and the four together fetch the tile's input
+// fragments 18 times (once per class tap).  The classes use only 8 distinct input positions -- (d, h, w) + (od, oh, ow), offsets
+// 0/1 -- so here a wave visits the 8 positions once and feeds each fragment to every class that has a tap there (4 + 2 + 2 + 1
+// classes per w offset = the same 18 MFMA groups): 8 input fetches instead of 18, four times the MFMAs behind every fetch, and
+// the 2 x 2 (d, h) output neighbourhood of a tile written by one block.  Positions run (od, oh) = (1,1), (1,0), (0,1), (0,0), so
+// every class accumulates its taps in the order of conv3d_kernel<kTr>: bit-identical results.
+template <int CIN, int COUT, int MT>
+__global__ __launch_bounds__(256) void convtr_all_kernel(const ConvParams p) {
+  constexpr int KPL = (CIN >= 16) ? 4 : 2, CK = 4 * KPL, NCH = CIN / CK;
+  constexpr int ROWS = 2 * COUT, NT = (ROWS + 15) / 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, n16 = lane & 15;
+  const unsigned tile_blk = mdf::xcd_remap(blockIdx.x, p.nblk);
+  const long long m0 = ((long long)tile_blk * 4 + wave) * (MT * 16);
+
+  int in_off[MT];
+  long long out_vox[MT];      // output voxel (2d, 2h, 2w) of the lane's input voxel
+  unsigned vmask[MT];         // bit 0: d+1 inside, bit 1: h+1 inside, bit 2: w+1 inside, bit 3: live
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    long long m = m0 + t * 16 + n16;
+    const bool live = m < p.m_total;
+    if (!live) m = p.m_total - 1;
+    const int mw = (int)(m % p.Wi);
+    long long r = m / p.Wi;
+    const int mh = (int)(r % p.Hi);
+    r /= p.Hi;
+    const int md = (int)(r % p.Di);
+    const int b = (int)(r / p.Di);
+    vmask[t] = live ? (8u | (md + 1 < p.Di ? 1u : 0u) | (mh + 1 < p.Hi ? 2u : 0u) | (mw + 1 < p.Wi ? 4u : 0u)) : 0u;
+    in_off[t] = (int)((((long long)b * p.Di + md) * p.Hi + mh) * p.Wi + mw) * CIN;
+    out_vox[t] = (((long long)b * p.Do + 2 * md) * p.Ho + 2 * mh) * p.Wo + 2 * mw;
+  }
+  f32x4 acc[4][MT][NT];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[c][t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 ep_al[NT], ep_be[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int r0 = nt * 16 + 4 * q, c0 = r0 % COUT;
+    ep_al[nt] = make_float4(1.f, 1.f, 1.f, 1.f);
+    ep_be[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 < ROWS && p.alpha) {
+      ep_al[nt] = *reinterpret_cast<const float4*>(p.alpha + c0);
+      ep_be[nt] = *reinterpret_cast<const float4*>(p.beta + c0);
+    }
+  }
+  const float* xq = p.x + KPL * q;
+  const float* wl = p.wpack + (size_t)lane * KPL;
+#pragma unroll
+  for (int pos = 0; pos < 8; ++pos) {
+    const int od = 1 - (pos >> 2), oh = 1 - ((pos >> 1) & 1), ow = pos & 1;
+    const unsigned need = 8u | (od ? 1u : 0u) | (oh ? 2u : 0u) | (ow ? 4u : 0u);
+    const int tapoff = ((od * p.Hi + oh) * p.Wi + ow) * CIN;
+    Frag<KPL> bf[NCH][MT];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {   // (branch-free, as in conv3d_kernel: an absent neighbour reads the voxel itself and is zeroed)
+        const bool ok = (vmask[t] & need) == need;
+        bf[ch][t].load(xq + in_off[t] + (ok ? tapoff : 0) + ch * CK);
+        bf[ch][t].scale(ok ? 1.0f : 0.0f);
+      }
+#pragma unroll
+    for (int cls = 0; cls < 4; ++cls) {
+      const int pd = cls >> 1, ph = cls & 1;
+      if (od > pd || oh > ph) continue;                   // parity 0 has its one tap at offset 0
+      const int kd = pd ? (od ? 0 : 2) : 1, kh = ph ? (oh ? 0 : 2) : 1;
+      const float* wt = wl + (size_t)((kd * 3 + kh) * 2 + ow) * (NCH * NT * 64 * KPL);
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        Frag<KPL> af[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) af[nt].load(wt + (size_t)(ch * NT + nt) * (64 * KPL));
+#pragma unroll
+        for (int s = 0; s < KPL; ++s)
+#pragma unroll
+          for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              if (ow == 1 && (nt + 1) * 16 <= COUT) continue;   // offset +1 feeds parity pw = 1 only: those n-tiles are structurally zero
+              acc[cls][t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[nt].v[s], bf[ch][t].v[s], acc[cls][t][nt], 0, 0, 0);
+            }
+      }
+    }
+  }
+#pragma unroll
+  for (int cls = 0; cls < 4; ++cls) {
+    const int pd = cls >> 1, ph = cls & 1;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int r0 = nt * 16 + 4 * q;
+      if (r0 >= ROWS) continue;
+      const int pw_out = r0 / COUT, c0 = r0 % COUT;
+      const float4 al = ep_al[nt], be = ep_be[nt];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        if (!(vmask[t] & 8u)) continue;
+        float4 o;
+        o.x = acc[cls][t][nt][0] * al.x + be.x;
+        o.y = acc[cls][t][nt][1] * al.y + be.y;
+        o.z = acc[cls][t][nt][2] * al.z + be.z;
+        o.w = acc[cls][t][nt][3] * al.w + be.w;
+        if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        const size_t oi = (size_t)(out_vox[t] + ((long long)pd * p.Ho + ph) * p.Wo + pw_out) * COUT + c0;
+        if (p.res) {
+          const float4 rr = *reinterpret_cast<const float4*>(p.res + oi);
+          o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+        }
+        *reinterpret_cast<float4*>(p.y + oi) = o;
+      }
+    }
+  }
+}
+
+template <int CIN, int COUT, int MT>
+int launch_convtr_all(ConvParams& p, hipStream_t st) {
+  p.nblk = (unsigned)((p.m_total + 4LL * MT * 16 - 1) / (4LL * MT * 16));
+  hipLaunchKernelGGL((convtr_all_kernel<CIN, COUT, MT>), dim3(p.nblk), dim3(256), 0, st, p);
+  return mdf::check_launch("convtr_all_kernel");
+}
+
 // ---- weight packing ------------------------------------------------------------------------------------------------
 // Every packing reads the LOGICAL conv weight W[o][i][t] (o < Co output rows, i < Ci input channels in memory, t < T taps)
 // through WSrc, which maps it onto the parameter tensor as it sits in the module.  Mode 0 is the parameter itself; the
@@ -760,6 +887,14 @@ static int conv3d_entry(const float* x, const float* wpack, const float* alpha, 
   if (m == kS1 && p.m_total >= lds_min) {  // large stride-1 layers: LDS-staged planes (conv_lds.hip)
     const int rc = mdf_conv_lds_dispatch(x, wpack, alpha, beta, res, 1.0f, nullptr, y, B, Di, Hi, Wi, Cin, Cin, Cout, 3, 3, 1, relu, stream, 0, 0, stat);
     if (rc != MDF_EUNSUPPORTED) return rc;
+  }
+  if (m == kTr && !stat) {   // large transposed layers: all four parity classes per tile (convtr_all_kernel)
+    const long long tr_min = [] { const char* e = getenv("MDF_CONVTR_ALL_MIN_VOXELS"); return e ? atoll(e) : 100000LL; }();   // dev A/B (read per call); -1 = never
+    if (tr_min >= 0 && p.m_total >= tr_min) {
+      if (Cin == 16 && Cout == 8) return launch_convtr_all<16, 8, 2>(p, (hipStream_t)stream);
+      if (Cin == 32 && Cout == 16) return launch_convtr_all<32, 16, 2>(p, (hipStream_t)stream);
+      if (Cin == 64 && Cout == 32) return launch_convtr_all<64, 32, 1>(p, (hipStream_t)stream);
+    }
   }
   // stride 1 (every Cin x Cout the nets use)
   MDF_CONV_CASE(32, 16, kS1) MDF_CONV_CASE(16, 16, kS1) MDF_CONV_CASE(32, 32, kS1) MDF_CONV_CASE(64, 64, kS1)

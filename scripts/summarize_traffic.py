@@ -16,7 +16,7 @@ def family(name):
         return "aggregate_train_passes"
     if "bn_" in name:
         return "batchnorm_train"
-    if "conv_lds_kernel" in name or "conv3d_kernel" in name or "conv_pair_kernel" in name or "conv1x1_kernel" in name:
+    if "conv_lds_kernel" in name or "conv3d_kernel" in name or "conv_pair_kernel" in name or "conv1x1_kernel" in name or "refine_tail_kernel" in name or "prob_fused_kernel" in name:
         return "mfma_conv"
     if "warp_kernel" in name:
         return "warp_aggregate"

@@ -192,3 +192,24 @@ def test_prob_head_in_one_launch_equals_the_two_launch_route(cin, D, h, w, monke
             assert torch.equal(got, exp)
         else:
             assert torch.equal(got[0], exp[0]) and torch.equal(got[1], exp[1])
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 8), (32, 16), (64, 32)])
+@pytest.mark.parametrize("shape", [(1, 5, 37, 53), (2, 3, 20, 70), (1, 1, 9, 17)])
+def test_transposed_conv_all_classes_kernel_equals_the_per_class_kernel(cin, cout, shape, monkeypatch):
+    """convtr_all_kernel (every input fragment fetched once, fed to all four (pd, ph) parity classes) against
+    conv3d_kernel<kTr> (one block per class): the taps of a class are accumulated in the same order, so bit for bit --
+    ragged tiles, single-plane volume, with the skip connection and the folded BatchNorm + ReLU."""
+    b, d, h, w = shape
+    g = torch.Generator().manual_seed(cin + d * h)
+    x = torch.randn(b, d, h, w, cin, generator=g).to(DEV)
+    wt = (torch.randn(cin, cout, 3, 3, 3, generator=g) / (27 * cin) ** 0.5).to(DEV)
+    wp = ops.pack_conv3d_weight(wt, True)
+    al, be = (torch.rand(cout, generator=g) + 0.5).to(DEV), (torch.randn(cout, generator=g) * 0.1).to(DEV)
+    res = torch.randn(b, 2 * d, 2 * h, 2 * w, cout, generator=g).to(DEV)
+    for kw in (dict(), dict(alpha=al, beta=be, relu=True, res=res)):
+        monkeypatch.setenv("MDF_CONVTR_ALL_MIN_VOXELS", "0")
+        got = ops.conv3d_ndhwc(x, wp, cin, cout, 2, True, **kw)
+        monkeypatch.setenv("MDF_CONVTR_ALL_MIN_VOXELS", "-1")
+        exp = ops.conv3d_ndhwc(x, wp, cin, cout, 2, True, **kw)
+        assert torch.equal(got, exp)
