@@ -95,6 +95,21 @@ template <> __device__ __forceinline__ void buf_load_to<1>(__amdgpu_buffer_rsrc_
   o[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
+// B-fragment read from LDS.  KPL = 2: hipcc merges two neighbouring 8-byte reads (taps kw, kw+1) into ONE ds_read2_b64, which
+// the LDS serves at half the rate of ds_read_b64 (8 cycles per wave instead of 2 x 2) and banks modulo 32 instead of 64 -- the
+// layouts chosen for ds_read_b64 (round_s) then conflict: SQ_LDS_BANK_CONFLICT was 90 % of the LDS cycles of the 8-channel
+// kernels.  A volatile access is not merged.
+typedef float lds_f2 __attribute__((ext_vector_type(2)));
+template <int KPL> __device__ __forceinline__ void lds_frag(const float* p, float* o) {
+  if constexpr (KPL == 2) {
+    typedef const volatile __attribute__((address_space(3))) lds_f2* lds_ptr;   // (explicitly LDS: a volatile generic access becomes a flat load)
+    const lds_f2 v = *(lds_ptr)(p);
+    o[0] = v.x; o[1] = v.y;
+  } else {
+    vec_to<KPL>(*reinterpret_cast<const typename VecT<KPL>::type*>(p), o);
+  }
+}
+
 template <int KPL> __device__ __forceinline__ typename VecT<KPL>::type vec_zero();
 template <> __device__ __forceinline__ float4 vec_zero<4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 template <> __device__ __forceinline__ float2 vec_zero<2>() { return make_float2(0.f, 0.f); }
@@ -255,7 +270,7 @@ __device__ __forceinline__ void step_mfma(const float* const (&planes)[KD], __am
     const int kw = tap % C::KW, kh = (tap / C::KW) % KHW, kd = tap / (KHW * C::KW);
 #pragma unroll
     for (int t = 0; t < MTL; ++t)
-      vec_to<KPL>(*reinterpret_cast<const vec_t*>(planes[kd] + ((ch * 4) * S + kh * PW + kw + t * 16 * C::SW) * KPL), bf[buf][t]);
+      lds_frag<KPL>(planes[kd] + ((ch * 4) * S + kh * PW + kw + t * 16 * C::SW) * KPL, bf[buf][t]);
   };
   if constexpr (!C::WREG) {
     // the first fragments of every call are the same: they stay in registers for the whole kernel (wfirst), so a step
@@ -440,7 +455,7 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __a
   auto read_elem = [&](f32x2_t (&v)[16][NV], int kd, int ch, int e) {     // e = j*4 + i: column-major so a column completes every 4 reads
     const int i = e & 3, j = e >> 2;
     float t[KPL];
-    vec_to<KPL>(*reinterpret_cast<const vec_t*>(planes[kd] + ((ch * 4) * S + i * PW + j) * KPL), t);
+    lds_frag<KPL>(planes[kd] + ((ch * 4) * S + i * PW + j) * KPL, t);
 #pragma unroll
     for (int c = 0; c < NV; ++c) v[i * 4 + j][c] = (f32x2_t){t[2 * c], t[2 * c + 1]};
   };
