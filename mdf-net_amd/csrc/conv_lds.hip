@@ -246,7 +246,6 @@ __device__ __forceinline__ void step_mfma(const float* const (&planes)[KD], __am
                                           const float (&wr)[C::WN][C::NT][C::KPL], const float (&wfirst)[2][C::NT][C::KPL],
                                           f32x4 (&acc)[MTL][C::NT]) {
   constexpr int KPL = C::KPL, NCH = C::NCH, NT = C::NT, S = C::S, PW = C::PW;
-  typedef typename VecT<KPL>::type vec_t;
 #pragma unroll
   for (int t = 0; t < MTL; ++t)
 #pragma unroll
@@ -410,7 +409,6 @@ template <typename C, int COUT, int NKD, int ST = 0>
 __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __amdgpu_buffer_rsrc_t wres, int wvoff, const LdsConvParams& p,
                                           int b, int d, int d_lim, int h, int w0, int q, int n16, const float (&wfirst)[2][C::NT][C::KPL]) {
   constexpr int NCH = C::NCH, NTALL = C::NT, NT = C::NTP, S = C::S, PW = C::PW, KPL = C::KPL;
-  typedef typename VecT<KPL>::type vec_t;
   extern __shared__ __attribute__((aligned(16))) float lds_base_[];
   const float* epi_tab = lds_base_ + C::EPI_OFF;
   // Cout > 32: two passes over K with 2 n-tiles each (16 accumulators x 4 n-tiles would be the whole register file); the
