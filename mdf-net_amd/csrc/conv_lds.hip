@@ -17,103 +17,9 @@
 #include <type_traits>
 #include "common.h"
 
+#include "conv_lds_common.h"
+
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct LdsConvParams {
-  const float* x;      // [B,D,H,W,CIN_MEM]
-  const float* wpack;  // conv3d.hip packing (taps = KD*KHW*KHW)
-  const float* alpha;  // [COUT] or null
-  const float* beta;   // [COUT] or null (bias when alpha is null)
-  const float* res;    // [B,D,Ho,Wo,COUT] or null
-  const float* res_up; // [B,D,Ho/2,Wo/2,COUT] or null: bilinear x2 (align_corners=False) of it is added (FPN top-down)
-  float* y;            // [B,D,Ho,Wo,COUT]
-  float res_scale;     // y = res + res_scale * act(...)  (Res block: x + 0.1*conv)
-  int B, D, H, W, Ho, Wo;
-  int relu;
-  int tiles_h, tiles_w, dchunks, dch;  // item space (3-D: tile x depth chunk)
-  int n_items;
-  int n_tiles, tiles_per_item;         // 2-D: an item is a run of consecutive tiles
-  int planar_in;                       // 2-D, CIN_MEM != CIN: input is planar [B,CIN_MEM,H,W] (e.g. the RGB images as they arrive)
-  int sched_slot;                      // which pair of g_sched words this launch uses (one per stream)
-  int shuffle2;                        // 2-D, Cout = 32: write PixelShuffle(2) of the result ([B,2Ho,2Wo,8]); rows packed sub-pixel-major
-  int prefetch_early;                  // 3-D: issue the next plane's loads before (1) or after (0) the MFMA block
-  // training (ST kernels): per-channel sums of the output in the epilogue, see conv3d.hip ConvParams::stat_mode
-  int stat_mode;
-  const float* stat_y;
-  const float* stat_aux;               // [groups][4*COUT]
-  double* stat_out;                    // [groups][2*COUT]
-  int stat_groups;                     // 2-D: BatchNorm groups (consecutive sets of B / groups images); the ST grid is groups x blocks-per-group
-  int stat_slices;                     // slices of stat_out [slices][groups][2C] the blocks are spread over (common.h: conv_stat_send)
-};
-
-// fp64 LDS add and the DPP sum over the 16 lanes that hold the 16 MFMA columns of one 4-channel row group
-__device__ __forceinline__ void lds_add_f64(double* p, double v) { atomicAdd(p, v); }
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov_f(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float row16_sum(float v) {
-  v += dpp_mov_f<0xB1>(v);    // quad_perm [1,0,3,2]
-  v += dpp_mov_f<0x4E>(v);    // quad_perm [2,3,0,1]
-  v += dpp_mov_f<0x141>(v);   // row_half_mirror
-  v += dpp_mov_f<0x140>(v);   // row_mirror
-  return v;
-}
-
-template <int N> struct VecT;
-template <> struct VecT<4> { typedef float4 type; };
-template <> struct VecT<2> { typedef float2 type; };
-template <> struct VecT<1> { typedef float type; };
-
-template <int KPL> __device__ __forceinline__ void vec_to(const typename VecT<KPL>::type& v, float* o);
-template <> __device__ __forceinline__ void vec_to<4>(const float4& v, float* o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
-template <> __device__ __forceinline__ void vec_to<2>(const float2& v, float* o) { o[0] = v.x; o[1] = v.y; }
-template <> __device__ __forceinline__ void vec_to<1>(const float& v, float* o) { o[0] = v; }
-
-// Weight fragments are fetched with BUFFER loads: the address is {SGPR resource, one lane-offset VGPR that never changes,
-// scalar/immediate fragment offset}.  With flat global loads every fragment needed its own 64-bit VGPR address (held in
-// registers or re-added on the VALU): 150-300 address pairs per kernel, the reason the pipelined tap loop sat at its
-// register cap and spilled (scripts/isa_stats.py).
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);   // raw buffer, dword format (gfx9)
-}
-template <int KPL> __device__ __forceinline__ void buf_load_to(__amdgpu_buffer_rsrc_t r, int voff, int soff, float* o);
-template <> __device__ __forceinline__ void buf_load_to<4>(__amdgpu_buffer_rsrc_t r, int voff, int soff, float* o) {
-  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-  o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w);
-}
-template <> __device__ __forceinline__ void buf_load_to<2>(__amdgpu_buffer_rsrc_t r, int voff, int soff, float* o) {
-  const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-  o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y);
-}
-template <> __device__ __forceinline__ void buf_load_to<1>(__amdgpu_buffer_rsrc_t r, int voff, int soff, float* o) {
-  o[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-}
-
-// B-fragment read from LDS.  KPL = 2: hipcc merges two neighbouring 8-byte reads (taps kw, kw+1) into ONE ds_read2_b64, which
-// the LDS serves at half the rate of ds_read_b64 (8 cycles per wave instead of 2 x 2) and banks modulo 32 instead of 64 -- the
-// layouts chosen for ds_read_b64 (round_s) then conflict: SQ_LDS_BANK_CONFLICT was 90 % of the LDS cycles of the 8-channel
-// kernels.  A volatile access is not merged.
-typedef float lds_f2 __attribute__((ext_vector_type(2)));
-template <int KPL> __device__ __forceinline__ void lds_frag(const float* p, float* o) {
-  if constexpr (KPL == 2) {
-    typedef const volatile __attribute__((address_space(3))) lds_f2* lds_ptr;   // (explicitly LDS: a volatile generic access becomes a flat load)
-    const lds_f2 v = *(lds_ptr)(p);
-    o[0] = v.x; o[1] = v.y;
-  } else {
-    vec_to<KPL>(*reinterpret_cast<const typename VecT<KPL>::type*>(p), o);
-  }
-}
-
-template <int KPL> __device__ __forceinline__ typename VecT<KPL>::type vec_zero();
-template <> __device__ __forceinline__ float4 vec_zero<4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-template <> __device__ __forceinline__ float2 vec_zero<2>() { return make_float2(0.f, 0.f); }
-template <> __device__ __forceinline__ float vec_zero<1>() { return 0.f; }
 
 // Dynamic work distribution: per stream slot [0] next item, [1] finished blocks.  Module-level device words (nothing is
 // allocated); the last block of a launch resets both, so every launch starts from zero.  Launches on DIFFERENT streams
@@ -125,187 +31,6 @@ __device__ unsigned g_sched[2 * kSchedSlots];
 __device__ unsigned long long g_stamps[8];   // sched, prologue, compute, refill, total, blocks, items, dsteps
 #define STAMP() __builtin_readcyclecounter()
 #endif
-
-// Plane stride S (in KPL-float vectors per cin group) such that the B-fragment reads of a lane group fall on distinct banks
-// (MI355X LDS: ds_read_b128 is served in 16-lane groups that mix two q rows, ds_read_b64/b32 in 32-lane halves = two q rows;
-// bank = dword address mod 64, mod 32 for b32 and all stores).  A lane reads vector q*S + n16*SW (+ tap shift):
-//  SW = 1: the two q rows of a group must land 16 vectors (KPL 4) / 32 dwords (KPL 2) apart: S % 32 == 16;
-//  SW = 2 (stride-2 layers, w-phase RW = 2, Winograd): each row covers the even slots, so the neighbour row needs an odd S --
-//          with S % 32 == 16 every one of those reads was a 2-way conflict.  Among the odd residues the fill stores (cin group
-//          fastest over 4 groups: vectors g*S + v) are conflict-free for S % 8 == 3 (KPL 4) and nearly so for S % 16 == 5 (KPL 2);
-//  SW = 4 (w-phase RW = 4): a row alone is 2-way (n16 and n16 + 4/8 share banks); S % 4 == 2 keeps the two rows apart (was 4-way).
-constexpr int round_up_mod(int n, int m, int r) { return n + ((r - n % m) + m) % m; }
-constexpr int round_s(int n, int kpl, int sw) {
-  if (sw == 1) return round_up_mod(n, 32, 16);
-  if (sw % 4 == 0) return round_up_mod(n, 4, 2);
-  return kpl == 4 ? round_up_mod(n, 8, 3) : (kpl == 2 ? round_up_mod(n, 16, 5) : round_up_mod(n, 2, 1));
-}
-
-#ifndef EARLY2_MAX_REGS
-#define EARLY2_MAX_REGS 32
-#endif
-// RW > 1 ("w-phase" form, for Cout < 16): an MFMA output tile has 16 rows, so a Cout = 8 (4) layer would waste half
-// (three quarters) of every MFMA.  Instead RW = 2 (4) neighbouring output voxels along w share one MFMA column: GEMM row
-// r*Cout + c is channel c of output voxel RW*m + r, which is the same conv written with stride RW, Cout' = RW*Cout and a
-// kernel of KHW + RW - 1 taps along w (tap kw' of phase r is the original tap kw' - r, zero outside) -- KW' taps serve RW
-// outputs instead of RW*KHW: 4 vs 6 (RW 2), 6 vs 12 (RW 4) MFMAs.  The expanded weights are packed by conv3d.hip.
-//
-// WG = 1 (Winograd form, 3-D stride-1 3x3x3 layers): F(2x2, 3x3) in (h, w), direct in d.  An MFMA column is a 2x2 output
-// tile; per input plane and 16-cin chunk a lane reads its tile's 4x4 patch from LDS, transforms it (B^T d B, 32 adds per
-// channel), and feeds 16 transform-domain GEMMs (one accumulator each); the output transform A^T M A runs in the epilogue.
-// 16 x 3 instead of 9 x 4 x 3 MFMAs per 4 outputs: 2.25x fewer.  fp32 Winograd F(2,3) costs no accuracy here: single-layer
-// error vs fp64 1.1e-6 (direct 1.8e-6), end-to-end depth deviation 3.9-4.4e-4 mm = the floor of any fp32 re-ordering
-// (scripts/study_winograd.py).  Geometry: RW = 2 supplies the w bookkeeping (4-wide patch, stride 2); a wave owns 2 rows.
-//
-// WG = 2 (depth-pair Winograd, 3-D layers with 8 output channels): with Cout = 8 the Winograd GEMMs would fill only half of
-// the 16 MFMA rows.  Here a step produces TWO output planes d, d+1: GEMM row r*8 + c is channel c of plane d + r, and the four
-// input planes d-1 .. d+2 of the step (ring of 4) each meet tap kd = j - r (zero rows where that is outside 0..2).  Every
-// transformed patch feeds both planes: 4 x 16 instead of 2 x 3 x 16 MFMA groups (and 4 instead of 6 patch transforms) per
-// pair of planes, 2.25x fewer MFMAs than the w-phase form.  Also for Cin = 8 (two k-steps per group).
-template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT, int RW = 1, int WG = 0>
-struct Cfg {
-  static_assert(RW == 1 || WG != 0 || (SHW == 1 && COUT * RW <= 16 && COUT % 4 == 0), "w-phase form: stride 1, RW*Cout <= 16, Cout % 4 == 0");
-  static_assert(WG == 0 || ((KD == 3 || KD == 1) && KHW == 3 && SHW == 1 && RW == 2 && MT == 1 && CIN % (WG == 2 ? 8 : 16) == 0 && COUT % 4 == 0), "Winograd form: 3x3(x3) stride 1, RW = 2, MT = 1");
-  static_assert(WG != 2 || (KD == 3 && COUT == 8), "depth-pair Winograd form: 3-D, Cout = 8");
-  static constexpr bool WINO = (WG != 0);
-  static constexpr int RD = (WG == 2) ? 2 : 1;    // output planes per depth step
-  static constexpr int NPL = KD + RD - 1;         // input planes a depth step reads
-  static constexpr int NTP = ((COUT + 15) / 16 > 2) ? 2 : (COUT + 15) / 16;   // Winograd: n-tiles per pass over K (16 accumulators each)
-  static constexpr int CIN_ = CIN;
-  static constexpr int RWF = RW;
-  static constexpr int KW = KHW + RW - 1;       // taps along w
-  static constexpr int SW = SHW * RW;           // input step along w between neighbouring MFMA columns
-  static constexpr int ROWS = WINO ? COUT * RD : COUT * RW;   // GEMM rows
-  static constexpr int KPL = (CIN >= 16) ? 4 : (CIN == 8 ? 2 : 1);
-  static constexpr int CK = 4 * KPL;
-  static constexpr int NCH = CIN / CK;
-  static constexpr int NG = CIN / KPL;  // k-groups per voxel
-  static constexpr int NT = (ROWS + 15) / 16;
-  static constexpr int WROWS = WINO ? 2 : 1;    // output rows per wave
-  static constexpr int TH = 4 * WROWS, TW = 16 * MT;   // tile: TH rows x TW MFMA columns = TW*RW output voxels along w
-  static constexpr int TWO = TW * RW;
-  static constexpr int PAD = (KHW - 1) / 2, PD = (KD - 1) / 2;
-  static constexpr int PH = WINO ? TH + 2 : (TH - 1) * SHW + KHW, PW = (TW - 1) * SW + KW;
-  static constexpr int S = round_s(PH * PW, KPL, SW);
-  static constexpr int PLANE = CIN * S;  // floats
-  static constexpr int NFILL = (NG * PH * PW + 255) / 256;
-  // 3-D: rolling window of KD planes; 2-D: double-buffered tiles -- except the 64-channel Winograd form, whose 10x34 tile
-  // (87 KB) fits once: single buffer, the next tile's loads wait in registers during the (long) compute
-  static constexpr int RING = (KD > 1) ? NPL : ((WINO && CIN >= 64) ? 1 : 2);
-  static constexpr int NSTEP = WINO ? NPL * 16 * NCH : KD * KHW * KW * NCH;   // MFMA pipeline steps per output row-tile (tap x cin chunk)
-  // small layers keep ALL their weight fragments in registers for the whole kernel (<= 40 VGPRs; beyond that occupancy drops and it is a loss, measured) instead of re-fetching
-  // them from L1 for every tile: with 8-16 MFMAs per step there is nothing to hide that round trip behind
-  static constexpr bool WREG = (KD == 1) && !WINO && (NSTEP * NT * KPL <= 40);
-  // epilogue scale/shift hoisted out of the tile loop where registers allow (the 3-D and 4-n-tile kernels sit at their caps)
-  static constexpr bool EPI_REG = (KD == 1) && (NT <= 2);
-  static constexpr int WN = WREG ? NSTEP : 1;
-  // 2-D: issue the next tile's global loads before this tile's MFMAs when the staging registers are cheap
-  static constexpr bool EARLY2 = (KD == 1) && ((!WINO && (NFILL * KPL <= EARLY2_MAX_REGS)) || (WINO && CIN >= 64));
-  // + the broadcast slot of the item id (16 B) + the epilogue table: alpha[64], beta[64] (read per step from LDS instead of
-  // from global memory: the per-call L1/L2 round trip was ~1000 exposed cycles per depth step, in-kernel stamps)
-  static constexpr int EPI_OFF = RING * PLANE + 4;   // floats
-  static constexpr size_t LDS_BYTES = (size_t)RING * PLANE * sizeof(float) + 16 + 128 * sizeof(float);
-  // ST kernels: + fp64 sums [2][64] + the producing layer's (a, b, mean, invstd) [4][64]
-  static constexpr int STAT_OFF = EPI_OFF + 128, SAUX_OFF = STAT_OFF + 256;   // floats (STAT_OFF*4 is a multiple of 8)
-  static constexpr size_t LDS_BYTES_ST = LDS_BYTES + 512 * sizeof(float);
-};
-
-// ST epilogue: the lane's 4 output values o[] of channels c0.. at output index oi -> its running sums (ps, pq)
-template <typename C, int ST>
-__device__ __forceinline__ void stat_accum(const LdsConvParams& p, const float* lds_base, size_t oi, int c0, const float (&o)[4],
-                                           float (&ps)[4], float (&pq)[4]) {
-  if constexpr (ST == 1) {     // (the two modes are separate instantiations: together they cost the 2-D kernels an occupancy step)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { ps[k] += o[k]; pq[k] = fmaf(o[k], o[k], pq[k]); }
-  } else {
-    const float* ax = lds_base + C::SAUX_OFF;
-    const float4 yv4 = *reinterpret_cast<const float4*>(p.stat_y + oi);
-    const float yv[4] = {yv4.x, yv4.y, yv4.z, yv4.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float dr = (fmaf(yv[k], ax[c0 + k], ax[64 + c0 + k]) > 0.0f) ? o[k] : 0.0f;
-      ps[k] += dr;
-      pq[k] = fmaf(dr, (yv[k] - ax[128 + c0 + k]) * ax[192 + c0 + k], pq[k]);
-    }
-  }
-}
-template <typename C>
-__device__ __forceinline__ void stat_commit(float* lds_base, int c0, int n16, const float (&ps)[4], const float (&pq)[4]) {
-  double* tab = reinterpret_cast<double*>(lds_base + C::STAT_OFF);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float a1 = row16_sum(ps[k]), a2 = row16_sum(pq[k]);
-    if (n16 == 0) { lds_add_f64(&tab[c0 + k], (double)a1); lds_add_f64(&tab[64 + c0 + k], (double)a2); }
-  }
-}
-
-// The MFMA part of one output row-tile of one depth plane: MTL live m-tiles (16 voxels each) x all GEMM rows, accumulated into
-// acc (zeroed here).  Fully unrolled over the taps: LDS offsets are immediates, no bounds logic (halos are zero-filled in LDS).
-template <typename C, int KD, int KHW, int MTL>
-__device__ __forceinline__ void step_mfma(const float* const (&planes)[KD], __amdgpu_buffer_rsrc_t wres, int wvoff,
-                                          const float (&wr)[C::WN][C::NT][C::KPL], const float (&wfirst)[2][C::NT][C::KPL],
-                                          f32x4 (&acc)[MTL][C::NT]) {
-  constexpr int KPL = C::KPL, NCH = C::NCH, NT = C::NT, S = C::S, PW = C::PW;
-#pragma unroll
-  for (int t = 0; t < MTL; ++t)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // Software pipeline over the flattened (kd,kh,kw,chunk) steps.  hipcc otherwise places every operand load right
-  // before its MFMAs (prefetch distance <= 1), leaving the matrix pipe idle for an L1/L2 round trip per step.
-  // Weight fragments (global, L1-resident) run AHEAD_A steps ahead, LDS activation fragments one step ahead; the
-  // order is pinned with sched_barrier, the counted s_waitcnt is left to the compiler.
-  constexpr int NSTEP = C::NSTEP;
-  constexpr int AHEAD_A = (NSTEP >= 3) ? 2 : (NSTEP - 1 > 0 ? NSTEP - 1 : 0);
-  constexpr int NA = AHEAD_A + 1;
-  float af[NA][NT][KPL], bf[2][MTL][KPL];
-  auto load_a = [&](int i, int buf) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-      buf_load_to<KPL>(wres, wvoff, (i * NT + nt) * (64 * KPL * 4), af[buf][nt]);
-  };
-  auto load_b = [&](int i, int buf) {
-    const int ch = i % NCH, tap = i / NCH;
-    const int kw = tap % C::KW, kh = (tap / C::KW) % KHW, kd = tap / (KHW * C::KW);
-#pragma unroll
-    for (int t = 0; t < MTL; ++t)
-      lds_frag<KPL>(planes[kd] + ((ch * 4) * S + kh * PW + kw + t * 16 * C::SW) * KPL, bf[buf][t]);
-  };
-  if constexpr (!C::WREG) {
-    // the first fragments of every call are the same: they stay in registers for the whole kernel (wfirst), so a step
-    // does not begin with an exposed L1/L2 round trip
-#pragma unroll
-    for (int i = 0; i < AHEAD_A; ++i) {
-      if (i < 2) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int k = 0; k < KPL; ++k) af[i % NA][nt][k] = wfirst[i][nt][k];
-      } else {
-        load_a(i, i % NA);
-      }
-    }
-  }
-  load_b(0, 0);
-#pragma unroll
-  for (int i = 0; i < NSTEP; ++i) {
-    if constexpr (!C::WREG) {
-      if (i + AHEAD_A < NSTEP) load_a(i + AHEAD_A, (i + AHEAD_A) % NA);
-    }
-    if (i + 1 < NSTEP) load_b(i + 1, (i + 1) & 1);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < KPL; ++s)
-#pragma unroll
-      for (int t = 0; t < MTL; ++t)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const float a = C::WREG ? wr[C::WREG ? i : 0][nt][s] : af[i % NA][nt][s];
-          acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[i & 1][t][s], acc[t][nt], 0, 0, 0);
-        }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
 
 // One output row-tile of one depth plane: the MFMAs above, then the epilogue.
 template <typename C, int KD, int KHW, int SHW, int COUT, int MTL, int ST = 0>
@@ -1035,332 +760,7 @@ int launch_lds(LdsConvParams& p, hipStream_t st) {
   return mdf::check_launch("conv_lds_kernel");
 }
 
-// ---- `prob` head in one launch (regular.py:66-69,129-133 + regress.py:5-7) -------------------------------------------------
-// logit[d] = P0[d-1] + P1[d] + P2[d+1], P_kd[z] = the 2-D (kh, kw, cin) contraction of input plane z with the kd-th slice of
-// the 3x3x3 kernel (prob_head.hip).  The two-launch route runs the partials as a 4-channel 2-D conv over the B*D planes
-// (Cfg<Cin,Cin,4,1,3,1,1,4>: 4 pixels along w per MFMA column, GEMM row = phase*4 + kd) and writes / re-reads them: 16 B per
-// voxel each way next to the 4*Cin B the layer has to read.  Here a block owns ONE 4 x 64 pixel tile and walks the depth axis
-// with that same MFMA step: a lane's accumulator is (P0, P1, P2, 0) of its pixel, the two-plane delay line and the running
-// maximum live in registers, the D logits of a pixel wait in LDS (own column: no barrier; parked in global memory the two
-// normalisation passes were a chain of D dependent L2 round trips per thread) and `prob` is written once.  Same partial sums, same combine / softmax / soft-argmin arithmetic and order as conv + prob_from_partials:
-// bit-identical results, 2/3 of the traffic.  (Parallelism is spatial only: tiles = B*ceil(h/4)*ceil(w/64) -- the caller keeps
-// the two-launch route for maps too small to fill the chip.)
-struct ProbParams {
-  const float* x;       // [B*D][H][W][CIN]
-  const float* wpack;   // w-phase segment of pack_conv2d_weight([kd (+ zero), cin, 3, 3])
-  const float* hypos;   // [B,D] or [B,D,H,W] or null
-  int per_pixel;
-  float* prob;          // [B,D,H,W]
-  float* depth;         // [B,H,W] or null
-  int B, D, H, W, tiles_h, tiles_w;
-};
-
-// the w-phase configuration of the partial-sum conv with a tile of NW rows (one per wave).  NW = 8 re-reads less halo
-// ((NW + 2) / NW rows) but halves the blocks: 68 vs 69 us at 8x592x800, 108 vs 72 us at 24x296x400 -- 4 it is
-template <int CIN, int NW>
-struct ProbCfg : Cfg<CIN, CIN, 4, 1, 3, 1, 1, 4> {
-  typedef Cfg<CIN, CIN, 4, 1, 3, 1, 1, 4> Base;
-  static constexpr int TH = NW, PH = NW + 2;
-  static constexpr int S = round_s(PH * Base::PW, Base::KPL, Base::SW);
-  static constexpr int PLANE = CIN * S;
-  static constexpr int NTHR = 64 * NW;
-  static constexpr int NFILL = (Base::NG * PH * Base::PW + NTHR - 1) / NTHR;
-};
-
-template <int CIN, int NW>
-__global__ __launch_bounds__(64 * NW) void prob_fused_kernel(const ProbParams p) {
-  typedef ProbCfg<CIN, NW> C;
-  constexpr int KPL = C::KPL, NG = C::NG, S = C::S, PW = C::PW, PH = C::PH, NTHR = C::NTHR;
-  typedef typename VecT<KPL>::type vec_t;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q = lane >> 4, n16 = lane & 15;
-  const __amdgpu_buffer_rsrc_t wres = make_rsrc(p.wpack, (unsigned)(C::NSTEP * C::NT * 64 * KPL * 4));
-  const int wvoff = lane * KPL * 4;
-  const int lane_lds = (q * S + wave * PW + n16 * C::SW) * KPL;
-  float wfirst[2][C::NT][KPL], wr[C::WN][C::NT][KPL];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    if constexpr (!C::WREG) buf_load_to<KPL>(wres, wvoff, i * (64 * KPL * 4), wfirst[i][0]);
-    else {
-#pragma unroll
-      for (int k = 0; k < KPL; ++k) wfirst[i][0][k] = 0.f;
-    }
-  }
-  if constexpr (C::WREG) {
-#pragma unroll
-    for (int i = 0; i < C::NSTEP; ++i) buf_load_to<KPL>(wres, wvoff, i * (64 * KPL * 4), wr[i][0]);
-  } else {
-#pragma unroll
-    for (int k = 0; k < KPL; ++k) wr[0][0][k] = 0.f;
-  }
-  int sp = blockIdx.x;
-  const int twi = sp % p.tiles_w; sp /= p.tiles_w;
-  const int th = sp % p.tiles_h;
-  const int b = sp / p.tiles_h;
-  const int th0 = th * C::TH, tw0 = twi * C::TWO;
-
-  // plane tile -> LDS: the mapping of conv_lds_kernel's 2-D path (cin group fastest: coalesced 16-B pieces)
-  constexpr int GF2 = (NG < 4) ? NG : 4;
-  auto split2 = [&](int idx, int& v, int& g) {
-    const int glo = idx % GF2, r = idx / GF2;
-    v = r % (PH * PW);
-    g = (r / (PH * PW)) * GF2 + glo;
-  };
-  auto load2 = [&](int idx, int d) -> vec_t {
-    int g, v;
-    split2(idx, v, g);
-    const int row = v / PW, col = v - row * PW;
-    const int ih = th0 - 1 + row, iw = tw0 - 1 + col;
-    if (idx >= NG * PH * PW || ih < 0 || ih >= p.H || iw < 0 || iw >= p.W) return vec_zero<KPL>();
-    return *reinterpret_cast<const vec_t*>(p.x + ((((size_t)b * p.D + d) * p.H + ih) * p.W + iw) * CIN + g * KPL);
-  };
-  auto store2 = [&](int idx, int slot, const vec_t& val) {
-    if (idx < NG * PH * PW) {
-      int g, v;
-      split2(idx, v, g);
-      *reinterpret_cast<vec_t*>(lds + slot * C::PLANE + (g * S + v) * KPL) = val;
-    }
-  };
-#pragma unroll
-  for (int k = 0; k < C::NFILL; ++k) store2(tid + k * NTHR, 0, load2(tid + k * NTHR, 0));
-  __syncthreads();
-
-  // this lane's pixel: row th0 + wave, column tw0 + 4*n16 + q (GEMM rows 4q..4q+3 = phase q, channels P0 P1 P2 0)
-  const int oh = th0 + wave, ow = tw0 + 4 * n16 + q;
-  const bool row_live = oh < p.H;
-  const bool live = row_live && ow < p.W;
-  const size_t hw = (size_t)p.H * p.W;
-  const size_t pix = live ? (size_t)oh * p.W + ow : 0;
-  float* pr = p.prob + (size_t)b * p.D * hw + pix;
-  float* lg = lds + 2 * C::PLANE + tid;   // [D][NTHR]: this thread's logits
-  float carry1 = 0.f, carry0 = 0.f;   // P0[d-1] + P1[d] (awaiting P2[d+1]);  P0[d] (feeds logit[d+1])
-  float mx = -INFINITY;
-  for (int d = 0; d < p.D; ++d) {
-    const int slot = d & 1;
-    const bool more = d + 1 < p.D;
-    vec_t pf[C::NFILL];
-    if (more) {
-#pragma unroll
-      for (int k = 0; k < C::NFILL; ++k) pf[k] = load2(tid + k * NTHR, d + 1);
-    }
-    if (row_live) {
-      const float* planes[1] = {lds + slot * C::PLANE + lane_lds};
-      f32x4 acc[1][C::NT];
-      step_mfma<C, 1, 3, 1>(planes, wres, wvoff, wr, wfirst, acc);
-      const float done = carry1 + acc[0][0][2];      // logit[d-1] complete
-      if (d >= 1) { lg[(d - 1) * NTHR] = done; mx = fmaxf(mx, done); }
-      carry1 = carry0 + acc[0][0][1];
-      carry0 = acc[0][0][0];
-    }
-    if (more) {
-#pragma unroll
-      for (int k = 0; k < C::NFILL; ++k) store2(tid + k * NTHR, slot ^ 1, pf[k]);
-      __syncthreads();
-    }
-  }
-  if (!live) return;
-  lg[(p.D - 1) * NTHR] = carry1;
-  mx = fmaxf(mx, carry1);
-  float sum = 0.f;
-  for (int d = 0; d < p.D; ++d) {
-    const float e = expf(lg[d * NTHR] - mx);
-    lg[d * NTHR] = e;
-    sum += e;
-  }
-  mdf::CascadeSum dep;   // regress.py:5-7 with ATen's summation order
-  for (int d = 0; d < p.D; ++d) {
-    const float pv = lg[d * NTHR] / sum;
-    pr[(size_t)d * hw] = pv;
-    if (p.depth) dep.add(pv * (p.per_pixel ? p.hypos[((size_t)b * p.D + d) * hw + pix] : p.hypos[(size_t)b * p.D + d]));
-  }
-  if (p.depth) p.depth[(size_t)b * hw + pix] = dep.result();
-}
-
-template <int CIN, int NW>
-int launch_prob_fused(ProbParams& p, hipStream_t st) {
-  typedef ProbCfg<CIN, NW> C;
-  const size_t kLds = ((size_t)2 * C::PLANE + (size_t)p.D * C::NTHR) * sizeof(float);
-  if (kLds > 160 * 1024) return mdf::fail(MDF_EUNSUPPORTED, "fused prob head: D=%d does not fit the LDS (use the two-launch route)", p.D);
-  p.tiles_h = (p.H + C::TH - 1) / C::TH;
-  p.tiles_w = (p.W + C::TWO - 1) / C::TWO;
-  const long long tiles = (long long)p.B * p.tiles_h * p.tiles_w;
-  if (tiles > 0x7fffffff) return mdf::fail(MDF_EARG, "prob head: too many tiles");
-  static bool attr_done_dev[64] = {};   // (the attribute is set to the device maximum once: the size depends on D)
-  int dev_id = 0;
-  (void)hipGetDevice(&dev_id);
-  bool& attr_done = attr_done_dev[(dev_id >= 0 && dev_id < 64) ? dev_id : 0];
-  if (!attr_done || dev_id >= 64) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prob_fused_kernel<CIN, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return mdf::fail(MDF_EHIP, "hipFuncSetAttribute(dynamic LDS): %s", hipGetErrorString(e));
-    attr_done = true;
-  }
-  hipLaunchKernelGGL((prob_fused_kernel<CIN, NW>), dim3((unsigned)tiles), dim3(C::NTHR), kLds, st, p);
-  return mdf::check_launch("prob_fused_kernel");
-}
-
 }  // namespace
-
-extern "C" int mdf_prob_fused_fwd(const float* x, const float* wpack, const float* hypos, int hypos_per_pixel, float* prob, float* depth,
-                                  int B, int D, int h, int wd, int Cin, void* stream) {
-  MDF_REQUIRE(x && wpack && prob, "null pointer argument");
-  MDF_REQUIRE(depth == nullptr || hypos != nullptr, "depth output needs hypos");
-  MDF_REQUIRE(B > 0 && D > 0 && h > 0 && wd > 0, "bad shape");
-  MDF_REQUIRE((long long)B * D * h * wd * Cin < (1ll << 31), "input too large for 32-bit offsets");
-  ProbParams p{};
-  p.x = x; p.hypos = hypos; p.per_pixel = hypos_per_pixel; p.prob = prob; p.depth = depth; p.B = B; p.D = D; p.H = h; p.W = wd;
-  p.wpack = wpack + (size_t)9 * Cin * 16;      // behind the plain fragments (conv3d.hip pack_segments), as LDS_CASE_RW reads them
-  if (Cin == 8) return launch_prob_fused<8, 4>(p, (hipStream_t)stream);
-  if (Cin == 16) return launch_prob_fused<16, 4>(p, (hipStream_t)stream);
-  return mdf::fail(MDF_EUNSUPPORTED, "fused prob head is built for Cin in {8,16}, got %d", Cin);
-}
-
-// ---- tail of the refinement net as one launch (refine.py:18-20,42-44) ---------------------------------------------------------
-//   Conv2d(8, 32, k3) -> PixelShuffle(2) -> Conv2d(8, 1, k3) [-> lo + y * span]
-// As two launches the 8-channel map at twice the resolution (60 MB at 1184 x 1600) is written and read back, and the 8 -> 1
-// layer runs on the matrix cores with ONE live GEMM row in sixteen.  Here a block owns 8 x 30 low-resolution pixels: it stages
-// their 12 x 34 input neighbourhood in LDS, computes the 8 -> 32 layer on 10 x 32 pixels with the MFMA step of the single-layer
-// kernel (same packed weights, PixelShuffle as the row order), writes the 18 x 64 x 8 shuffled block (zero outside the image:
-// the second layer's padding) to LDS, and finishes with the 8 -> 1 layer on the vector ALUs (72 FMAs per output, weights as
-// scalar operands, a column per lane so every LDS read is conflict-free and every store is a contiguous row).
-namespace {
-
-struct TailParams {
-  const float* x;      // [B,H,W,8]
-  const float* w1;     // pack_conv2d_weight(shuffle2_rows(conv[0].weight)): plain fragments [9][nt 2][64][2]
-  const float* w2;     // conv[2].weight [1,8,3,3]
-  const float* lo;     // [B] or null: y = lo + y * span (torch's roundings)
-  const float* span;
-  float* y;            // [B,2H,2W]
-  int B, H, W, tiles_h, tiles_w;
-};
-
-struct TailCfg : Cfg<8, 8, 32, 1, 3, 1, 2> {
-  typedef Cfg<8, 8, 32, 1, 3, 1, 2> Base;
-  static constexpr int LR_H = 8, LR_W = 30;          // low-resolution pixels a block owns (10 or 12 rows: 58 us against 54 at 592 x 800, two blocks per CU instead of three)
-  static constexpr int CR = LR_H + 2;                // rows of the first layer it computes (one halo row each side); 32 columns
-  static constexpr int PH = CR + 2;                  // input rows staged; Base::PW = 34 columns
-  static constexpr int S = round_s(PH * Base::PW, Base::KPL, Base::SW);
-  static constexpr int PLANE = 8 * S;
-  static constexpr int NFILL = (Base::NG * PH * Base::PW + 255) / 256;
-  static constexpr int MID_ROWS = 2 * LR_H + 2, MID_COLS = 64;   // shuffled block: rows 2*r0-1 .., columns 2*c0-2 ..; [half][row][col] float4
-  static constexpr int MID_FLOATS = 2 * MID_ROWS * MID_COLS * 4;
-  static_assert(Base::WREG, "the first layer's weights are expected to fit the registers");
-};
-
-__global__ __launch_bounds__(256, 3) void refine_tail_kernel(const TailParams p) {
-  typedef TailCfg C;
-  constexpr int KPL = C::KPL, NG = C::NG, S = C::S, PW = C::PW, PH = C::PH;
-  typedef typename VecT<KPL>::type vec_t;
-  __shared__ __attribute__((aligned(16))) float in_img[C::PLANE];
-  __shared__ __attribute__((aligned(16))) float mid[C::MID_FLOATS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q = lane >> 4, n16 = lane & 15;
-  int bid = blockIdx.x;
-  const int twi = bid % p.tiles_w; bid /= p.tiles_w;
-  const int th = bid % p.tiles_h;
-  const int b = bid / p.tiles_h;
-  const int r0 = th * C::LR_H, c0 = twi * C::LR_W;
-
-  // input neighbourhood rows r0-2 .., columns c0-2 ..  (cin group fastest: coalesced 32-B pixels)
-#pragma unroll
-  for (int k = 0; k < C::NFILL; ++k) {
-    const int idx = tid + k * 256;
-    if (idx < NG * PH * PW) {
-      const int g = idx % NG, v = idx / NG;
-      const int row = v / PW, col = v - row * PW;
-      const int ih = r0 - 2 + row, iw = c0 - 2 + col;
-      vec_t val = vec_zero<KPL>();
-      if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) val = *reinterpret_cast<const vec_t*>(p.x + (((size_t)b * p.H + ih) * p.W + iw) * 8 + g * KPL);
-      *reinterpret_cast<vec_t*>(in_img + (g * S + v) * KPL) = val;
-    }
-  }
-  const __amdgpu_buffer_rsrc_t wres = make_rsrc(p.w1, (unsigned)(C::NSTEP * C::NT * 64 * KPL * 4));
-  const int wvoff = lane * KPL * 4;
-  float wr[C::WN][C::NT][KPL], wfirst[2][C::NT][KPL];
-#pragma unroll
-  for (int i = 0; i < C::NSTEP; ++i)
-#pragma unroll
-    for (int nt = 0; nt < C::NT; ++nt) buf_load_to<KPL>(wres, wvoff, (i * C::NT + nt) * (64 * KPL * 4), wr[i][nt]);
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int nt = 0; nt < C::NT; ++nt)
-#pragma unroll
-      for (int k = 0; k < KPL; ++k) wfirst[i][nt][k] = 0.f;
-  __syncthreads();
-
-  // layer 1 on rows r0-1 .. r0+8, columns c0-1 .. c0+30; PixelShuffle(2) into `mid`
-  for (int rr = wave; rr < C::CR; rr += 4) {
-    const float* planes[1] = {in_img + (q * S + rr * PW + n16) * KPL};
-    f32x4 acc[2][C::NT];
-    step_mfma<C, 1, 3, 2>(planes, wres, wvoff, wr, wfirst, acc);
-    const int lr = r0 - 1 + rr;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int nt = 0; nt < C::NT; ++nt) {
-        const int row0 = nt * 16 + 4 * q;                 // GEMM row = sub*8 + oc, sub = dy*2 + dx
-        const int sub = row0 >> 3, oc0 = row0 & 7;
-        const int lc = c0 - 1 + t * 16 + n16;
-        const int hy = 2 * lr + (sub >> 1), hx = 2 * lc + (sub & 1);
-        const int my = hy - (2 * r0 - 1), mxx = hx - (2 * c0 - 2);
-        if (my < 0 || my >= C::MID_ROWS) continue;        // (the outermost computed rows have one sub-row nobody reads)
-        const bool in = hy >= 0 && hy < 2 * p.H && hx >= 0 && hx < 2 * p.W;
-        const float4 v = in ? make_float4(acc[t][nt][0], acc[t][nt][1], acc[t][nt][2], acc[t][nt][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(mid + (((oc0 >> 2) * C::MID_ROWS + my) * C::MID_COLS + mxx) * 4) = v;
-      }
-  }
-  __syncthreads();
-
-  // layer 2: lane = output column 2*c0 + tx, rows 2*r0 + RPT*ty .. +RPT-1; out row o reads mid rows o..o+2, out column tx reads mid columns tx+1..tx+3
-  constexpr int RPT = (2 * C::LR_H + 3) / 4;
-  const int tx = tid & 63, ty = tid >> 6;
-  if (tx >= 2 * C::LR_W) return;
-  const int hx = 2 * c0 + tx;
-  if (hx >= 2 * p.W) return;
-  const float l = p.lo ? p.lo[b] : 0.f, sp = p.lo ? p.span[b] : 1.f;
-#pragma unroll 1      // (unrolled, hipcc hoists all 36 LDS reads of the four rows: 224 registers, two blocks per CU instead of three)
-  for (int j = 0; j < RPT; ++j) {
-    const int orow = RPT * ty + j, hy = 2 * r0 + orow;
-    if (orow >= 2 * C::LR_H || hy >= 2 * p.H) break;
-    float o = 0.f;
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const float* row = mid + ((hf * C::MID_ROWS + orow + kh) * C::MID_COLS + tx + 1) * 4;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const float4 v = *reinterpret_cast<const float4*>(row + kw * 4);
-          const float* w = p.w2 + (hf * 4) * 9 + kh * 3 + kw;     // weight [c][kh][kw], c = 4*hf + i
-          o = fmaf(v.x, w[0], o);
-          o = fmaf(v.y, w[9], o);
-          o = fmaf(v.z, w[18], o);
-          o = fmaf(v.w, w[27], o);
-        }
-      }
-    p.y[((size_t)b * 2 * p.H + hy) * (2 * p.W) + hx] = p.lo ? __fadd_rn(l, __fmul_rn(o, sp)) : o;
-  }
-}
-
-}  // namespace
-
-extern "C" int mdf_refine_tail_fwd(const float* x, const float* w1pack, const float* w2, const float* lo, const float* span, float* y,
-                                   int B, int H, int W, void* stream) {
-  MDF_REQUIRE(x && w1pack && w2 && y, "null pointer argument");
-  MDF_REQUIRE((lo == nullptr) == (span == nullptr), "lo and span must both be given or both be NULL");
-  MDF_REQUIRE(B > 0 && H > 0 && W > 0, "bad shape");
-  MDF_REQUIRE((long long)B * H * W * 8 < (1ll << 31), "input too large for 32-bit offsets");
-  TailParams p{};
-  p.x = x; p.w1 = w1pack; p.w2 = w2; p.lo = lo; p.span = span; p.y = y; p.B = B; p.H = H; p.W = W;
-  p.tiles_h = (H + TailCfg::LR_H - 1) / TailCfg::LR_H;
-  p.tiles_w = (W + TailCfg::LR_W - 1) / TailCfg::LR_W;
-  const long long blocks = (long long)B * p.tiles_h * p.tiles_w;
-  MDF_REQUIRE(blocks < (1ll << 31), "too many blocks");
-  hipLaunchKernelGGL(refine_tail_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
-  return mdf::check_launch("refine_tail_kernel");
-}
 
 #ifdef MDF_STAMPS
 extern "C" int mdf_debug_read_stamps(unsigned long long* out8, int reset) {
