@@ -130,34 +130,24 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // ---- Winograd form (Cfg::WINO) ---------------------------------------------------------------------------------
 // Weight fragments (pack_weights_wino_kernel, conv3d.hip): [kd][chunk][ab = a*4+b][nt][lane][4], U = G g_kd G^T.
-template <typename C, int COUT, int NKD, int ST = 0>
-__device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __amdgpu_buffer_rsrc_t wres, int wvoff, const LdsConvParams& p,
-                                          int b, int d, int d_lim, int h, int w0, int q, int n16, const float (&wfirst)[2][C::NT][C::KPL]) {
-  constexpr int NCH = C::NCH, NTALL = C::NT, NT = C::NTP, S = C::S, PW = C::PW, KPL = C::KPL;
-  extern __shared__ __attribute__((aligned(16))) float lds_base_[];
-  const float* epi_tab = lds_base_ + C::EPI_OFF;
-  // Cout > 32: two passes over K with 2 n-tiles each (16 accumulators x 4 n-tiles would be the whole register file); the
-  // patch is re-read and re-transformed per pass, which costs ~15 % of a pass
-#pragma unroll 1
-  for (int pass = 0; pass < NTALL / NT; ++pass) {
-  f32x4 acc[16][NT];
-#pragma unroll
-  for (int ab = 0; ab < 16; ++ab)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[ab][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  constexpr int NF = NKD * NCH * 16;        // (kd, chunk, ab) steps
 #ifndef MDF_WG_AHEAD
 #define MDF_WG_AHEAD 2
 #endif
+// The transform-domain MFMAs of the planes J0 .. J0+NKD-1 of a step's window (planes[] holds those), added to acc.
+template <typename C, int J0, int NKD>
+__device__ __forceinline__ void wino_accumulate(const float* const (&planes)[NKD], __amdgpu_buffer_rsrc_t wres, int wvoff, int pass,
+                                                f32x4 (&acc)[16][C::NTP], const float (&wfirst)[2][C::NT][C::KPL]) {
+  constexpr int NCH = C::NCH, NTALL = C::NT, NT = C::NTP, S = C::S, PW = C::PW, KPL = C::KPL;
+  constexpr int NF = NKD * NCH * 16;        // (kd, chunk, ab) steps of this call; fragment J0*NCH*16 + i of the packed weights
   constexpr int AHEAD = MDF_WG_AHEAD, NA = AHEAD + 1;
   float af[NA][NT][KPL];
   auto load_a = [&](int i, int buf) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) buf_load_to<KPL>(wres, wvoff, (i * NTALL + pass * NT + nt) * (64 * KPL * 4), af[buf][nt]);
+    for (int nt = 0; nt < NT; ++nt) buf_load_to<KPL>(wres, wvoff, ((J0 * NCH * 16 + i) * NTALL + pass * NT + nt) * (64 * KPL * 4), af[buf][nt]);
   };
 #pragma unroll
   for (int i = 0; i < AHEAD; ++i) {
-    if (i < 2 && pass == 0 && C::CIN_ < 64) {   // (pass 0 starts with the kernel-resident fragments; not kept for 64 channels: registers)
+    if (J0 == 0 && i < 2 && pass == 0 && C::CIN_ < 64) {   // (pass 0 starts with the kernel-resident fragments; not kept for 64 channels: registers)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -173,7 +163,7 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __a
   // land, and its column pass runs row by row right before the four MFMA steps that need that row.
   // (64 channels: two passes x 128 accumulator registers leave no room for the second patch buffer; the 16-channel depth-pair
   // form keeps a ring of 4 planes = 94 KB, one block per CU as well)
-  constexpr bool PIPE = (C::CIN_ >= 32 && C::CIN_ < 64) || (C::RD == 2 && C::CIN_ >= 16);
+  constexpr bool PIPE = (C::CIN_ >= 32 && C::CIN_ < 64) || (C::RD == 2 && C::CIN_ >= 16 && !C::STREAM);
   constexpr int NV = KPL / 2;                                              // packed pairs of input channels per lane
   auto read_elem = [&](f32x2_t (&v)[16][NV], int kd, int ch, int e) {     // e = j*4 + i: column-major so a column completes every 4 reads
     const int i = e & 3, j = e >> 2;
@@ -249,7 +239,15 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __a
       if constexpr (more) row_pass(vbuf[nxt], 3);                                     // last column (its reads were issued at steps 12..15)
     });
   }
-  // epilogue: Y = A^T M A per cout, A^T = [1 1 1 0; 0 1 -1 -1]; outputs (h + pr, w0 + 2*n16 + r)
+}
+
+// Output transform and epilogue of the accumulators: Y = A^T M A per cout, A^T = [1 1 1 0; 0 1 -1 -1]; outputs (h + pr, w0 + 2*n16 + r)
+template <typename C, int COUT, int ST>
+__device__ __forceinline__ void wino_epilogue(const f32x4 (&acc)[16][C::NTP], int pass, const LdsConvParams& p, int b, int d, int d_lim, int h,
+                                              int w0, int q, int n16) {
+  constexpr int NT = C::NTP;
+  extern __shared__ __attribute__((aligned(16))) float lds_base_[];
+  const float* epi_tab = lds_base_ + C::EPI_OFF;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int row0 = (pass * NT + nt) * 16 + 4 * q;
@@ -308,7 +306,24 @@ __device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __a
     }
     if constexpr (ST != 0) stat_commit<C>(lds_base_, c0, n16, ps, pq);
   }
-  }  // pass
+}
+
+// Weight fragments (pack_weights_wino_kernel, conv3d.hip): [kd][chunk][ab = a*4+b][nt][lane][4], U = G g_kd G^T.
+template <typename C, int COUT, int NKD, int ST = 0>
+__device__ __forceinline__ void step_wino(const float* const (&planes)[NKD], __amdgpu_buffer_rsrc_t wres, int wvoff, const LdsConvParams& p,
+                                          int b, int d, int d_lim, int h, int w0, int q, int n16, const float (&wfirst)[2][C::NT][C::KPL]) {
+  // Cout > 32: two passes over K with 2 n-tiles each (16 accumulators x 4 n-tiles would be the whole register file); the
+  // patch is re-read and re-transformed per pass, which costs ~15 % of a pass
+#pragma unroll 1
+  for (int pass = 0; pass < C::NT / C::NTP; ++pass) {
+    f32x4 acc[16][C::NTP];
+#pragma unroll
+    for (int ab = 0; ab < 16; ++ab)
+#pragma unroll
+      for (int nt = 0; nt < C::NTP; ++nt) acc[ab][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    wino_accumulate<C, 0, NKD>(planes, wres, wvoff, pass, acc, wfirst);
+    wino_epilogue<C, COUT, ST>(acc, pass, p, b, d, d_lim, h, w0, q, n16);
+  }
 }
 
 template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT, int RW = 1, int WG = 0, int ST = 0>
@@ -579,6 +594,56 @@ __global__ __launch_bounds__(256, (WG == 2 && CIN == 8) ? MDF_WD8_BLOCKS : (ST !
     constexpr int NPL = C::NPL, RD = C::RD;
     auto slot_of = [](int dz) { return (KD == 1) ? 0 : ((dz % C::RING) + C::RING) % C::RING; };
 
+    if constexpr (C::STREAM) {
+      // ---- depth-pair form on a ring of three planes (Cfg::STREAM): per pair of output planes d, d+1
+      //   planes d-1, d, d+1 resident -> their MFMAs (plane d+2 in flight) | barrier, d+2 -> slot of d-1, barrier |
+      //   MFMAs of plane d+2, output transform, stores (plane d+3 in flight) | barrier, d+3 -> slot of d, barrier
+      vec_t pro[KD][C::NFILL];
+#pragma unroll
+      for (int j = 0; j < KD; ++j)
+#pragma unroll
+        for (int k = 0; k < C::NFILL; ++k) pro[j][k] = load_elem(tid + k * 256, d0 - 1 + j);
+#pragma unroll
+      for (int j = 0; j < KD; ++j)
+#pragma unroll
+        for (int k = 0; k < C::NFILL; ++k) store_elem(tid + k * 256, slot_of(d0 - 1 + j), pro[j][k]);
+      __syncthreads();
+      for (int d = d0; d < d1; d += 2) {
+        vec_t pf[C::NFILL];
+#pragma unroll
+        for (int k = 0; k < C::NFILL; ++k) pf[k] = load_elem(tid + k * 256, d + 2);
+        f32x4 acc[16][C::NTP];
+#pragma unroll
+        for (int ab = 0; ab < 16; ++ab) acc[ab][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (mt_live > 0) {
+          const float* pa[3];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) pa[j] = lds + slot_of(d - 1 + j) * C::PLANE + lane_lds;
+          wino_accumulate<C, 0, 3>(pa, wres, wvoff, 0, acc, wfirst);
+        }
+        __syncthreads();   // every wave is past plane d-1
+#pragma unroll
+        for (int k = 0; k < C::NFILL; ++k) store_elem(tid + k * 256, slot_of(d + 2), pf[k]);
+        __syncthreads();
+        const bool more = d + 2 < d1;
+        if (more) {
+#pragma unroll
+          for (int k = 0; k < C::NFILL; ++k) pf[k] = load_elem(tid + k * 256, d + 3);
+        }
+        if (mt_live > 0) {
+          const float* pb[1] = {lds + slot_of(d + 2) * C::PLANE + lane_lds};
+          wino_accumulate<C, 3, 1>(pb, wres, wvoff, 0, acc, wfirst);
+          wino_epilogue<C, COUT, ST>(acc, 0, p, b, d, d1, h0 + 2 * wave, w0, q, n16);
+        }
+        if (more) {
+          __syncthreads();   // every wave is past plane d (read in the first half only, but it shares the barrier)
+#pragma unroll
+          for (int k = 0; k < C::NFILL; ++k) store_elem(tid + k * 256, slot_of(d + 3), pf[k]);
+          __syncthreads();
+        }
+      }
+      continue;
+    }
     // prologue: the planes of the first depth step, d0-PD .. d0-PD+NPL-1
     if constexpr (CIN <= 16 || (C::WINO && CIN >= 32)) {   // (the one-block-per-CU Winograd kernels have the registers for it)
       vec_t pro[NPL][C::NFILL];   // all planes in flight at once: one memory latency instead of NPL
@@ -695,7 +760,9 @@ int launch_lds(LdsConvParams& p, hipStream_t st) {
     // 1-plane tail chunk (D = 4 -> 3 + 1) costs a whole prologue for a third of the work: 93 -> 77 us on 16->16 @4x296x400.
     // (A makespan model "rounds x (chunk + prologue)" was tried and is wrong here: two resident blocks share one MFMA pipe,
     // so fewer, longer items do not finish sooner.)
-    long long ipb = (C::RD == 2 && blocks_per_cu == 1) ? 3 : 6;   // (one resident block and long pair steps: 179 -> 172 us on 16->8 @24x296x400)
+    // (one resident block and long pair steps: 179 -> 172 us on 16->8 @24x296x400 with 3; the three-plane ring form of that layer,
+    //  two resident blocks: 163 us with 6, 158 with 4, 151 with 2)
+    long long ipb = C::STREAM ? 2 : ((C::RD == 2 && blocks_per_cu == 1) ? 3 : 6);
     if (const char* e = getenv("MDF_CONV_ITEMS_PER_BLOCK")) { if (atoi(e) > 0) ipb = atoi(e); }   // dev A/B
     long long want = (ipb * max_grid + tiles - 1) / tiles;
     if (want < 1) want = 1;
@@ -839,6 +906,7 @@ extern "C" int mdf_release_stream(void* stream) {
 #define LDS_CASE_WD(ci)                                                                          \
   if (use_wd && KD == 3 && KHW == 3 && stride == 1 && Cin == ci && Cin_mem == ci && Cout == 8 && !res_up && D >= 2) { \
     p.wpack = wpack + (size_t)27 * ci * 16 + (size_t)36 * ci * 16 + (ci == 16 ? (size_t)3 * 16 * 64 * 4 : 0); \
+    if (ci == 16 && wd_stream && !stat) return launch_lds<ci, ci, 8, 3, 3, 1, 1, 2, 3>(p, (hipStream_t)stream); \
     return !stat ? launch_lds<ci, ci, 8, 3, 3, 1, 1, 2, 2>(p, (hipStream_t)stream) : (stat->mode == 1 ? launch_lds<ci, ci, 8, 3, 3, 1, 1, 2, 2, 1>(p, (hipStream_t)stream) : launch_lds<ci, ci, 8, 3, 3, 1, 1, 2, 2, 2>(p, (hipStream_t)stream)); \
   }
 
@@ -846,6 +914,7 @@ int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha
                           float res_scale, const float* res_up, float* y, int B, int D, int H, int W, int Cin, int Cin_mem, int Cout, int KD,
                           int KHW, int stride, int relu, void* stream, int planar_in, int shuffle2, const mdf::ConvStat* stat) {
   static const int wd_mask = [] { const char* e = getenv("MDF_CONV_WD"); return e ? atoi(e) : 3; }();   // dev A/B: bit 0 Cin 8, bit 1 Cin 16
+  const bool wd_stream = [] { const char* e = getenv("MDF_CONV_WD_STREAM"); return e ? atoi(e) != 0 : true; }();   // dev A/B (read per call): ring of 3 planes
   static const bool use_wg = [] { const char* e = getenv("MDF_CONV_WINOGRAD"); return e ? atoi(e) != 0 : true; }();   // dev A/B
   static const bool use_rw = [] { const char* e = getenv("MDF_CONV_RW"); return e ? atoi(e) != 0 : true; }();   // dev A/B
   LdsConvParams p{};

@@ -144,10 +144,14 @@ constexpr int round_s(int n, int kpl, int sw) {
 template <int CIN, int CIN_MEM, int COUT, int KD, int KHW, int SHW, int MT, int RW = 1, int WG = 0>
 struct Cfg {
   static_assert(RW == 1 || WG != 0 || (SHW == 1 && COUT * RW <= 16 && COUT % 4 == 0), "w-phase form: stride 1, RW*Cout <= 16, Cout % 4 == 0");
-  static_assert(WG == 0 || ((KD == 3 || KD == 1) && KHW == 3 && SHW == 1 && RW == 2 && MT == 1 && CIN % (WG == 2 ? 8 : 16) == 0 && COUT % 4 == 0), "Winograd form: 3x3(x3) stride 1, RW = 2, MT = 1");
-  static_assert(WG != 2 || (KD == 3 && COUT == 8), "depth-pair Winograd form: 3-D, Cout = 8");
+  static_assert(WG == 0 || ((KD == 3 || KD == 1) && KHW == 3 && SHW == 1 && RW == 2 && MT == 1 && CIN % (WG >= 2 ? 8 : 16) == 0 && COUT % 4 == 0), "Winograd form: 3x3(x3) stride 1, RW = 2, MT = 1");
+  static_assert(WG < 2 || (KD == 3 && COUT == 8), "depth-pair Winograd form: 3-D, Cout = 8");
   static constexpr bool WINO = (WG != 0);
-  static constexpr int RD = (WG == 2) ? 2 : 1;    // output planes per depth step
+  static constexpr int RD = (WG >= 2) ? 2 : 1;    // output planes per depth step
+  // WG = 3: the depth-pair form on a ring of THREE planes: the pair's first three input planes are multiplied, the fourth takes the
+  // oldest plane's slot and is multiplied next (conv_lds_kernel, STREAM path) -- a 16-channel plane tile is 22 KB, and three of them
+  // leave room for a second block per CU where four do not
+  static constexpr bool STREAM = (WG == 3);
   static constexpr int NPL = KD + RD - 1;         // input planes a depth step reads
   static constexpr int NTP = ((COUT + 15) / 16 > 2) ? 2 : (COUT + 15) / 16;   // Winograd: n-tiles per pass over K (16 accumulators each)
   static constexpr int CIN_ = CIN;
@@ -170,7 +174,7 @@ struct Cfg {
   static constexpr int NFILL = (NG * PH * PW + 255) / 256;
   // 3-D: rolling window of KD planes; 2-D: double-buffered tiles -- except the 64-channel Winograd form, whose 10x34 tile
   // (87 KB) fits once: single buffer, the next tile's loads wait in registers during the (long) compute
-  static constexpr int RING = (KD > 1) ? NPL : ((WINO && CIN >= 64) ? 1 : 2);
+  static constexpr int RING = (KD > 1) ? (STREAM ? KD : NPL) : ((WINO && CIN >= 64) ? 1 : 2);
   static constexpr int NSTEP = WINO ? NPL * 16 * NCH : KD * KHW * KW * NCH;   // MFMA pipeline steps per output row-tile (tap x cin chunk)
   // small layers keep ALL their weight fragments in registers for the whole kernel (<= 40 VGPRs; beyond that occupancy drops and it is a loss, measured) instead of re-fetching
   // them from L1 for every tile: with 8-16 MFMAs per step there is nothing to hide that round trip behind
