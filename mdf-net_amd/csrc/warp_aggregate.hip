@@ -79,24 +79,50 @@ __global__ __launch_bounds__(kThreads) void warp_kernel(const Params p) {
   const size_t map_stride = (size_t)hw * C;
   const unsigned lane_b = 16u * (unsigned)sub;      // byte offset of this lane's 4 channels inside a texel
 
+  // phase A bookkeeping: when the (pixel, view) pairs of the tile divide the block (5 views: 4 x PPB = 256 / 128 / 64), a thread keeps
+  // ITS pair over all planes and chunks, so the pair's index arithmetic, its three 16-byte loads of the projection and rot_xyz are done
+  // once per kernel instead of once per sample (they were a third of the per-sample instructions; the kernel is VALU-bound)
+  const int npair = PPB * p.n_src;
+  const bool fixed_pair = (kThreads % npair) == 0;
+  const int pa_pair = tid % npair, pa_grp = tid / npair, pa_ngrp = kThreads / npair;
+  const int pa_pl = pa_pair % PPB, pa_v = pa_pair / PPB;
+  const int pa_pix = min(pix0 + pa_pl, hw - 1);
+  PixelRay ray{};
+  if (fixed_pair) {
+    const int yy = pa_pix / p.g.w, xx = pa_pix - yy * p.g.w;
+    ray = warp_ray(p.proj + ((size_t)pa_v * p.B + b) * 12, (float)xx, (float)yy);
+  }
+
   for (int d0 = 0; d0 < p.D; d0 += p.dchunk) {
     const int nd = min(p.dchunk, p.D - d0);
     // ---------------- phase A: one thread per (plane, view, pixel) sample
-    const int nent = nd * p.n_src * PPB;
-    for (int e = tid; e < nent; e += kThreads) {
-      const int epl = e % PPB;
-      const int ev = (e / PPB) % p.n_src;
-      const int ed = e / (PPB * p.n_src);
-      const int epix = min(pix0 + epl, hw - 1);
-      const int yy = epix / p.g.w, xx = epix - yy * p.g.w;
-      const float* m = p.proj + ((size_t)ev * p.B + b) * 12;
-      const int d = d0 + ed;
-      const float dep = p.hypos_per_pixel ? p.hypos[((size_t)b * p.D + d) * hw + epix] : p.hypos[(size_t)b * p.D + d];
-      float ix, iy;
-      warp_position(m, (float)xx, (float)yy, dep, p.g, ix, iy);
-      TapEntry t;
-      make_taps(ix, iy, p.g, C, t);
-      tab[e] = t;
+    if (fixed_pair) {
+      for (int ed = pa_grp; ed < nd; ed += pa_ngrp) {
+        const int d = d0 + ed;
+        const float dep = p.hypos_per_pixel ? p.hypos[((size_t)b * p.D + d) * hw + pa_pix] : p.hypos[(size_t)b * p.D + d];
+        float ix, iy;
+        warp_position_ray(ray, dep, p.g, ix, iy);
+        TapEntry t;
+        make_taps(ix, iy, p.g, C, t);
+        tab[(ed * p.n_src + pa_v) * PPB + pa_pl] = t;
+      }
+    } else {
+      const int nent = nd * p.n_src * PPB;
+      for (int e = tid; e < nent; e += kThreads) {
+        const int epl = e % PPB;
+        const int ev = (e / PPB) % p.n_src;
+        const int ed = e / (PPB * p.n_src);
+        const int epix = min(pix0 + epl, hw - 1);
+        const int yy = epix / p.g.w, xx = epix - yy * p.g.w;
+        const float* m = p.proj + ((size_t)ev * p.B + b) * 12;
+        const int d = d0 + ed;
+        const float dep = p.hypos_per_pixel ? p.hypos[((size_t)b * p.D + d) * hw + epix] : p.hypos[(size_t)b * p.D + d];
+        float ix, iy;
+        warp_position(m, (float)xx, (float)yy, dep, p.g, ix, iy);
+        TapEntry t;
+        make_taps(ix, iy, p.g, C, t);
+        tab[e] = t;
+      }
     }
     __syncthreads();
     // ---------------- phase B

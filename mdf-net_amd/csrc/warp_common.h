@@ -20,6 +20,31 @@ struct Geom {
 //   P = rot_xyz*depth ; P += t ; px = Px/Pz ; py = Py/Pz  base.py:112-115 (no z>0 test)
 //   xn = px / f32((w-1)/2) - 1                             base.py:117 (true divide)
 //   ix = fma(xn + 1, w/2, -0.5)                            grid_sample(align_corners=False), FMA-contracted
+// The two halves of warp_position: the part that depends on (pixel, view) only -- rot_xyz and the translation --, and the part per
+// depth hypothesis.  A kernel whose threads keep their (pixel, view) pair over the planes computes the first half once.
+struct PixelRay {
+  float q0, q1, q2, t0, t1, t2;
+};
+__device__ __forceinline__ PixelRay warp_ray(const float* __restrict__ m, float x, float y) {
+  PixelRay r;
+  r.q0 = __fadd_rn(m[2], __fmaf_rn(m[1], y, __fmul_rn(m[0], x)));
+  r.q1 = __fadd_rn(m[6], __fmaf_rn(m[5], y, __fmul_rn(m[4], x)));
+  r.q2 = __fadd_rn(m[10], __fmaf_rn(m[9], y, __fmul_rn(m[8], x)));
+  r.t0 = m[3]; r.t1 = m[7]; r.t2 = m[11];
+  return r;
+}
+__device__ __forceinline__ void warp_position_ray(const PixelRay& r, float dep, const Geom& g, float& ix, float& iy) {
+  const float X = __fadd_rn(__fmul_rn(r.q0, dep), r.t0);
+  const float Y = __fadd_rn(__fmul_rn(r.q1, dep), r.t1);
+  const float Z = __fadd_rn(__fmul_rn(r.q2, dep), r.t2);
+  const float px = __fdiv_rn(X, Z);
+  const float py = __fdiv_rn(Y, Z);
+  const float xn = __fsub_rn(__fdiv_rn(px, g.half_w), 1.0f);
+  const float yn = __fsub_rn(__fdiv_rn(py, g.half_h), 1.0f);
+  ix = __fmaf_rn(__fadd_rn(xn, 1.0f), g.sw, -0.5f);
+  iy = __fmaf_rn(__fadd_rn(yn, 1.0f), g.sh, -0.5f);
+}
+
 __device__ __forceinline__ void warp_position(const float* __restrict__ m, float x, float y, float dep,
                                               const Geom& g, float& ix, float& iy) {
   const float q0 = __fadd_rn(m[2], __fmaf_rn(m[1], y, __fmul_rn(m[0], x)));
