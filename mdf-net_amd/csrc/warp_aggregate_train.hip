@@ -86,24 +86,48 @@ __global__ __launch_bounds__(kThreads) void warp_train_kernel(const TrainParams 
   const int nred = (PASS == kStats) ? 2 * p.n_src : 2 * p.n_src + 2;
   double total = 0.0;                 // thread k < nred: block total of reduction slot k
 
+  // tap table: a thread keeps its (pixel, view) pair over the planes when the pairs divide the block (warp_aggregate.hip, phase A)
+  const int npair = PPB * p.n_src;
+  const bool fixed_pair = (kThreads % npair) == 0;
+  const int pa_pair = tid % npair, pa_grp = tid / npair, pa_ngrp = kThreads / npair;
+  const int pa_pl = pa_pair % PPB, pa_v = pa_pair / PPB;
+  const int pa_pix = min(pix0 + pa_pl, hw - 1);
+  PixelRay ray{};
+  if (fixed_pair) {
+    const int yy = pa_pix / p.g.w, xx = pa_pix - yy * p.g.w;
+    ray = warp_ray(p.proj + ((size_t)pa_v * p.B + b) * 12, (float)xx, (float)yy);
+  }
+
   const int dlo = blockIdx.z * p.dslice, dhi = min(p.D, dlo + p.dslice);
   for (int d0 = dlo; d0 < dhi; d0 += p.dchunk) {
     const int nd = min(p.dchunk, dhi - d0);
-    const int nent = nd * p.n_src * PPB;
-    for (int e = tid; e < nent; e += kThreads) {
-      const int epl = e % PPB;
-      const int ev = (e / PPB) % p.n_src;
-      const int ed = e / (PPB * p.n_src);
-      const int epix = min(pix0 + epl, hw - 1);
-      const int yy = epix / p.g.w, xx = epix - yy * p.g.w;
-      const float* m = p.proj + ((size_t)ev * p.B + b) * 12;
-      const int d = d0 + ed;
-      const float dep = p.hypos_per_pixel ? p.hypos[((size_t)b * p.D + d) * hw + epix] : p.hypos[(size_t)b * p.D + d];
-      float ix, iy;
-      warp_position(m, (float)xx, (float)yy, dep, p.g, ix, iy);
-      TapEntry t;
-      make_taps(ix, iy, p.g, C, t);
-      tab[e] = t;
+    if (fixed_pair) {
+      for (int ed = pa_grp; ed < nd; ed += pa_ngrp) {
+        const int d = d0 + ed;
+        const float dep = p.hypos_per_pixel ? p.hypos[((size_t)b * p.D + d) * hw + pa_pix] : p.hypos[(size_t)b * p.D + d];
+        float ix, iy;
+        warp_position_ray(ray, dep, p.g, ix, iy);
+        TapEntry t;
+        make_taps(ix, iy, p.g, C, t);
+        tab[(ed * p.n_src + pa_v) * PPB + pa_pl] = t;
+      }
+    } else {
+      const int nent = nd * p.n_src * PPB;
+      for (int e = tid; e < nent; e += kThreads) {
+        const int epl = e % PPB;
+        const int ev = (e / PPB) % p.n_src;
+        const int ed = e / (PPB * p.n_src);
+        const int epix = min(pix0 + epl, hw - 1);
+        const int yy = epix / p.g.w, xx = epix - yy * p.g.w;
+        const float* m = p.proj + ((size_t)ev * p.B + b) * 12;
+        const int d = d0 + ed;
+        const float dep = p.hypos_per_pixel ? p.hypos[((size_t)b * p.D + d) * hw + epix] : p.hypos[(size_t)b * p.D + d];
+        float ix, iy;
+        warp_position(m, (float)xx, (float)yy, dep, p.g, ix, iy);
+        TapEntry t;
+        make_taps(ix, iy, p.g, C, t);
+        tab[e] = t;
+      }
     }
     __syncthreads();
 
