@@ -727,6 +727,9 @@ int launch_conv_mt(ConvParams& p, hipStream_t st) {
   constexpr int MTMAX = (ROWS > 32) ? 2 : 4;
   // small volumes: shrink the wave tile so the grid still covers the 256 CUs a few times over
   const long long tiles_big = p.m_total / (64LL * MTMAX) * (MODE == kTr ? 4 : 1);
+  // (8 -> 16 stride 2 at 24x296x400: 51.5 us with 4 m-tiles per wave, 47.8 with 2, 56.1 with 1; the other stride-2 / transposed layers
+  //  are best at their MTMAX or indifferent)
+  if (MODE == kS2 && CIN == 8 && ST == 0 && tiles_big >= 1024) return launch_conv<CIN, COUT, MODE, 2, 1, ST>(p, st);
   if (tiles_big >= 1024) return launch_conv<CIN, COUT, MODE, MTMAX, 1, ST>(p, st);
   // few tiles and a deep K (27*CIN >= 864): split the taps over the block's waves
   const long long tiles_1 = p.m_total / 16 * (MODE == kTr ? 4 : 1);
