@@ -53,6 +53,13 @@ def test_bad_arguments_return_codes_not_aborts():
     assert lib.mdf_warp_aggregate_vec_fwd(*args(16, 4, 2)) == EUNSUP
     # prob head in partial-sum form: D beyond the built register tiles
     assert lib.mdf_prob_from_partials_fwd(_ptr(y), None, 0, _ptr(x), None, 1, 200, 4, 4, st) == EUNSUP
+    # the one-launch prob head: channel count not built, depth output without hypotheses, a depth whose logits do not fit the LDS
+    assert lib.mdf_prob_fused_fwd(_ptr(x), _ptr(w), None, 0, _ptr(y), None, 1, 4, 8, 8, 32, st) == EUNSUP and "Cin" in _last()
+    assert lib.mdf_prob_fused_fwd(_ptr(x), _ptr(w), None, 0, _ptr(y), _ptr(y), 1, 4, 8, 8, 8, st) == EARG
+    assert lib.mdf_prob_fused_fwd(_ptr(x), _ptr(w), None, 0, _ptr(y), None, 1, 160, 8, 8, 8, st) == EUNSUP and "LDS" in _last()
+    # the refine tail: lo without span, null weights
+    assert lib.mdf_refine_tail_fwd(_ptr(x), _ptr(w), _ptr(w), _ptr(wp), None, _ptr(y), 1, 8, 8, st) == EARG and "lo and span" in _last()
+    assert lib.mdf_refine_tail_fwd(_ptr(x), None, _ptr(w), None, None, _ptr(y), 1, 8, 8, st) == EARG
     # ... and the library still works
     out = ops.conv2d_nhwc(torch.ones(1, 8, 8, 16, device=DEV), ops.pack_conv2d_weight(torch.ones(16, 16, 3, 3, device=DEV)), 16, 16, 3, 1)
     assert float(out[0, 4, 4, 0]) == 16 * 9
