@@ -645,7 +645,9 @@ __device__ __forceinline__ float pack_tr_elem(const WSrc& src, int i, int Cin, i
 }
 
 __host__ __device__ inline int rw_of(int Cout) { return Cout == 8 ? 2 : (Cout == 4 ? 4 : 0); }   // w-phase factor of a stride-1 k3 layer (0 = none)
-__host__ __device__ inline bool wino_built(int Cin, int Cout) { return ((Cout == 16 || Cout == 32) && (Cin == 16 || Cin == 32) && Cout <= Cin) || (Cin == 16 && Cout == 8); }   // 3-D
+__host__ __device__ inline bool wino_built(int Cin, int Cout) {   // 3-D ((16, 32): the input-gradient conv of the stage-0 regulariser's first layer, training)
+  return ((Cout == 16 || Cout == 32) && (Cin == 16 || Cin == 32)) || (Cin == 16 && Cout == 8);
+}
 __host__ __device__ inline bool wino2d_built(int Cin, int Cout) { return (Cin == 16 && Cout == 16) || (Cin == 32 && Cout == 32) || (Cin == 64 && Cout == 64); }
 __host__ __device__ inline bool wd_built(int Cin, int Cout) { return Cout == 8 && (Cin == 8 || Cin == 16); }   // 3-D, depth-pair Winograd
 __host__ __device__ inline int padded_cin(int c) { return c <= 4 ? 4 : c; }
