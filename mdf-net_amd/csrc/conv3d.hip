@@ -648,7 +648,9 @@ __host__ __device__ inline int rw_of(int Cout) { return Cout == 8 ? 2 : (Cout ==
 __host__ __device__ inline bool wino_built(int Cin, int Cout) {   // 3-D ((16, 32): the input-gradient conv of the stage-0 regulariser's first layer, training)
   return ((Cout == 16 || Cout == 32) && (Cin == 16 || Cin == 32)) || (Cin == 16 && Cout == 8);
 }
-__host__ __device__ inline bool wino2d_built(int Cin, int Cout) { return (Cin == 16 && Cout == 16) || (Cin == 32 && Cout == 32) || (Cin == 64 && Cout == 64); }
+__host__ __device__ inline bool wino2d_built(int Cin, int Cout) {   // ((16, 32), (32, 64): input gradients of the k5-s2 layers as 3x3 convs over the parity classes, training)
+  return (Cin == 16 && Cout == 16) || (Cin == 32 && Cout == 32) || (Cin == 64 && Cout == 64) || (Cin == 16 && Cout == 32) || (Cin == 32 && Cout == 64);
+}
 __host__ __device__ inline bool wd_built(int Cin, int Cout) { return Cout == 8 && (Cin == 8 || Cin == 16); }   // 3-D, depth-pair Winograd
 __host__ __device__ inline int padded_cin(int c) { return c <= 4 ? 4 : c; }
 

@@ -939,7 +939,7 @@ int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha
   { const bool use_wd = use_wg && (wd_mask & 2); LDS_CASE_WD(16) }
   // 3-D stride-1 layers with 16 output channels: Winograd F(2x2,3x3) in (h,w)
   LDS_CASE_WG(16, 16) LDS_CASE_WG(32, 16) LDS_CASE_WG(32, 32) LDS_CASE_WG(16, 8) LDS_CASE_WG(16, 32)
-  LDS_CASE_WG2(16, 16) LDS_CASE_WG2(32, 32) LDS_CASE_WG2(64, 64)
+  LDS_CASE_WG2(16, 16) LDS_CASE_WG2(32, 32) LDS_CASE_WG2(64, 64) LDS_CASE_WG2(16, 32) LDS_CASE_WG2(32, 64)
   // Cout < 16: w-phase form (RW output voxels per MFMA column)
   LDS_CASE_RW_T(16, 16, 8, 3, 3, 1, 2, 2) LDS_CASE_RW_T(8, 8, 8, 3, 3, 1, 2, 2)
   LDS_CASE_RW(16, 16, 4, 1, 3, 1, 1, 4) LDS_CASE_RW(8, 8, 4, 1, 3, 1, 1, 4)
