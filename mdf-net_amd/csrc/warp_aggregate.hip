@@ -217,6 +217,161 @@ __global__ __launch_bounds__(kThreads) void warp_kernel(const Params p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// kVec with EIGHT channels (four groups) per lane.  The loop of warp_kernel<C,kVec> is VALU-bound (PMC: the vector ALU is ~72 %
+// busy), and a third of its ~45 instructions per (lane, plane, view) is per-PIXEL work every lane of the pixel repeats: the
+// reduction of the view-weight dot product, BN -> ReLU -> 1x1 conv -> sigmoid (two transcendentals), the weighted accumulation.
+// With 8 channels per lane a pixel has half the lanes, so that part runs half as often, the reduction tree is one step shorter,
+// and the two 16-byte gathers of a corner are one contiguous 32 bytes per lane.  Lane s takes the channels of lanes 2s and 2s+1
+// of the 4-channel kernel and adds their two partial dot products first -- the first step of that kernel's reduction tree --, so
+// every sum is formed from the same operands: bit-identical cost volume.
+template <int C>
+__global__ __launch_bounds__(kThreads) void warp_vec8_kernel(const Params p) {
+  constexpr int LPP = C / 8;           // lanes per pixel
+  constexpr int PPB = kThreads / LPP;  // pixels per block
+  constexpr int G = C / 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  TapEntry* tab = reinterpret_cast<TapEntry*>(smem);
+  const int hw = p.g.h * p.g.w;
+  const int b = blockIdx.y;
+  const int tile = (int)mdf::xcd_remap(blockIdx.x, p.nblk_x);
+  const int pix0 = tile * PPB;
+  const int tid = threadIdx.x;
+  const int pl = tid / LPP, sub = tid % LPP;
+  const int pix = min(pix0 + pl, hw - 1);
+  const bool live = (pix0 + pl) < hw;
+
+  float rd[2][2], r1[2][2], cw[2][2];          // [half j = 4-channel slice 2*sub + j][group]: r0 - r1, r1 of the reference softmax; conv weights
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float4 rv = *reinterpret_cast<const float4*>(p.ref + ((size_t)b * hw + pix) * C + 8 * sub + 4 * j);
+    float a0, a1, b0, b1;
+    softmax2(rv.x, rv.y, a0, a1);
+    softmax2(rv.z, rv.w, b0, b1);
+    rd[j][0] = a0 - a1; r1[j][0] = a1;
+    rd[j][1] = b0 - b1; r1[j][1] = b1;
+    cw[j][0] = p.wpar[2 * (2 * sub + j)];
+    cw[j][1] = p.wpar[2 * (2 * sub + j) + 1];
+  }
+  const float alpha = p.wpar[G], beta = p.wpar[G + 1], w2 = p.wpar[G + 2], b2 = p.wpar[G + 3];
+  const size_t map_stride = (size_t)hw * C;
+  const unsigned lane_b = 32u * (unsigned)sub;      // byte offset of this lane's 8 channels inside a texel
+
+  // tap table: a thread keeps its (pixel, view) pair(s) over the planes (warp_kernel, phase A); here a tile has up to 2 pairs per thread
+  const int npair = PPB * p.n_src;
+  const bool few = (npair <= kThreads) && (kThreads % npair) == 0;          // >= 1 thread group per pair set
+  const bool two = (npair == 2 * kThreads);                                 // exactly two pairs per thread
+  const int pa_ngrp = few ? kThreads / npair : 1, pa_grp = few ? tid / npair : 0;
+  PixelRay ray[2];
+  int pa_pl[2], pa_v[2], pa_pix[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int pair = (few ? tid % npair : tid) + k * kThreads;
+    pa_pl[k] = pair % PPB; pa_v[k] = min(pair / PPB, p.n_src - 1);
+    pa_pix[k] = min(pix0 + pa_pl[k], hw - 1);
+    const int yy = pa_pix[k] / p.g.w, xx = pa_pix[k] - yy * p.g.w;
+    ray[k] = warp_ray(p.proj + ((size_t)pa_v[k] * p.B + b) * 12, (float)xx, (float)yy);
+  }
+
+  for (int d0 = 0; d0 < p.D; d0 += p.dchunk) {
+    const int nd = min(p.dchunk, p.D - d0);
+    if (few || two) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (k == 1 && !two) break;
+        for (int ed = pa_grp; ed < nd; ed += pa_ngrp) {
+          const int d = d0 + ed;
+          const float dep = p.hypos_per_pixel ? p.hypos[((size_t)b * p.D + d) * hw + pa_pix[k]] : p.hypos[(size_t)b * p.D + d];
+          float ix, iy;
+          warp_position_ray(ray[k], dep, p.g, ix, iy);
+          TapEntry t;
+          make_taps(ix, iy, p.g, C, t);
+          tab[(ed * p.n_src + pa_v[k]) * PPB + pa_pl[k]] = t;
+        }
+      }
+    } else {
+      const int nent = nd * p.n_src * PPB;
+      for (int e = tid; e < nent; e += kThreads) {
+        const int epl = e % PPB;
+        const int ev = (e / PPB) % p.n_src;
+        const int ed = e / (PPB * p.n_src);
+        const int epix = min(pix0 + epl, hw - 1);
+        const int yy = epix / p.g.w, xx = epix - yy * p.g.w;
+        const float* m = p.proj + ((size_t)ev * p.B + b) * 12;
+        const int d = d0 + ed;
+        const float dep = p.hypos_per_pixel ? p.hypos[((size_t)b * p.D + d) * hw + epix] : p.hypos[(size_t)b * p.D + d];
+        float ix, iy;
+        warp_position(m, (float)xx, (float)yy, dep, p.g, ix, iy);
+        TapEntry t;
+        make_taps(ix, iy, p.g, C, t);
+        tab[e] = t;
+      }
+    }
+    __syncthreads();
+    for (int dd = 0; dd < nd; ++dd) {
+      float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+      float wsum = 0.f;
+      for (int v = 0; v < p.n_src; ++v) {
+        const TapEntry t = tab[(dd * p.n_src + v) * PPB + pl];
+        const char* sb = reinterpret_cast<const char*>(p.src[v] + (size_t)b * map_stride);
+        float sim[2][2], part[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const unsigned lb = lane_b + 16u * j;
+          const float4 nw = *reinterpret_cast<const float4*>(sb + ((unsigned)t.off[0] * 4u + lb));
+          const float4 ne = *reinterpret_cast<const float4*>(sb + ((unsigned)t.off[1] * 4u + lb));
+          const float4 sw = *reinterpret_cast<const float4*>(sb + ((unsigned)t.off[2] * 4u + lb));
+          const float4 se = *reinterpret_cast<const float4*>(sb + ((unsigned)t.off[3] * 4u + lb));
+          const float v0 = __fmaf_rn(se.x, t.wt[3], __fmaf_rn(sw.x, t.wt[2], __fmaf_rn(ne.x, t.wt[1], __fmul_rn(nw.x, t.wt[0]))));
+          const float v1 = __fmaf_rn(se.y, t.wt[3], __fmaf_rn(sw.y, t.wt[2], __fmaf_rn(ne.y, t.wt[1], __fmul_rn(nw.y, t.wt[0]))));
+          const float v2 = __fmaf_rn(se.z, t.wt[3], __fmaf_rn(sw.z, t.wt[2], __fmaf_rn(ne.z, t.wt[1], __fmul_rn(nw.z, t.wt[0]))));
+          const float v3 = __fmaf_rn(se.w, t.wt[3], __fmaf_rn(sw.w, t.wt[2], __fmaf_rn(ne.w, t.wt[1], __fmul_rn(nw.w, t.wt[0]))));
+          sim[j][0] = __fmaf_rn(softmax2_p0(v0, v1), rd[j][0], r1[j][0]);   // homoaggregate.py:38-39
+          sim[j][1] = __fmaf_rn(softmax2_p0(v2, v3), rd[j][1], r1[j][1]);
+          part[j] = __fmaf_rn(cw[j][0], sim[j][0], cw[j][1] * sim[j][1]);
+        }
+        const float z = pixel_sum<LPP>(part[0] + part[1]);                     // Conv3d(G->1, 1x1x1); first tree step in the lane
+        const float u = __fmaf_rn(fmaxf(__fmaf_rn(z, alpha, beta), 0.0f), w2, b2);  // BN(eval) -> ReLU -> Conv3d(1->1)
+        const float wv = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-u * kLog2e));  // Sigmoid
+        wsum += wv;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[j][0] += wv * sim[j][0];
+          acc[j][1] += wv * sim[j][1];
+        }
+      }
+      if (!live) continue;
+      const size_t vox = ((size_t)b * p.D + d0 + dd) * hw + pix;
+      const float o0 = acc[0][0] / wsum, o1 = acc[0][1] / wsum, o2 = acc[1][0] / wsum, o3 = acc[1][1] / wsum;   // homoaggregate.py:46
+      if (p.out_ndhwc) {
+        *reinterpret_cast<float4*>(p.out + vox * G + 4 * sub) = make_float4(o0, o1, o2, o3);
+      } else {
+        const size_t cs = (size_t)p.D * hw;
+        float* o = p.out + ((size_t)b * G * p.D + d0 + dd) * hw + pix;
+        o[(size_t)(4 * sub) * cs] = o0;
+        o[(size_t)(4 * sub + 1) * cs] = o1;
+        o[(size_t)(4 * sub + 2) * cs] = o2;
+        o[(size_t)(4 * sub + 3) * cs] = o3;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int C>
+int launch_vec8(Params& p, hipStream_t st) {
+  constexpr int ppb = kThreads / (C / 8);
+  p.nblk_x = (p.g.h * p.g.w + ppb - 1) / ppb;
+  int dch = 1024 / (p.n_src * ppb);  // ~32 KiB of tap table per block (twice the pixels of warp_kernel's tile, the same planes)
+  if (dch < 1) dch = 1;
+  if (dch > p.D) dch = p.D;
+  p.dchunk = dch;
+  const size_t lds = (size_t)dch * p.n_src * ppb * sizeof(TapEntry);
+  if (lds > 64 * 1024) return MDF_EUNSUPPORTED;
+  hipLaunchKernelGGL((warp_vec8_kernel<C>), dim3(p.nblk_x, p.B), dim3(kThreads), lds, st, p);
+  return mdf::check_launch("warp_vec8_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // kVec with LDS-staged source-feature tiles.  Per depth chunk the block finds, for every source view, the bounding box
 // of its taps in that view's feature map (min/max over the tap table), loads the boxes ONCE with coalesced row loads
 // (ww*C contiguous floats per window row in NHWC) into a pool of LDS windows, and takes the 4 bilinear taps of every
@@ -499,6 +654,17 @@ extern "C" int mdf_warp_aggregate_vec_fwd(const float* ref_fea, const float* con
     else if (C == 32) rc = launch_win<32>(p, (hipStream_t)stream);
     else if (C == 16) rc = launch_win<16>(p, (hipStream_t)stream);
     if (rc != MDF_EUNSUPPORTED) return rc;
+  }
+  {
+    const char* e8 = getenv("MDF_WARP_VEC8");      // dev A/B (read per call): 8 channels per lane
+    if (!e8 || atoi(e8) != 0) {
+      int rc = MDF_EUNSUPPORTED;
+      // (in a cfg2 forward: C 64 243 -> 233 us, C 32 254 -> 250 us; C 16 -- two lanes per pixel, a 128-pixel tile -- 204 -> 221 us: not used)
+      if (C == 64) rc = launch_vec8<64>(p, (hipStream_t)stream);
+      else if (C == 32) rc = launch_vec8<32>(p, (hipStream_t)stream);
+      else if (C == 16 && e8 && atoi(e8) == 2) rc = launch_vec8<16>(p, (hipStream_t)stream);
+      if (rc != MDF_EUNSUPPORTED) return rc;
+    }
   }
   return launch<kVec>(p, C, (hipStream_t)stream);
 }

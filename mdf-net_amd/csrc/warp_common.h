@@ -112,7 +112,7 @@ __device__ __forceinline__ float dpp_mov(float v) {
 template <int LPP>
 __device__ __forceinline__ float pixel_sum(float v) {
   v += dpp_mov<0xB1>(v);                  // quad_perm [1,0,3,2]
-  v += dpp_mov<0x4E>(v);                  // quad_perm [2,3,0,1]
+  if (LPP >= 4) v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
   if (LPP >= 8) v += dpp_mov<0x141>(v);   // row_half_mirror
   if (LPP >= 16) v += dpp_mov<0x140>(v);  // row_mirror
   return v;

@@ -156,3 +156,28 @@ def test_lds_window_variant_is_bit_identical(seeded_sd, stage, rot, nv, monkeypa
     monkeypatch.setenv("MDF_WARP_WINDOW", "1")
     win = ops.warp_aggregate_vec(feats, proj, hyp, wpar, g)
     assert torch.equal(plain, win)
+
+
+@pytest.mark.parametrize("stage,nv", [(0, 5), (1, 5), (2, 5), (1, 3), (2, 11), (0, 2)])
+def test_eight_channels_per_lane_variant_is_bit_identical(seeded_sd, stage, nv, monkeypatch):
+    """warp_vec8_kernel (a lane owns 8 channels = the work of two lanes of warp_kernel<C,kVec>; their two partial dot products are
+    added first, which is the first step of that kernel's reduction tree) returns the same cost volume bit for bit -- all three
+    channel counts, 1 / 2 pairs per thread and the generic tap-table path (10 source views)."""
+    from net.unit.scale import scale_cam
+    c, g, d = ((64, 32, 48), (32, 16, 24), (16, 8, 8))[stage]
+    h, w = (37, 50) if stage == 0 else ((74, 100) if stage == 1 else (148, 200))
+    torch.manual_seed(stage * 5 + nv)
+    intr, extr, dr = synth.make_cameras(w * 2 ** (3 - stage), h * 2 ** (3 - stage), nv, batch=2, rot_deg=3.0, seed=3)
+    rp, sps = scale_cam(intr, extr, stage)
+    proj = ops.relative_projections(rp, list(sps)).to(DEV)
+    feats = [torch.randn(2, c, h, w, device=DEV) for _ in range(nv)]
+    if stage == 0:
+        hyp = torch.linspace(425, 935, d, device=DEV).reshape(1, d, 1, 1).repeat(2, 1, 1, 1)
+    else:
+        hyp = (425 + 510 * torch.rand(2, 1, h, w, device=DEV)) + torch.linspace(-20, 20, d, device=DEV).reshape(1, d, 1, 1)
+    wpar = torch.randn(g + 4, device=DEV)
+    monkeypatch.setenv("MDF_WARP_VEC8", "0")
+    four = ops.warp_aggregate_vec(feats, proj, hyp, wpar, g).clone()
+    monkeypatch.setenv("MDF_WARP_VEC8", "2")
+    eight = ops.warp_aggregate_vec(feats, proj, hyp, wpar, g)
+    assert torch.equal(four, eight)
