@@ -18,7 +18,7 @@ def family(name):
         return "batchnorm_train"
     if "conv_lds_kernel" in name or "conv3d_kernel" in name or "conv_pair_kernel" in name or "conv1x1_kernel" in name or "refine_tail_kernel" in name or "prob_fused_kernel" in name:
         return "mfma_conv"
-    if "warp_kernel" in name:
+    if "warp_kernel" in name or "warp_vec8_kernel" in name:
         return "warp_aggregate"
     if "prob_head" in name or "prob_from_partials" in name:
         return "prob_head"
