@@ -774,10 +774,13 @@ int launch_lds(LdsConvParams& p, hipStream_t st) {
     // lengthen the chunks until one round holds everything, if that round is shorter than the two it replaces.
     {
       const long long items0 = tiles * ((p.D + dch - 1) / dch);
-      if (items0 > max_grid && items0 < 2 * (long long)max_grid) {
+      // (also from the third round: 16->8 @24x296x400, 481 tiles x 3 chunks on 512 blocks 152 us, one chunk 144 us; not beyond -- with four
+      //  or more rounds the dynamic queue fills the tail, and long chunks lose: 16->16 @48x148x200 130 -> 154 us)
+      if (items0 > max_grid && items0 < 3 * (long long)max_grid) {
+        const long long rounds0 = (items0 + max_grid - 1) / max_grid;
         for (int d2 = dch + 1; d2 <= p.D; ++d2) {
           if (tiles * ((p.D + d2 - 1) / d2) <= max_grid) {
-            if (10 * (d2 + C::NPL - 1) < 18 * (dch + C::NPL - 1)) dch = d2;
+            if (10 * (d2 + C::NPL - 1) < 9 * rounds0 * (dch + C::NPL - 1)) dch = d2;
             break;
           }
         }
