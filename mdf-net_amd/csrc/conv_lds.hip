@@ -769,6 +769,7 @@ int launch_lds(LdsConvParams& p, hipStream_t st) {
     if (want > p.D / 3) want = p.D / 3;
     if (want < 1) want = 1;
     int dch = (int)((p.D + want - 1) / want);
+    if (C::RD == 2 && (dch & 1)) ++dch;   // depth-pair form: whole pairs per chunk (an odd tail pair computes a plane it does not store)
     // Between one and two rounds of resident blocks the second round runs mostly empty (32->32 @24x74x100: 40 tiles x 8 chunks = 320
     // items on 256 blocks took 98 us; x 6 chunks = 240 items: 74 us; 16->16 @12x148x200: 532 items on 512 blocks 50 us, 399 items 45 us):
     // lengthen the chunks until one round holds everything, if that round is shorter than the two it replaces.
@@ -778,7 +779,7 @@ int launch_lds(LdsConvParams& p, hipStream_t st) {
       //  or more rounds the dynamic queue fills the tail, and long chunks lose: 16->16 @48x148x200 130 -> 154 us)
       if (items0 > max_grid && items0 < 3 * (long long)max_grid) {
         const long long rounds0 = (items0 + max_grid - 1) / max_grid;
-        for (int d2 = dch + 1; d2 <= p.D; ++d2) {
+        for (int d2 = dch + C::RD; d2 <= p.D + C::RD - 1; d2 += C::RD) {
           if (tiles * ((p.D + d2 - 1) / d2) <= max_grid) {
             if (10 * (d2 + C::NPL - 1) < 9 * rounds0 * (dch + C::NPL - 1)) dch = d2;
             break;
