@@ -507,7 +507,7 @@ int launch_convtr_all(ConvParams& p, hipStream_t st) {
 // through WSrc, which maps it onto the parameter tensor as it sits in the module.  Mode 0 is the parameter itself; the
 // other modes are the re-indexings the training step needs every time the optimizer has changed the weights (the input-
 // gradient convs of train_ops.py), done here instead of as flip / transpose / pad / index_select launches of their own.
-enum { kSrcDirect = 0, kSrcSwapFlip = 1, kSrcK5S2Dgrad = 2, kSrcProbSlices = 3, kSrcShuffle2 = 4, kSrcSwap = 5 };
+enum { kSrcDirect = 0, kSrcSwapFlip = 1, kSrcK5S2Dgrad = 2, kSrcProbSlices = 3, kSrcShuffle2 = 4, kSrcSwap = 5, kSrcK5S2Phases = 6 };
 struct WSrc {
   const float* w;
   int mode, Co, Ci, T, a0, a1;
@@ -523,6 +523,12 @@ struct WSrc {
         const int ky = (cls >> 1) ? (ty == 0 ? -1 : 5 - 2 * ty) : 4 - 2 * ty;    // p=0: (4,2,0); p=1: (-,3,1)
         const int kx = (cls & 1) ? (tx == 0 ? -1 : 5 - 2 * tx) : 4 - 2 * tx;
         return (ky < 0 || kx < 0) ? 0.f : w[(((size_t)i * a0 + ci) * 5 + ky) * 5 + kx];
+      }
+      case kSrcK5S2Phases: { // Conv2d(k5,s2,p2) [Co][a0][5][5] as a stride-1 3x3 conv over the four parity images of its input (internal:
+        // the Winograd segment of a k5-s2 weight set): logical input channel i = (py*2+px)*a0 + ci, tap (ty,tx) <- (2(ty-1)+py+2, 2(tx-1)+px+2)
+        const int ph = i / a0, ci = i - ph * a0;
+        const int ky = 2 * (t / 3) + (ph >> 1), kx = 2 * (t % 3) + (ph & 1);
+        return (ky > 4 || kx > 4) ? 0.f : w[(((size_t)o * a0 + ci) * 5 + ky) * 5 + kx];
       }
       case kSrcProbSlices:  // `prob` conv [1][Ci][3][3][3] as a 2-D conv with one output row per depth tap (+ a zero row)
         return o < 3 ? w[((size_t)i * 3 + o) * 9 + t] : 0.f;
@@ -652,6 +658,8 @@ __host__ __device__ inline bool wino2d_built(int Cin, int Cout) {   // ((16, 32)
   return (Cin == 16 && Cout == 16) || (Cin == 32 && Cout == 32) || (Cin == 64 && Cout == 64) || (Cin == 16 && Cout == 32) || (Cin == 32 && Cout == 64);
 }
 __host__ __device__ inline bool wd_built(int Cin, int Cout) { return Cout == 8 && (Cin == 8 || Cin == 16); }   // 3-D, depth-pair Winograd
+// 2-D k5 s2 layers that also run as a Winograd 3x3 conv over the four parity images of their input (conv_lds.hip, LdsConvParams::s2d)
+__host__ __device__ inline bool k5w_built(int Cin, int Cout) { return Cin == 16 && Cout == 32; }
 __host__ __device__ inline int padded_cin(int c) { return c <= 4 ? 4 : c; }
 
 // One complete packed weight set, as mdf_conv3d_pack_weights / mdf_conv_pack_weights lay it out: the plain fragments, then
@@ -678,6 +686,7 @@ __host__ __device__ inline void pack_segments(int is3d, int transposed, int Cin_
   if (k3 && rw_of(Cout)) *rw = (long long)(is3d ? 9 : 3) * (3 + rw_of(Cout) - 1) * NCH * 64 * KPL;
   if (k3 && (is3d ? wino_built(Cin_mem, Cout) : wino2d_built(Cin_mem, Cout))) *wino = (long long)(is3d ? 3 : 1) * (Cin / 16) * 16 * ((Cout + 15) / 16) * 64 * 4;
   if (k3 && is3d && wd_built(Cin_mem, Cout)) *wd = 4ll * NCH * 16 * 64 * KPL;
+  if (!is3d && ntaps == 25 && k5w_built(Cin_mem, Cout)) *wino = (long long)(4 * Cin / 16) * 16 * ((Cout + 15) / 16) * 64 * 4;   // (its only extra segment)
 }
 __device__ __forceinline__ void pack_job_elem(const PackJob& j, long long i) {
   const int Cin = padded_cin(j.Cin_mem);
@@ -689,7 +698,14 @@ __device__ __forceinline__ void pack_job_elem(const PackJob& j, long long i) {
   if (j.transposed) v = pack_tr_elem(src, (int)i, Cin, j.Cout);
   else if (i < plain) v = pack_plain_elem(src, (int)i, Cin, j.Cin_mem, j.Cout);
   else if (i < plain + rw) v = pack_rw_elem(src, (int)(i - plain), Cin, j.Cin_mem, j.Cout, 3, rw_of(j.Cout));
-  else if (i < plain + rw + wino) v = pack_wino_elem(src, (int)(i - plain - rw), Cin, j.Cout, j.is3d ? 3 : 1);
+  else if (i < plain + rw + wino) {
+    if (!j.is3d && j.ntaps == 25) {   // k5 s2 as 3x3 over the parity images: 4*Cin logical input channels
+      const WSrc ph{j.src, kSrcK5S2Phases, j.Cout, 4 * j.Cin_mem, 9, j.Cin_mem, 0};
+      v = (j.mode == kSrcDirect) ? pack_wino_elem(ph, (int)(i - plain - rw), 4 * Cin, j.Cout, 1) : 0.f;
+    } else {
+      v = pack_wino_elem(src, (int)(i - plain - rw), Cin, j.Cout, j.is3d ? 3 : 1);
+    }
+  }
   else v = pack_wd_elem(src, (int)(i - plain - rw - wino), Cin);
   j.dst[i] = v;
 }

@@ -464,6 +464,15 @@ __global__ __launch_bounds__(256, (WG == 2 && CIN == 8) ? MDF_WD8_BLOCKS : (ST !
         split2(idx, v, g);
         const int row = v / PW, col = v - row * PW;
         const int ih = th0 * SHW - C::PAD + row, iw = tw0 * SHW - C::PAD + col;
+        if constexpr (CIN_MEM == CIN && NG % 4 == 0 && KPL == 4) {
+          if (p.s2d) {   // parity images of a map at twice the resolution (p.H x p.W is that map): group g = parity * (NG/4) + 4-channel slice
+            constexpr int GPP = NG / 4;
+            const int par = g / GPP, c4 = g - par * GPP;
+            const int ihf = 2 * ih + (par >> 1), iwf = 2 * iw + (par & 1);
+            if (idx >= NG * PH * PW || ihf < 0 || ihf >= p.H || iwf < 0 || iwf >= p.W) return vec_zero<KPL>();
+            return *reinterpret_cast<const vec_t*>(p.x + (((size_t)tb * p.H + ihf) * p.W + iwf) * (CIN / 4) + c4 * KPL);
+          }
+        }
         if (idx >= NG * PH * PW || ih < 0 || ih >= p.H || iw < 0 || iw >= p.W) return vec_zero<KPL>();
         const float* src = p.x + (((size_t)tb * p.H + ih) * p.W + iw) * CIN_MEM + g * KPL;
         if (CIN_MEM == CIN) return *reinterpret_cast<const vec_t*>(src);
@@ -953,6 +962,19 @@ int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha
   const int pad = (KHW - 1) / 2;
   p.Ho = (H + 2 * pad - KHW) / stride + 1;
   p.Wo = (W + 2 * pad - KHW) / stride + 1;
+  // The 2-D k5 s2 layer 16 -> 32 as a Winograd 3x3 conv over the four parity images of its input (64 -> 32: 16 instead of 25 MFMA groups per
+  // input channel; 163 -> 141 us); the transform-domain fragments follow the 25 plain taps (conv3d.hip: k5w_built).  (8 -> 16 the same way,
+  // 32 -> 16 over the parity images, measured 200 against 203 us -- that layer waits on HBM, and one block per CU does not help it; 32 -> 64
+  // would need 128 input channels in LDS.)
+  {
+    const bool k5w = [] { const char* e = getenv("MDF_CONV_K5_WINOGRAD"); return e ? atoi(e) != 0 : true; }();   // dev A/B (read per call)
+    if (use_wg && k5w && KD == 1 && KHW == 5 && stride == 2 && !stat && !res_up && !shuffle2 && !planar_in && H % 2 == 0 && W % 2 == 0) {
+      if (Cin == 16 && Cin_mem == 16 && Cout == 32) {
+        p.s2d = 1; p.wpack = wpack + (size_t)25 * 1 * 2 * 64 * 4;
+        return launch_lds<64, 64, 32, 1, 3, 1, 1, 2, 1>(p, (hipStream_t)stream);
+      }
+    }
+  }
   // 3-D stride-1 layers with 8 output channels: depth-pair Winograd
   { const bool use_wd = use_wg && (wd_mask & 1); LDS_CASE_WD(8) }
   { const bool use_wd = use_wg && (wd_mask & 2); LDS_CASE_WD(16) }

@@ -29,6 +29,8 @@ struct LdsConvParams {
   int sched_slot;                      // which pair of g_sched words this launch uses (one per stream)
   int shuffle2;                        // 2-D, Cout = 32: write PixelShuffle(2) of the result ([B,2Ho,2Wo,8]); rows packed sub-pixel-major
   int prefetch_early;                  // 3-D: issue the next plane's loads before (1) or after (0) the MFMA block
+  int s2d;                             // 2-D: x is [B,H,W,CIN/4] at TWICE the resolution; the kernel's input is its four parity images as
+                                       // channels (py*2+px)*CIN/4 + c (space-to-depth done by the tile fill): a k5 s2 layer as a 3x3 conv
   // training (ST kernels): per-channel sums of the output in the epilogue, see conv3d.hip ConvParams::stat_mode
   int stat_mode;
   const float* stat_y;

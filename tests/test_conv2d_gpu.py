@@ -97,6 +97,25 @@ def test_refine_tail_in_one_launch(shape):
     np.testing.assert_allclose(got_raw.cpu().numpy(), two.cpu().numpy(), rtol=0, atol=4e-6)
 
 
+@pytest.mark.parametrize("shape", [(2, 26, 70), (1, 8, 32), (1, 64, 132), (3, 2, 2)])
+def test_k5s2_as_winograd_over_the_parity_images(shape, monkeypatch):
+    """Conv2d(16, 32, k5, s2, p2) run as a Winograd 3x3 conv over the four parity images of its input (conv_lds.hip, LdsConvParams::s2d)
+    against the direct 25-tap kernel and torch: tiles that hang over the right / bottom edge, a map smaller than a tile."""
+    b, h, w = shape
+    rng = np.random.RandomState(h * 7 + w)
+    x = T(rng.randn(b, 16, h, w).astype(np.float32))
+    wt = T((rng.randn(32, 16, 5, 5) / 20).astype(np.float32))
+    al, be = T(rng.uniform(0.5, 1.5, 32).astype(np.float32)), T(rng.randn(32).astype(np.float32) * 0.1)
+    exp = F.relu(F.conv2d(x, wt, None, 2, 2) * al.view(1, -1, 1, 1) + be.view(1, -1, 1, 1))
+    xd, wp = ops.to_nhwc(x.to(DEV)), ops.pack_conv2d_weight(wt.to(DEV))
+    monkeypatch.setenv("MDF_CONV_K5_WINOGRAD", "1")
+    got = ops.from_nhwc(ops.conv2d_nhwc(xd, wp, 16, 32, 5, 2, al.to(DEV), be.to(DEV), True)).cpu()
+    monkeypatch.setenv("MDF_CONV_K5_WINOGRAD", "0")
+    direct = ops.from_nhwc(ops.conv2d_nhwc(xd, wp, 16, 32, 5, 2, al.to(DEV), be.to(DEV), True)).cpu()
+    np.testing.assert_allclose(got.numpy(), exp.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(got.numpy(), direct.numpy(), rtol=1e-4, atol=2e-5)
+
+
 def test_backbone_and_refine_vs_reference_golden(golden, seeded_sd):
     g = golden("ops.npz")
     m = build_model()

@@ -86,8 +86,11 @@ def test_stagewise_vs_reference_trace(golden, model, seeded_sd):
         hk.remove()
     _, live = O.core_forward(seeded_sd, imgs, extr, intr, dr, keep=True, warp=O.homo_warping_explicit)
     print()
+    # hypotheses (mm): the tight leg is the live oracle on this host (2e-3); against the golden -- another host's BLAS / libm in the curve
+    # fit -- the MAXIMUM over the 9216 hypotheses of a stage sits at 5.5e-3 .. 6.3e-3 depending on which fp32-equivalent form the backbone
+    # convs run in (direct k5 kernel vs Winograd over the parity images; the mean is 3.8e-4 in both, the final depth error unchanged)
     for st in range(3):
-        for k, tol_gold, tol_live in (("hypos", 6e-3, 2e-3), ("cost", 2e-5, 2e-5), ("prob", 5e-4, 5e-4)):
+        for k, tol_gold, tol_live in (("hypos", 8e-3, 2e-3), ("cost", 2e-5, 2e-5), ("prob", 5e-4, 5e-4)):
             a = tr[f"{k}{st}"].cpu().numpy()
             dg, dl = np.abs(a - g[f"{k}{st}"]), np.abs(a - live[f"{k}{st}"].numpy())
             print(f"stage {st} {k:5s}: vs golden max {dg.max():.3e} mean {dg.mean():.3e} | vs live oracle max {dl.max():.3e} "
