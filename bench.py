@@ -346,6 +346,65 @@ def training_block(dev, steps, blocks, stock_steps):
     return rec
 
 
+def training_graph_child(steps, blocks):
+    """The same training step recorded ONCE as a hipGraph and replayed per step (mdfnet_hip/graphstep.py): run as a child process of
+    the bench (`--train-graph-child`), prints one JSON line.  A replay costs the host one call; the GPU executes the same launches."""
+    import statistics
+    from mdfnet_hip import synth, ddp
+    from mdfnet_hip.graphstep import GraphedTrainStep
+    from mdfnet_hip.optim import FlatAdam
+    from net import loss as loss_mod
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    model = build(dev).train()
+    bucket = ddp.FlatBucket(model)
+    opt = FlatAdam(bucket, lr=1e-3)
+    crit = loss_mod.Loss().to(dev)
+    imgs, extr, intr, dr = synth.make_scene(TRAIN_W, TRAIN_H, TRAIN_V, batch=1, rot_deg=2.0, seed=3)
+    gt = {str(k): (torch.rand(1, TRAIN_H >> k, TRAIN_W >> k, device=dev) * 400 + 480) for k in (3, 2, 1, 0)}
+    t0 = time.perf_counter()
+    step = GraphedTrainStep(model, crit, bucket, opt, (imgs.to(dev), extr.to(dev), intr.to(dev), dr.to(dev), gt), warmup=2)
+    torch.cuda.synchronize()
+    t_rec = time.perf_counter() - t0
+    imgs_d = imgs.to(dev)
+    for _ in range(3):
+        first = step(imgs_d, extr, intr, dr, gt)          # cameras and range as HOST tensors (a loader's): their arithmetic is the host's
+    first = float(first)
+    torch.cuda.synchronize()
+    times, hosts = [], []
+    for _ in range(blocks):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = step(imgs_d, extr, intr, dr, gt)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) / steps)
+        hosts.append((t1 - t0) / steps)
+    med = statistics.median(times)
+    assert torch.isfinite(last).item()
+    print(json.dumps({"ms_per_step": round(1e3 * med, 3), "samples_per_s": round(1.0 / med, 2), "steps": steps, "blocks": blocks,
+                      "ms_per_step_blocks": [round(1e3 * t, 3) for t in times],
+                      "host_ms_per_step": round(1e3 * statistics.median(hosts), 3), "recording_s": round(t_rec, 2),
+                      "loss_first": round(first, 3), "loss_last": round(float(last), 3),
+                      "note": "forward + loss + backward + bucket + Adam recorded once (torch.cuda.graph over the hand-written launches) and "
+                              "replayed per step; per step the host uploads the packed control plane + Adam's scalars and issues one "
+                              "replay (host_ms_per_step), the GPU executes the same launches as the eager step"}), flush=True)
+
+
+def training_graph(steps, blocks, timeout=240.0):
+    """Runs training_graph_child in a fresh process (a fault there must not take the bench line with it) -> dict."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--train-graph-child", "--train-steps", str(steps), "--blocks", str(blocks)]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"error": f"child exited with {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+    except Exception as e:      # noqa: BLE001  (timeout, spawn failure: reported, never fatal for the bench line)
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def cpu_baseline(timed_views=3):
     """Oracle (CPU port of the reference algorithm) on the host cores; bounded sample of the same workload: BASELINE.md
     section 3's protocol -- 1 full-size warm-up view + 3 timed full-size views, median."""
@@ -402,6 +461,8 @@ def main():
     ap.add_argument("--no-training", action="store_true", help="skip the BASELINE configs[2] training-step block (rank 0, N=1)")
     ap.add_argument("--train-steps", type=int, default=20)
     ap.add_argument("--train-stock-steps", type=int, default=2, help="steps of the stock PyTorch-ROCm autograd baseline (0 = skip)")
+    ap.add_argument("--no-train-graph", action="store_true", help="skip the hipGraph-replayed variant of the training step (a child process)")
+    ap.add_argument("--train-graph-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -409,6 +470,11 @@ def main():
         # has happened yet; the children are fresh subprocesses, nothing is exec'ed over an initialised process)
         from mdfnet_hip import shard
         raise SystemExit(shard.launch_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:], timeout=args.rank_timeout))
+    if args.train_graph_child:
+        if not torch.cuda.device_count():
+            raise SystemExit("bench.py needs an MI355X (no GPU visible)")
+        training_graph_child(args.train_steps, max(1, args.blocks))
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -503,6 +569,8 @@ def main():
         kernels, prof_info = profile_pass(model, inputs)
     if rank == 0 and world == 1 and not args.no_training:
         training = training_block(dev, args.train_steps, max(1, args.blocks), args.train_stock_steps)
+        if not args.no_train_graph:
+            training["graph_replay"] = training_graph(args.train_steps, max(1, args.blocks))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
     if rank == 0:

@@ -361,6 +361,12 @@ int64_t mdf_adam_job_fill(void* jobs_host, int index, float* param, long long of
 int mdf_adam_step(const void* jobs_dev, const int* block_job_dev, int nblocks, const float* grads, float* exp_avg,
                   float* exp_avg_sq, float lr, float beta1, float beta2, float eps, float weight_decay, long long step,
                   void* stream);
+/*      The same step with its per-step scalars in DEVICE memory: hyper_dev[3] = (lr, 1 - beta1^step, sqrt(1 - beta2^step)), computed
+ *      by the caller as mdf_adam_step computes them.  For a training step recorded once and replayed as a hipGraph
+ *      (mdfnet_hip/graphstep.py): kernel arguments are frozen in the recording, memory is not.  */
+int mdf_adam_step_hyper(const void* jobs_dev, const int* block_job_dev, int nblocks, const float* grads, float* exp_avg,
+                        float* exp_avg_sq, const float* hyper_dev, float beta1, float beta2, float eps, float weight_decay,
+                        void* stream);
 
 #ifdef __cplusplus
 }

@@ -123,8 +123,12 @@ constexpr int kAdamPerBlock = 1024;
 
 __global__ __launch_bounds__(256) void adam_step_kernel(const AdamJob* __restrict__ jobs, const int* __restrict__ block_job,
                                                         const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, float lr,
-                                                        float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2_sqrt) {
+                                                        float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2_sqrt,
+                                                        const float* __restrict__ hyper) {
   const AdamJob j = jobs[block_job[blockIdx.x]];
+  if (hyper) {   // a step replayed as a hipGraph: the per-step scalars come from memory, not from the (recorded) arguments
+    lr = hyper[0]; bc1 = hyper[1]; bc2_sqrt = hyper[2];
+  }
   const float step_size = lr / bc1;
   const int base = (blockIdx.x - j.blk0) * kAdamPerBlock;
 #pragma unroll
@@ -164,6 +168,16 @@ extern "C" int mdf_adam_step(const void* jobs_dev, const int* block_job_dev, int
   MDF_REQUIRE(nblocks > 0 && step >= 1 && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "bad argument");
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adam_step_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, static_cast<const AdamJob*>(jobs_dev), block_job_dev, grads,
-                     exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
+                     exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), (const float*)nullptr);
+  return mdf::check_launch("adam_step_kernel");
+}
+
+extern "C" int mdf_adam_step_hyper(const void* jobs_dev, const int* block_job_dev, int nblocks, const float* grads, float* exp_avg,
+                                   float* exp_avg_sq, const float* hyper_dev, float beta1, float beta2, float eps, float weight_decay,
+                                   void* stream) {
+  MDF_REQUIRE(jobs_dev && block_job_dev && grads && exp_avg && exp_avg_sq && hyper_dev, "null pointer argument");
+  MDF_REQUIRE(nblocks > 0 && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "bad argument");
+  hipLaunchKernelGGL(adam_step_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, static_cast<const AdamJob*>(jobs_dev), block_job_dev, grads,
+                     exp_avg, exp_avg_sq, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, hyper_dev);
   return mdf::check_launch("adam_step_kernel");
 }

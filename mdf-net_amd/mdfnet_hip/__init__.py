@@ -84,6 +84,7 @@ SIGNATURES = {
     "mdf_adam_job_bytes": (c_i64, []),
     "mdf_adam_job_fill": (c_i64, [c_fp, c_int, c_fp, c_i64, c_i64, c_int]),
     "mdf_adam_step": (c_int, [c_fp, c_fp, c_int, c_fp, c_fp, c_fp] + [ctypes.c_float] * 5 + [c_i64, c_fp]),
+    "mdf_adam_step_hyper": (c_int, [c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp] + [ctypes.c_float] * 4 + [c_fp]),
     "mdf_hypos_from_fit_fwd": (c_int, [c_int, c_fp, c_fp, c_fp, ctypes.c_float, c_fp] + [c_int] * 5 + [c_fp]),
 }
 

@@ -46,17 +46,60 @@ class active:
         _tls.plan = self.prev
 
 
-def prepare(model, intrinsics, extrinsics, depth_range):
-    """-> Plan or None (None: not the builtin slot set, CPU tensors, ...; the slots then work on their own)."""
-    from net.unit.scale import scale_cam, host_cameras
+class Staging:
+    """A FIXED device buffer (and its layout) for the packed control plane, for a training step that is replayed as a hipGraph
+    (mdfnet_hip/graphstep.py): the graph's kernels read the same addresses every replay, the step driver computes the values
+    on the host and uploads them with one stream-ordered copy BEFORE each replay (`upload`), and a forward that runs under
+    `staged(st)` -- the capture -- takes its device views from this buffer instead of allocating and copying its own."""
+
+    def __init__(self, device):
+        self.device, self.dev, self.where = device, None, None
+
+    def upload(self, pieces):
+        """pieces: [(name, host tensor)] as `host_pieces` returns them -> one pinned buffer, one non-blocking copy on the current
+        stream (torch's pinned allocator recycles the host buffer once the copy has run)."""
+        n = sum(t.numel() for _, t in pieces)
+        buf = torch.empty(n, dtype=torch.float32, pin_memory=True)
+        off, where = 0, {}
+        for name, t in pieces:
+            k = t.numel()
+            buf[off:off + k].copy_(t.reshape(-1))
+            where[name] = (off, tuple(t.shape))
+            off += k
+        if self.dev is None:
+            self.dev, self.where = torch.empty(n, dtype=torch.float32, device=self.device), where
+        elif where != self.where:
+            raise RuntimeError("controlplane.Staging: the control plane's layout changed (other batch size, view count or slot set); "
+                               "a captured step is bound to the layout it was captured with")
+        self.dev.copy_(buf, non_blocking=True)
+
+
+class staged:
+    def __init__(self, staging):
+        self.staging = staging
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "staging", None)
+        _tls.staging = self.staging
+        return self.staging
+
+    def __exit__(self, *exc):
+        _tls.staging = self.prev
+
+
+def builtin_slots(model):
+    from net.unit.scale import scale_cam
     from net.unit.depthhypos import HyposByFit
-    if not (intrinsics.is_cuda and extrinsics.is_cuda and depth_range.is_cuda) or model.scale is not scale_cam:
-        return None
     hyps = list(model.Depth_hypos)
-    if len(hyps) != 3 or not all(isinstance(h, HyposByFit) for h in hyps):
-        return None
-    dev = intrinsics.device
-    pieces = []          # (name, host tensor)
+    return model.scale is scale_cam and len(hyps) == 3 and all(isinstance(h, HyposByFit) for h in hyps)
+
+
+def host_pieces(model, intrinsics, extrinsics, depth_range):
+    """The host half of `prepare`: -> ([(name, host tensor)], per-stage host cameras, host hyp0).  Pure host arithmetic on the
+    host mirrors of the three tensors (or on the tensors themselves when they are CPU tensors)."""
+    from net.unit.scale import host_cameras
+    hyps = list(model.Depth_hypos)
+    pieces = []
     nstage = len(hyps)
     hosts = [host_cameras(intrinsics, extrinsics, st) for st in range(nstage)]          # [V,B,4,4] each
     rel = [ops.relative_projections(h[0], [h[v] for v in range(1, h.shape[0])]) for h in hosts]        # [n_src,B,12]
@@ -71,15 +114,35 @@ def prepare(model, intrinsics, extrinsics, depth_range):
     pieces += [("hyp0", hyp0), ("rng", rng), ("lo", lo.contiguous()), ("span", span.contiguous())]
     if row is not None:
         pieces.append(("row", row))
-    n = sum(t.numel() for _, t in pieces)
-    buf = torch.empty(n, dtype=torch.float32, pin_memory=True)      # (torch's pinned allocator recycles it once the copy has run)
-    off, where = 0, {}
-    for name, t in pieces:
-        k = t.numel()
-        buf[off:off + k].copy_(t.reshape(-1))
-        where[name] = (off, tuple(t.shape))
-        off += k
-    on_dev = buf.to(dev, non_blocking=True)
+    return pieces, hosts, hyp0
+
+
+def prepare(model, intrinsics, extrinsics, depth_range):
+    """-> Plan or None (None: not the builtin slot set, CPU tensors, ...; the slots then work on their own)."""
+    if not (intrinsics.is_cuda and extrinsics.is_cuda and depth_range.is_cuda) or not builtin_slots(model):
+        return None
+    dev = intrinsics.device
+    nstage = len(model.Depth_hypos)
+    pieces, hosts, hyp0 = host_pieces(model, intrinsics, extrinsics, depth_range)
+    row = any(name == "row" for name, _ in pieces)
+    staging = getattr(_tls, "staging", None)
+    if staging is not None:
+        # a step being captured (or rehearsed) for replay: the driver has uploaded this step's values into the fixed buffer
+        if staging.dev is None:
+            staging.upload(pieces)
+        on_dev, where = staging.dev, staging.where
+        if {k: v[1] for k, v in where.items()} != {name: tuple(t.shape) for name, t in pieces}:
+            raise RuntimeError("controlplane.prepare: the staged control plane has another layout than this forward's")
+    else:
+        n = sum(t.numel() for _, t in pieces)
+        buf = torch.empty(n, dtype=torch.float32, pin_memory=True)      # (torch's pinned allocator recycles it once the copy has run)
+        off, where = 0, {}
+        for name, t in pieces:
+            k = t.numel()
+            buf[off:off + k].copy_(t.reshape(-1))
+            where[name] = (off, tuple(t.shape))
+            off += k
+        on_dev = buf.to(dev, non_blocking=True)
 
     def view(name):
         o, shape = where[name]
@@ -95,7 +158,7 @@ def prepare(model, intrinsics, extrinsics, depth_range):
         plan.keep.append(outs)
     plan.hyp0 = hostmirror.put(view("hyp0"), hyp0)
     plan.rng, plan.lo, plan.span = view("rng"), view("lo"), view("span")
-    plan.fit_row = view("row") if row is not None else None
+    plan.fit_row = view("row") if row else None
     return plan
 
 

@@ -1,0 +1,137 @@
+"""A whole training step -- forward, loss, backward, gradient bucket, Adam (train.py:36-45) -- recorded ONCE as a hipGraph and
+replayed per step.
+
+Why: at BASELINE config 3 the step is ~330 launches of 5-300 us; issued one by one from Python the host needs as long to issue
+them (~9 ms) as the GPU needs to run them (~8 ms of kernel time), so neither a faster kernel nor a leaner wrapper moves the wall
+clock on its own.  A replay is one host call; the launches are dispatched by the runtime from the recorded graph.
+
+What has to hold for a recording to stay valid, and how each point is met:
+  * every address the kernels touch is the same at every replay: activations, gradients and workspaces come from the graph's
+    private pool (torch.cuda.graph); the step's INPUTS live in fixed device tensors that `__call__` overwrites, stream-ordered,
+    before the replay (images, ground truth, depth range, and the packed control plane -- cameras, relative projections,
+    hypotheses row, fit row -- which is host arithmetic: controlplane.host_pieces -> controlplane.Staging.upload);
+  * nothing the host computes per step is frozen into a kernel ARGUMENT: Adam's learning rate and bias corrections are read from
+    a 3-float device buffer uploaded per replay (mdf_adam_step_hyper), the control plane as above; the step is built from
+    hand-written kernels only, none of which synchronises or allocates (the C library never calls hipMalloc / hipMemcpy);
+  * the per-step zeroed reduction pool (train_ops.ZeroPool) hands out the same offsets in the same order every step, and its one
+    fill per step is part of the recording; a pool that overflowed DURING the recording would have been replaced by a pool
+    tensor from the graph's memory, which is equally stable;
+  * the parameters change through raw pointers inside the graph, so after every replay the version counters of parameters and
+    buffers are bumped on the host: any cache keyed on them (eval-mode folded weights) sees the update.
+
+Data parallelism: with more than one rank the gradient all-reduce stays OUTSIDE the graphs -- recording A ends with the bucket
+gather, the collective runs eagerly on the same stream (RCCL), recording B is the Adam launch.
+
+The recorded step equals the eager step on the same inputs up to the summation order of the floating-point atomics that both
+use (tests/test_train_graph_gpu.py: three steps with different cameras and images per step, both ways).
+"""
+import torch
+from torch.autograd import graph as _graph
+
+from . import controlplane, hostmirror, train_ops
+
+
+class GraphedTrainStep:
+    def __init__(self, model, criterion, bucket, optimizer, example, warmup=2):
+        """example = (imgs, extrinsics, intrinsics, depth_range, gt dict): shapes and device of every later step.  Runs `warmup`
+        eager steps on a side stream (lazy initialisation, autograd's buffers, the weight-pack plan), then records.  The model,
+        the optimizer state and the BatchNorm buffers ARE advanced by the warm-up steps and by the recording step (a recording
+        executes nothing, but the warm-up does): restore a checkpoint afterwards if the example is not a real step."""
+        imgs, extr, intr, dr, gt = example
+        if not imgs.is_cuda:
+            raise RuntimeError("GraphedTrainStep records hand-written MI355X kernels: the example tensors must be on the GPU")
+        if not controlplane.builtin_slots(model):
+            raise RuntimeError("GraphedTrainStep needs the builtin slot set (scale_cam, HyposByFit): other slots compute their "
+                               "control plane where the recording cannot follow")
+        self.model, self.crit, self.bucket, self.opt = model, criterion, bucket, optimizer
+        dev = imgs.device
+        self.device = dev
+        self.world = bucket.world
+        # fixed inputs
+        self.imgs = imgs.detach().clone()
+        self.dr = dr.detach().clone()
+        self.gt = {k: v.detach().clone() for k, v in gt.items()}
+        # cameras and range reach the kernels through the packed control plane only; the slot API still wants tensors to key on
+        self.extr, self.intr = extr.detach().clone(), intr.detach().clone()
+        self.staging = controlplane.Staging(dev)
+        self.hyper = torch.zeros(3, device=dev, dtype=torch.float32)
+        self.stream = torch.cuda.Stream(dev)
+        self.loss = None
+        self.graph_a = self.graph_b = None
+        self._versioned = list(bucket.params) + [b for b in model.buffers() if b.is_cuda]
+        host = [hostmirror.get(t).clone() for t in (extr, intr, dr)]
+        cur = torch.cuda.current_stream(dev)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            for _ in range(warmup):
+                self._upload(*host)
+                self._eager_step()
+        cur.wait_stream(self.stream)
+        torch.cuda.synchronize(dev)
+        self._record(host)
+
+    # ---- pieces of a step ------------------------------------------------------------------------------------------------
+    def _upload(self, extr_h, intr_h, dr_h):
+        """This step's host-computed values -> the fixed device buffers (stream-ordered copies on the current stream)."""
+        for fixed, h in ((self.extr, extr_h), (self.intr, intr_h), (self.dr, dr_h)):
+            hostmirror.put(fixed, h)                        # the slots find the host values without a device->host hop
+        pieces, _, _ = controlplane.host_pieces(self.model, intr_h, extr_h, dr_h)
+        self.staging.upload(pieces)
+        hv = torch.tensor(self.opt.hyper_values(self.opt.steps + 1), dtype=torch.float32).pin_memory()
+        self.hyper.copy_(hv, non_blocking=True)
+
+    def _forward_backward(self):
+        with controlplane.staged(self.staging):
+            out = self.model(self.imgs, self.extr, self.intr, self.dr)
+        loss = self.crit(out, self.gt, self.dr)
+        self.bucket.zero_grad()
+        loss.backward()
+        self.bucket.gather()
+        return loss.detach()
+
+    def _eager_step(self):
+        loss = self._forward_backward()
+        self.bucket.allreduce_gradients()
+        self.opt.step(hyper=self.hyper)
+        self.opt.steps += 1
+        return loss
+
+    def _record(self, host):
+        dev = self.device
+        self._upload(*host)                                 # (values for the recording pass: it executes nothing, but the host-side
+        torch.cuda.synchronize(dev)                         #  slot code reads the mirrors)
+        self.graph_a = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_a, stream=self.stream):
+            self.loss = self._forward_backward()
+            if self.world <= 1:
+                self.opt.step(hyper=self.hyper)
+        if self.world > 1:
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_b, stream=self.stream, pool=self.graph_a.pool()):
+                self.opt.step(hyper=self.hyper)
+        torch.cuda.synchronize(dev)
+
+    # ---- one step --------------------------------------------------------------------------------------------------------
+    def __call__(self, imgs, extrinsics, intrinsics, depth_range, gt):
+        """Same arguments as one iteration of train.py's loop body; tensors may live on the host (the loader's) or on the GPU.
+        Cameras and range are needed on the HOST (their arithmetic is LAPACK's, scale.py / base.py): hand them over as CPU
+        tensors, or registered with hostmirror.put, to avoid a device->host hop.  -> the loss (a fixed device tensor,
+        overwritten by the next step)."""
+        extr_h, intr_h, dr_h = (hostmirror.get(t) for t in (extrinsics, intrinsics, depth_range))
+        if imgs.shape != self.imgs.shape or any(gt[k].shape != v.shape for k, v in self.gt.items()):
+            raise RuntimeError("GraphedTrainStep: tensor shapes differ from the recorded step's")
+        if imgs is not self.imgs:
+            self.imgs.copy_(imgs, non_blocking=True)
+        for k, v in self.gt.items():
+            if gt[k] is not v:
+                v.copy_(gt[k], non_blocking=True)
+        if depth_range is not self.dr:
+            self.dr.copy_(depth_range if depth_range.is_cuda else dr_h, non_blocking=True)
+        self._upload(extr_h, intr_h, dr_h)
+        self.graph_a.replay()
+        if self.world > 1:
+            self.bucket.allreduce_gradients()
+            self.graph_b.replay()
+        self.opt.steps += 1
+        _graph.increment_version(self._versioned)           # written through raw pointers inside the graph
+        return self.loss

@@ -63,8 +63,20 @@ class FlatAdam(torch.optim.Optimizer):
         self._table = (torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev), torch.tensor(block_job, dtype=torch.int32).to(dev), first,
                        tuple(p.data_ptr() for p in params))
 
+    def hyper_values(self, step):
+        """(lr, 1 - beta1^step, sqrt(1 - beta2^step)) as mdf_adam_step forms them from its arguments (float betas widened to
+        double, the results narrowed to float): what a replayed step (graphstep.py) uploads for mdf_adam_step_hyper."""
+        import math
+        import numpy as np
+        grp = self.param_groups[0]
+        b1, b2 = (float(np.float32(b)) for b in grp["betas"])
+        return [float(np.float32(grp["lr"])), float(np.float32(1.0 - math.pow(b1, float(step)))),
+                float(np.float32(math.sqrt(1.0 - math.pow(b2, float(step)))))]
+
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, hyper=None):
+        """hyper: optional DEVICE tensor [3] = hyper_values(step) -- the launch then takes its per-step scalars from memory and
+        the caller owns the step count (`self.steps` is advanced by graphstep.GraphedTrainStep per replay, not here)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -73,7 +85,8 @@ class FlatAdam(torch.optim.Optimizer):
         b.gather()                                   # (a no-op when allreduce_gradients() has just run)
         grp = self.param_groups[0]
         beta1, beta2 = grp["betas"]
-        self.steps += 1
+        if hyper is None:
+            self.steps += 1
         if not b.flat.is_cuda:
             # CPU rehearsal (gloo tests): the same update with torch ops on the flat buffers
             g = b.flat
@@ -91,6 +104,13 @@ class FlatAdam(torch.optim.Optimizer):
         if self._table is None or self._table[3] != tuple(p.data_ptr() for p in b.params):
             self._build_table()
         jobs, block_job, nblocks, _ = self._table
+        if hyper is not None:
+            _abi("mdf_adam_step_hyper", (jobs.data_ptr(), block_job.data_ptr(), nblocks, b.flat.data_ptr(), self.exp_avg.data_ptr(),
+                                         self.exp_avg_sq.data_ptr(), hyper.data_ptr(), ctypes.c_float(beta1), ctypes.c_float(beta2),
+                                         ctypes.c_float(grp["eps"]), ctypes.c_float(grp["weight_decay"]), _stream(b.flat)),
+                 tag=f"{len(b.params)} tensors")
+            _graph.increment_version(b.params)
+            return loss
         _abi("mdf_adam_step", (jobs.data_ptr(), block_job.data_ptr(), nblocks, b.flat.data_ptr(), self.exp_avg.data_ptr(),
                                self.exp_avg_sq.data_ptr(), ctypes.c_float(grp["lr"]), ctypes.c_float(beta1), ctypes.c_float(beta2),
                                ctypes.c_float(grp["eps"]), ctypes.c_float(grp["weight_decay"]), self.steps, _stream(b.flat)),

@@ -30,6 +30,18 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 n = int(os.environ.get("MDF_TRAIN_STEPS", "10"))
 for _ in range(n): l = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+if os.environ.get("MDF_TRAIN_GRAPH") == "1":       # the same step recorded once and replayed (mdfnet_hip/graphstep.py)
+    from mdfnet_hip.graphstep import GraphedTrainStep
+    t0 = time.perf_counter()
+    gstep = GraphedTrainStep(model, crit, bucket, opt, (imgs, extr, intr, dr, gt), warmup=1)
+    torch.cuda.synchronize(); trec = time.perf_counter() - t0
+    for _ in range(3): lg = gstep(imgs, extr, intr, dr, gt)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): lg = gstep(imgs, extr, intr, dr, gt)
+    t_issue = (time.perf_counter() - t0) / n
+    torch.cuda.synchronize(); dtg = (time.perf_counter() - t0) / n
+    print(f"train step {W}x{H}x{V} B=1 [one hipGraph replay per step]: {dtg*1e3:.2f} ms ({1/dtg:.2f} samples/s; host {t_issue*1e3:.2f} ms per step), "
+          f"loss {float(lg):.3f}, recording {trec:.2f} s, eager {dt*1e3:.2f} ms", flush=True)
 mode = "stock PyTorch-ROCm autograd" if os.environ.get("MDF_TRAIN_STOCK") == "1" else "HIP training kernels"
 print(f"train step {W}x{H}x{V} B=1 [{mode}]: {dt*1e3:.1f} ms  ({1/dt:.2f} samples/s), loss {float(l):.3f}, peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
 if os.environ.get("MDF_TRAIN_STOCK") != "1" and not os.environ.get("MDF_TRAIN_NOPROFILE"):
