@@ -1,9 +1,11 @@
 """A whole training step -- forward, loss, backward, gradient bucket, Adam (train.py:36-45) -- recorded ONCE as a hipGraph and
 replayed per step.
 
-Why: at BASELINE config 3 the step is ~330 launches of 5-300 us; issued one by one from Python the host needs as long to issue
-them (~9 ms) as the GPU needs to run them (~8 ms of kernel time), so neither a faster kernel nor a leaner wrapper moves the wall
-clock on its own.  A replay is one host call; the launches are dispatched by the runtime from the recorded graph.
+Why: at BASELINE config 3 the step is ~330 launches of 5-300 us.  Issued one by one from Python they keep the host busy for the
+whole step (~9 ms of issue time for ~9 ms of wall); a replay is one host call (0.45 ms per step including the uploads below), so
+the host is free for the loader, for the collective of a multi-rank step and for the next batch's control plane.  It does NOT
+shorten the step on this stack: the GPU executes the same launches with the same ~3-4 us between two dependent ones (cfg3: 8.96 ms
+replayed, 9.0-9.1 ms eager).  Opt-in: train.py takes it with MDF_TRAIN_HIPGRAPH=1.
 
 What has to hold for a recording to stay valid, and how each point is met:
   * every address the kernels touch is the same at every replay: activations, gradients and workspaces come from the graph's
@@ -28,7 +30,7 @@ use (tests/test_train_graph_gpu.py: three steps with different cameras and image
 import torch
 from torch.autograd import graph as _graph
 
-from . import controlplane, hostmirror, train_ops
+from . import controlplane, hostmirror
 
 
 class GraphedTrainStep:
@@ -62,10 +64,11 @@ class GraphedTrainStep:
         host = [hostmirror.get(t).clone() for t in (extr, intr, dr)]
         cur = torch.cuda.current_stream(dev)
         self.stream.wait_stream(cur)
+        self.warmup_loss = None                             # loss of the last warm-up step (a real training step on the example)
         with torch.cuda.stream(self.stream):
             for _ in range(warmup):
                 self._upload(*host)
-                self._eager_step()
+                self.warmup_loss = self._eager_step().clone()
         cur.wait_stream(self.stream)
         torch.cuda.synchronize(dev)
         self._record(host)

@@ -18,18 +18,35 @@ from net import loss as loss_mod
 from tools.data_io import tocuda
 
 
+HIP_GRAPH = bool(int(os.environ.get("MDF_TRAIN_HIPGRAPH", "0")))   # opt-in: the step recorded once, replayed per batch (mdfnet_hip/graphstep.py)
+
+
 def train_one_epoch(model, bucket, optimizer, loss_criterion, batches, device, log=print, epoch=0):
     model.train()
     total = 0.0
     for it, data in enumerate(batches):
+        host = data
         data = tocuda(data, device)
         t0 = time.time()
-        out = model(data["imgs"], data["extrinsics"], data["intrinsics"], data["depth_range"])
-        loss = loss_criterion(out, data["ref_depths"], data["depth_range"])
-        bucket.zero_grad()
-        loss.backward()
-        bucket.allreduce_gradients()
-        optimizer.step()
+        if HIP_GRAPH and torch.device(device).type == "cuda":
+            # the first batch is stepped eagerly (it is the recording's one warm-up step), every later one is a replay; cameras and
+            # range are handed over as the loader's HOST tensors -- their arithmetic is the host's (scale.py, base.py)
+            args = (data["imgs"], host["extrinsics"], host["intrinsics"], host["depth_range"], data["ref_depths"])
+            step = getattr(model, "_mdf_graph_step", None)
+            if step is None:
+                from mdfnet_hip.graphstep import GraphedTrainStep
+                example = (data["imgs"], data["extrinsics"], data["intrinsics"], data["depth_range"], data["ref_depths"])
+                step = model._mdf_graph_step = GraphedTrainStep(model, loss_criterion, bucket, optimizer, example, warmup=1)
+                loss = step.warmup_loss
+            else:
+                loss = step(*args)
+        else:
+            out = model(data["imgs"], data["extrinsics"], data["intrinsics"], data["depth_range"])
+            loss = loss_criterion(out, data["ref_depths"], data["depth_range"])
+            bucket.zero_grad()
+            loss.backward()
+            bucket.allreduce_gradients()
+            optimizer.step()
         cur = loss.detach().item()
         total += cur
         log("\r" + "epoch: " + str(epoch) + " batch: " + str(it + 1) + "/" + str(len(batches))

@@ -17,14 +17,17 @@ from tools import data_io
 pytestmark = pytest.mark.gpu
 
 
-def test_two_rank_training_epoch_on_one_card(tmp_path):
+@pytest.mark.parametrize("hipgraph", ["0", "1"])
+def test_two_rank_training_epoch_on_one_card(tmp_path, hipgraph):
+    """hipgraph = 1: the same epoch with every step after the first replayed from two recordings per rank (forward .. bucket gather, and
+    Adam) around the eager all-reduce (mdfnet_hip/graphstep.py, MDF_TRAIN_HIPGRAPH)."""
     root = tmp_path / "data"
     synthetic.write_blendedmvs_set(str(root / "blendedmvs768x576"), scans=("scanA", "scanB"), nviews_total=7, width=128, height=96, short_pairs=False)
     pkg = os.path.dirname(os.path.dirname(data_io.__file__))
     env = dict(os.environ, MDF_DATA_ROOT=str(root), MDF_PTH_PATH=str(tmp_path / "pth"), MDF_MAX_EPOCH="1", OMP_NUM_THREADS="2", PYTHONPATH=pkg,
-               MDF_SHARE_GPU="1", MDF_DIST_BACKEND="gloo", MDF_DUMP_RANK_STATE=str(tmp_path))
+               MDF_SHARE_GPU="1", MDF_DIST_BACKEND="gloo", MDF_DUMP_RANK_STATE=str(tmp_path), MDF_TRAIN_HIPGRAPH=hipgraph)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29653", os.path.join(pkg, "train.py"), "-d", "blendedmvs"],
+                        "--master-port", str(29653 + int(hipgraph)), os.path.join(pkg, "train.py"), "-d", "blendedmvs"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     ck = torch.load(str(tmp_path / "pth" / "blendedmvs_1.pth"), map_location="cpu")
