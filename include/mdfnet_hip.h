@@ -350,6 +350,19 @@ int mdf_masked_smooth_l1_finalize(const double* acc, int nscales, float* loss, f
 int mdf_masked_smooth_l1_bwd(const float* est, const float* gt, const void* floor_, int floor_f64, int floor_stride, int B,
                              long long per_batch, const float* dloss, const float* inv_count, float* dest, void* stream);
 
+/* ---- feature-pyramid heads in training mode, the small algebra (net/unit/backbone.py:59-63: lat2, lat3, out2, out3, out4 -- 1x1 convs
+ *      around two bilinear up-samplings, evaluated through the products O2 L2, O2 L3, O3 L3; train_ops.py:FPNHeadsComposedFn).
+ *      Matrices are the Conv2d weights, row-major [out][in]: O2 [c2][cm], O3 [c3][cm], L2 [cm][c2], L3 [cm][c3], biases b2, b3 [cm].
+ *      _fwd writes comp = A2 = O2 L2 [c2][c2] | B3 = O2 L3 [c2][c3] | A3 = O3 L3 [c3][c3] | O2 b2 [c2] | O2 b3 [c2] | O3 b3 [c3].
+ *      _bwd maps the gradients of the composed matrices (dA2, dB3, dA3), the pixel sums W2 = sum g (x) t4 [c2][cm], W3 [c3][cm] and
+ *      the per-channel gradient sums s2, sc3 [c2], s3 [c3] (double, as mdf_bn_stats_fwd leaves them) onto the parameters' gradients.  */
+int mdf_fpn_compose_fwd(const float* O2, const float* O3, const float* L2, const float* b2, const float* L3, const float* b3,
+                        int c2, int c3, int cm, float* comp, void* stream);
+int mdf_fpn_compose_bwd(const float* O2, const float* O3, const float* L2, const float* b2, const float* L3, const float* b3,
+                        const float* dA2, const float* dB3, const float* dA3, const float* W2, const float* W3,
+                        const double* s2, const double* sc3, const double* s3, int c2, int c3, int cm, float* dO2, float* dO3,
+                        float* dL2, float* dL3, float* db2, float* db3, void* stream);
+
 /* ---- optimizer step (train.py:14,43: torch.optim.Adam(lr) -> optimizer.step()) over all parameters in one launch.  The
  *      parameters stay the module's tensors; grads, exp_avg, exp_avg_sq are flat float buffers in parameter order.  A job
  *      is one parameter tensor (param, its offset in the flat buffers, n elements); mdf_adam_job_fill writes job `index`

@@ -81,6 +81,8 @@ SIGNATURES = {
     "mdf_masked_smooth_l1_reduce": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_i64, c_fp, c_fp]),
     "mdf_masked_smooth_l1_finalize": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp]),
     "mdf_masked_smooth_l1_bwd": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_i64, c_fp, c_fp, c_fp, c_fp]),
+    "mdf_fpn_compose_fwd": (c_int, [c_fp] * 6 + [c_int] * 3 + [c_fp, c_fp]),
+    "mdf_fpn_compose_bwd": (c_int, [c_fp] * 14 + [c_int] * 3 + [c_fp] * 7),
     "mdf_adam_job_bytes": (c_i64, []),
     "mdf_adam_job_fill": (c_i64, [c_fp, c_int, c_fp, c_i64, c_i64, c_int]),
     "mdf_adam_step": (c_int, [c_fp, c_fp, c_int, c_fp, c_fp, c_fp] + [ctypes.c_float] * 5 + [c_i64, c_fp]),

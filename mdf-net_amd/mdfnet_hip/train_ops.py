@@ -132,19 +132,26 @@ DEFER_WGRAD_SUMS = bool(int(_os.environ.get("MDF_WGRAD_DEFER", "1")))      # dev
 _PENDING_SUMS = {}          # device index -> [stream, [(work, dw, nslab, n), ...]]
 
 
+def sum_wgrad_jobs(jobs):
+    """jobs: [(slab tensor, address of the gradient tensor, slabs, elements)] -> the gradients, ONE launch on the current stream."""
+    k = len(jobs)
+    if k == 0:
+        return
+    slabs = (ctypes.c_void_p * k)(*[j[0].data_ptr() for j in jobs])
+    outs = (ctypes.c_void_p * k)(*[j[1] for j in jobs])
+    nsl = (ctypes.c_int * k)(*[j[2] for j in jobs])
+    ns = (ctypes.c_int * k)(*[j[3] for j in jobs])
+    _abi("mdf_wgrad_sum_batch", (slabs, outs, nsl, ns, k, _stream(jobs[0][0])), tag=f"{k} weight gradients",
+         work={"bytes": 4.0 * sum(j[2] * j[3] for j in jobs), "bound": "hbm"})
+
+
 def _flush_wgrad_sums(dev_index):
     ent = _PENDING_SUMS.pop(dev_index, None)
     if not ent or not ent[1]:
         return
     st, jobs = ent
-    k = len(jobs)
-    slabs = (ctypes.c_void_p * k)(*[j[0].data_ptr() for j in jobs])
-    outs = (ctypes.c_void_p * k)(*[j[1] for j in jobs])
-    nsl = (ctypes.c_int * k)(*[j[2] for j in jobs])
-    ns = (ctypes.c_int * k)(*[j[3] for j in jobs])
     with torch.cuda.stream(st):
-        _abi("mdf_wgrad_sum_batch", (slabs, outs, nsl, ns, k, _stream(jobs[0][0])), tag=f"{k} weight gradients",
-             work={"bytes": 4.0 * sum(j[2] * j[3] for j in jobs), "bound": "hbm"})
+        sum_wgrad_jobs(jobs)
 
 
 def _sum_later(work, dw, nslab, n, param):
@@ -450,8 +457,10 @@ def aggregate_train(module, features, proj, hypos):
 
 
 # --------------------------------------------------------------------------- feature-pyramid trunk (2-D) in training mode
-def conv2d_wgrad(small, big, ksize, stride, out_shape, param=None):
-    """dw[a][b][kh][kw] = sum_o small[o][a] * big[stride*o + (kh,kw) - pad][b]; small [B,Hs,Ws,A], big [B,s*Hs,s*Ws,Bc] NHWC."""
+def conv2d_wgrad(small, big, ksize, stride, out_shape, param=None, hold=None):
+    """dw[a][b][kh][kw] = sum_o small[o][a] * big[stride*o + (kh,kw) - pad][b]; small [B,Hs,Ws,A], big [B,s*Hs,s*Ws,Bc] NHWC.
+    hold: a list -- the partial tiles are left un-summed and their job is appended to it; the caller sums several gradients it needs
+    at once with ONE sum_wgrad_jobs(hold) (and must do so before reading any of them)."""
     _need_gpu(small, big)
     b, hs, ws, a = small.shape
     bc = big.shape[-1]
@@ -464,6 +473,10 @@ def conv2d_wgrad(small, big, ksize, stride, out_shape, param=None):
     _abi("mdf_conv2d_wgrad_partial", (small.data_ptr(), big.data_ptr(), dw.data_ptr(), work.data_ptr(), b, hs, ws, a, bc, ksize, stride,
                                       ctypes.byref(nslab), _stream(dw)), tag=f"wgrad2d {a}x{bc} k{ksize}s{stride} {hs}x{ws}x{b}",
          work={"flops": 2.0 * ksize * ksize * a * bc * b * hs * ws, "bytes": 4.0 * (small.numel() + big.numel()), "bound": "mfma"})
+    if hold is not None:
+        assert tuple(out_shape) == tuple(dw.shape)
+        hold.append((work, dw.data_ptr(), nslab.value, dw.numel()))
+        return dw
     _sum_later(work, dw, nslab.value, dw.numel(), param if tuple(out_shape) == tuple(dw.shape) else None)
     if tuple(out_shape) != tuple(dw.shape):
         pass     # (the image layer's weight gradient is computed over 4 padded input channels: summed at once, sliced below)
@@ -625,6 +638,7 @@ class PackPlan:
         from .layers import cache_of_key
         L = lib()
         self.jobs, self.entries = [], []          # jobs: ctypes arguments; entries: (cache, parameter, value)
+        self.fpn = None                           # composed matrices of the feature pyramid's heads (see below)
         self.device = next(model.parameters()).device
 
         def buf(is3d, cin, cout, ntaps):
@@ -672,6 +686,28 @@ class PackPlan:
             for c in (bb.lat2, bb.lat3, bb.out2, bb.out3, bb.out4):
                 entry(c, "fwd", c.weight, job(c.weight, 0, 0, _SRC_DIRECT, c.in_channels, c.out_channels, 1))
                 entry(c, "dgrad", c.weight, job(c.weight, 0, 0, _SRC_SWAP, c.out_channels, c.in_channels, 1))
+            c2, c3, cm = bb.out2.out_channels, bb.out3.out_channels, bb.out2.in_channels
+            if (COMPOSE_FPN_HEADS and (bb.lat2.in_channels, bb.lat3.in_channels) == (c2, c3) and bb.lat2.bias is not None and bb.lat3.bias is not None
+                    and bb.out2.bias is None and bb.out3.bias is None
+                    and {bb.out3.in_channels, bb.out4.in_channels, bb.lat2.out_channels, bb.lat3.out_channels} == {cm}):
+                # the heads through their algebra (FPNHeadsComposedFn): A2 = O2 L2, B3 = O2 L3, A3 = O3 L3 and three bias vectors are
+                # formed by ONE launch ahead of the batched pack (mdf_fpn_compose_fwd), which then packs them like parameters
+                comp = torch.empty(c2 * c2 + c2 * c3 + c3 * c3 + 2 * c2 + c3, device=self.device, dtype=torch.float32)
+                o = [0]
+
+                def piece(*shape):
+                    n = 1
+                    for d in shape:
+                        n *= d
+                    v = comp[o[0]:o[0] + n].view(shape)
+                    o[0] += n
+                    return v
+                A2, B3, A3 = piece(c2, c2, 1, 1), piece(c2, c3, 1, 1), piece(c3, c3, 1, 1)
+                self.fpn = {"bb": bb, "dims": (c2, c3, cm), "comp": comp, "e2": piece(c2), "e3": piece(c2), "f3": piece(c3),
+                            "A2f": job(A2, 0, 0, _SRC_DIRECT, c2, c2, 1), "A2t": job(A2, 0, 0, _SRC_SWAP, c2, c2, 1),
+                            "B3f": job(B3, 0, 0, _SRC_DIRECT, c3, c2, 1), "B3t": job(B3, 0, 0, _SRC_SWAP, c2, c3, 1),
+                            "A3f": job(A3, 0, 0, _SRC_DIRECT, c3, c3, 1), "A3t": job(A3, 0, 0, _SRC_SWAP, c3, c3, 1),
+                            "params": (bb.out2.weight, bb.out3.weight, bb.lat2.weight, bb.lat2.bias, bb.lat3.weight, bb.lat3.bias)}
         rf = getattr(model, "Refine", None)
         if rf is not None and hasattr(rf, "ress"):
             shuffled = rf.conv2[0]
@@ -701,6 +737,10 @@ class PackPlan:
             if id(p_) not in seen:
                 seen.add(id(p_))
                 self.params.append(p_)
+        for p_ in (self.fpn["params"] if self.fpn is not None else ()):      # (the heads' biases have no packed set of their own)
+            if id(p_) not in seen:
+                seen.add(id(p_))
+                self.params.append(p_)
         self.ptrs = tuple(p_.data_ptr() for p_ in self.params)
         self.versions = None
 
@@ -710,9 +750,18 @@ class PackPlan:
     def run(self):
         versions = tuple(p_._version for p_ in self.params)
         if versions != self.versions:
+            if self.fpn is not None:
+                f = self.fpn
+                O2, O3, L2, b2, L3, b3 = f["params"]
+                c2, c3, cm = f["dims"]
+                _abi("mdf_fpn_compose_fwd", (O2.data_ptr(), O3.data_ptr(), L2.data_ptr(), b2.data_ptr(), L3.data_ptr(), b3.data_ptr(), c2, c3, cm,
+                                             f["comp"].data_ptr(), _stream(f["comp"])), tag="composed FPN head matrices")
             _abi("mdf_pack_batch", (self.table.data_ptr(), self.block_job.data_ptr(), self.nblocks, _stream(self.table)),
                  tag=f"{len(self.jobs)} weight sets")
             self.versions = versions
+        if self.fpn is not None:      # the heads find this step's composed packs on their module (valid while the parameters are these)
+            self.fpn["key"] = tuple((p_.data_ptr(), p_._version) for p_ in self.fpn["params"])
+            self.fpn["bb"].__dict__["_mdf_fpn"] = self.fpn
         idx = self.device.index
         for cache, p_, value in self.entries:
             cache.key, cache.val, cache.ev, cache.seen = ((p_.data_ptr(), p_._version, idx),), value, None, ()
@@ -826,8 +875,32 @@ class FPNHeadsComposedFn(torch.autograd.Function):
     maps, mapped back onto the seven parameters by a dozen tiny matrix products."""
 
     @staticmethod
+    def _plan(m):
+        """This step's composed matrices, packed by the step's weight pack (PackPlan, mdf_fpn_compose_fwd) -- or None when the heads are
+        called outside a prepared training step (then the same algebra runs as torch ops, below)."""
+        f = m.__dict__.get("_mdf_fpn")
+        if f is not None and f["key"] == tuple((p_.data_ptr(), p_._version) for p_ in f["params"]):
+            return f
+        return None
+
+    @staticmethod
     def forward(ctx, m, t2, t3, t4, *params):
         t2n, t3n, t4n = ops.to_nhwc(t2.detach()), ops.to_nhwc(t3.detach()), ops.to_nhwc(t4.detach())
+        f = FPNHeadsComposedFn._plan(m)
+        if f is not None:
+            c2, c3, cm = f["dims"]
+
+            def cw(x, wp, cin, cout, bias=None, res_up=None):
+                return ops.conv2d_nhwc(x, wp, cin, cout, 1, 1, None, bias, False, None, 1.0, res_up)
+            with torch.no_grad():
+                y4 = cw(t4n, _pack1x1(m.out4, False), cm, m.out4.out_channels)
+                y3 = cw(t3n, f["A3f"], c3, c3, f["f3"], res_up=cw(t4n, _pack1x1(m.out3, False), cm, c3))
+                u3 = cw(t3n, f["B3f"], c3, c2, f["e3"], res_up=cw(t4n, _pack1x1(m.out2, False), cm, c2))
+                y2 = cw(t2n, f["A2f"], c2, c2, f["e2"], res_up=u3)
+            ctx.m, ctx.saved, ctx.params, ctx.fast = m, (t2n, t3n, t4n), params, f
+            ctx.set_materialize_grads(False)
+            return ops.from_nhwc(y4), ops.from_nhwc(y3), ops.from_nhwc(y2)
+        ctx.fast = None
         with torch.no_grad():
             O2, O3, O4 = (c.weight.detach().reshape(c.out_channels, c.in_channels) for c in (m.out2, m.out3, m.out4))
             L2, L3 = (c.weight.detach().reshape(c.out_channels, c.in_channels) for c in (m.lat2, m.lat3))
@@ -851,6 +924,8 @@ class FPNHeadsComposedFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g4, g3, g2):
         m = ctx.m
+        if ctx.fast is not None:
+            return FPNHeadsComposedFn._backward_fast(ctx, g4, g3, g2)
         t2n, t3n, t4n, O2, O3, O4, L2, L3, b2, b3, A2, B3, A3 = ctx.saved
         pool = step_pool(t2n.device)
 
@@ -911,6 +986,62 @@ class FPNHeadsComposedFn(torch.autograd.Function):
         return (None, ops.from_nhwc(dt2), ops.from_nhwc(dt3), ops.from_nhwc(dt4)) + tuple(pg.get(p) for p in ctx.params)
 
 
+def _fpn_backward_fast(ctx, g4, g3, g2):
+    """The backward of FPNHeadsComposedFn on the step's packed composed matrices: the five large-map weight gradients are summed
+    by ONE launch, the map back onto the seven parameters is ONE launch (mdf_fpn_compose_bwd)."""
+    m, f = ctx.m, ctx.fast
+    t2n, t3n, t4n = ctx.saved
+    c2, c3, cm = f["dims"]
+    dev = t2n.device
+    pool = step_pool(dev)
+    if g2 is None or g3 is None or g4 is None:      # (a head without a gradient: not a training step of this network)
+        g4 = torch.zeros_like(ops.from_nhwc(t4n)[:, :m.out4.out_channels]) if g4 is None else g4
+        g3 = torch.zeros((t3n.shape[0], c3, t3n.shape[1], t3n.shape[2]), device=dev) if g3 is None else g3
+        g2 = torch.zeros((t2n.shape[0], c2, t2n.shape[1], t2n.shape[2]), device=dev) if g2 is None else g2
+    hold = []
+
+    def cwt(g, wp, cin, cout, res=None):            # W^T g on the transposed pack
+        return ops.conv2d_nhwc(g, wp, cin, cout, 1, 1, None, None, False, res, 1.0, None)
+
+    def wg(g, t):
+        return conv2d_wgrad(g, t, 1, 1, (g.shape[-1], t.shape[-1], 1, 1), hold=hold)
+
+    def colsum(g):
+        c = g.shape[-1]
+        return bn_stats(g, g.numel() // c, c, pool=pool)
+    g2n, g3n, g4n = ops.to_nhwc(g2), ops.to_nhwc(g3), ops.to_nhwc(g4)
+    dA2, s2 = wg(g2n, t2n), colsum(g2n)
+    dt2 = cwt(g2n, f["A2t"], c2, c2)
+    gc3 = upsample2_backward(g2n)                                  # [.,h/4,w/4,c2]
+    dB3, sc3 = wg(gc3, t3n), colsum(gc3)
+    dt3 = cwt(gc3, f["B3t"], c2, c3)
+    gc4 = upsample2_backward(gc3)                                  # [.,h/8,w/8,c2]
+    W2 = wg(gc4, t4n)
+    dt4 = cwt(gc4, _pack1x1(m.out2, True), c2, cm)
+    dA3, s3 = wg(g3n, t3n), colsum(g3n)
+    dt3 = cwt(g3n, f["A3t"], c3, c3, res=dt3)
+    ga4 = upsample2_backward(g3n)                                  # [.,h/8,w/8,c3]
+    W3 = wg(ga4, t4n)
+    dt4 = cwt(ga4, _pack1x1(m.out3, True), c3, cm, res=dt4)
+    dO4 = conv2d_wgrad(g4n, t4n, 1, 1, tuple(m.out4.weight.shape), m.out4.weight)      # (summed with the rest of the pass)
+    dt4 = cwt(g4n, _pack1x1(m.out4, True), m.out4.out_channels, cm, res=dt4)
+    sum_wgrad_jobs(hold)
+    O2, O3, L2, b2, L3, b3 = f["params"]
+    out = {p_: torch.empty_like(p_) for p_ in (m.out2.weight, m.out3.weight, m.lat2.weight, m.lat3.weight, m.lat2.bias, m.lat3.bias)}
+    _abi("mdf_fpn_compose_bwd", (O2.data_ptr(), O3.data_ptr(), L2.data_ptr(), b2.data_ptr(), L3.data_ptr(), b3.data_ptr(),
+                                 dA2.data_ptr(), dB3.data_ptr(), dA3.data_ptr(), W2.data_ptr(), W3.data_ptr(),
+                                 s2.data_ptr(), sc3.data_ptr(), s3.data_ptr(), c2, c3, cm,
+                                 out[m.out2.weight].data_ptr(), out[m.out3.weight].data_ptr(), out[m.lat2.weight].data_ptr(),
+                                 out[m.lat3.weight].data_ptr(), out[m.lat2.bias].data_ptr(), out[m.lat3.bias].data_ptr(), _stream(t2n)),
+         tag="FPN head parameter gradients")
+    out[m.out4.weight] = dO4
+    ctx.saved = None
+    return (None, ops.from_nhwc(dt2), ops.from_nhwc(dt3), ops.from_nhwc(dt4)) + tuple(out.get(p_) for p_ in ctx.params)
+
+
+FPNHeadsComposedFn._backward_fast = staticmethod(_fpn_backward_fast)
+
+
 def fpn_heads_train(module, t2, t3, t4):
     params = tuple(p for mod in (module.lat2, module.lat3, module.out2, module.out3, module.out4) for p in mod.parameters())
     fn = FPNHeadsComposedFn if (COMPOSE_FPN_HEADS and module.lat2.bias is not None and module.out2.bias is None) else FPNHeadsTrainFn
@@ -937,7 +1068,9 @@ class RefineTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, m, depth, lo, span, *params):
-        x = ((depth.detach().unsqueeze(1) - lo) / span).permute(0, 2, 3, 1).contiguous()          # [B,h,w,1]
+        bsz = depth.shape[0]
+        # (depth - lo) / span and lo + o * span: one launch each with torch's roundings (mdf_range_affine_fwd, as in eval)
+        x = ops.range_affine(depth.detach(), lo.reshape(bsz), span.reshape(bsz), 0).unsqueeze(-1)   # [B,h,w,1]
         x0 = _conv3x3(m.conv0, x)
         y, chain = x0, []
         for blk in m.ress:                                                                          # y + 0.1*conv(relu(conv(y)))
@@ -949,7 +1082,7 @@ class RefineTrainFn(torch.autograd.Function):
         s_ = _conv3x3(m.conv2[0], z, shuffle=True)                                                  # [B,2h,2w,8]
         o = _conv3x3(m.conv2[2], s_)                                                                # [B,2h,2w,1]
         ctx.m, ctx.saved, ctx.params, ctx.span = m, (x, x0, chain, y, z, s_), params, span
-        return (lo + o.permute(0, 3, 1, 2) * span).squeeze(1)
+        return ops.range_affine(o.squeeze(-1), lo.reshape(bsz), span.reshape(bsz), 1)
 
     @staticmethod
     def backward(ctx, dout):

@@ -523,8 +523,13 @@ def test_all_parameter_gradients_vs_the_oracle(golden, seeded_sd):
     m = build_model()
     m.load_state_dict(seeded_sd)
     m.train().to(DEV)
+    ops.count_begin()
     out, loss = _step(m, DEV, g)
     loss.backward()
+    calls = ops.count_end()
+    # inside a prepared step the pyramid's heads run on the step's packed composed matrices: one launch forms them, one maps their
+    # gradients back onto the seven parameters (csrc/fpn_compose.hip), one slab sum serves the five large-map products
+    assert calls.get("mdf_fpn_compose_fwd") == 1 and calls.get("mdf_fpn_compose_bwd") == 1, calls
     for i, (a, b) in enumerate(zip(out["depth"], out_ref["depth"])):
         err = (a.detach().cpu() - b.detach()).abs()
         print(f"\ndepth{i}: HIP training path vs the oracle (same host): mean |d| {float(err.mean()):.3e} max {float(err.max()):.3e}")
