@@ -3,8 +3,8 @@
 //     y4 = O4 t4,   y3 = up(O3 t4) + (O3 L3) t3 + O3 b3,   y2 = up(up(O2 t4) + (O2 L3) t3 + O2 b3) + (O2 L2) t2 + O2 b2
 // and the 64-channel 1/2- and 1/4-resolution tensors are never formed (train_ops.py:FPNHeadsComposedFn).  What is left of the
 // five convs besides the large-map kernels is a dozen products of matrices with 16..64 rows: as torch ops they were ~45 launches
-// per training step (3 mm + 3 mv forward; zeros, mm, mv, outer, add backward) of a few microseconds each, every one followed
-// by the ~4 us gap between two dependent launches.  Here: ONE launch forward (the composed matrices and bias vectors, which the
+// per training step (3 mm + 3 mv forward; zeros, mm, mv, outer, add backward) of 3.5-5 us each by the rocprof trace, whatever little they
+// compute.  Here: ONE launch forward (the composed matrices and bias vectors, which the
 // step's batched weight pack then reads like any parameter) and ONE launch backward (the gradients of the composed matrices
 // mapped back onto the seven parameters).  Matrices are row-major [out][in] as the Conv2d weights are; sums run in index order.
 #include "common.h"

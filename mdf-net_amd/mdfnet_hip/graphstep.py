@@ -4,8 +4,8 @@ replayed per step.
 Why: at BASELINE config 3 the step is ~330 launches of 5-300 us.  Issued one by one from Python they keep the host busy for the
 whole step (~9 ms of issue time for ~9 ms of wall); a replay is one host call (0.45 ms per step including the uploads below), so
 the host is free for the loader, for the collective of a multi-rank step and for the next batch's control plane.  It does NOT
-shorten the step on this stack: the GPU executes the same launches with the same ~3-4 us between two dependent ones (cfg3: 8.96 ms
-replayed, 9.0-9.1 ms eager).  Opt-in: train.py takes it with MDF_TRAIN_HIPGRAPH=1.
+shorten the step: its wall clock is the sum of its kernels' durations either way (cfg3: 8.96 ms replayed, 9.0-9.1 ms eager; the rocprof
+trace of the eager step shows the kernels back to back).  Opt-in: train.py takes it with MDF_TRAIN_HIPGRAPH=1.
 
 What has to hold for a recording to stay valid, and how each point is met:
   * every address the kernels touch is the same at every replay: activations, gradients and workspaces come from the graph's

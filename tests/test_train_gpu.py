@@ -787,3 +787,38 @@ def test_wgrad_tap_packing_row_lengths(a, bc, w):
         else:
             dw = train_ops.conv2d_wgrad(ops.to_nhwc(dy.to(DEV)), ops.to_nhwc(x.detach().to(DEV)), 3, 1, tuple(conv.weight.shape))
         assert _rel(dw, conv.weight.grad) < 3e-5, (three_d, _rel(dw, conv.weight.grad))
+
+
+def test_fpn_head_algebra_kernels_vs_float64():
+    """csrc/fpn_compose.hip on its own: the composed matrices and the map of their gradients back onto the seven parameters, against
+    the same products in float64 (backbone.py:59-63 written out; train_ops.py:FPNHeadsComposedFn holds the torch form)."""
+    import ctypes
+    from mdfnet_hip import lib, check
+    rng = np.random.RandomState(9)
+    c2, c3, cm = 16, 32, 64
+    f = lambda *s: T(rng.randn(*s).astype(np.float32))
+    O2, O3, L2, b2, L3, b3 = f(c2, cm), f(c3, cm), f(cm, c2), f(cm), f(cm, c3), f(cm)
+    dev = [t.to(DEV) for t in (O2, O3, L2, b2, L3, b3)]
+    comp = torch.empty(c2 * c2 + c2 * c3 + c3 * c3 + 2 * c2 + c3, device=DEV)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    check(lib().mdf_fpn_compose_fwd(*[t.data_ptr() for t in dev], c2, c3, cm, comp.data_ptr(), st), "mdf_fpn_compose_fwd")
+    d = [t.double() for t in (O2, O3, L2, b2, L3, b3)]
+    exp = torch.cat([(d[0] @ d[2]).reshape(-1), (d[0] @ d[4]).reshape(-1), (d[1] @ d[4]).reshape(-1), d[0] @ d[3], d[0] @ d[5], d[1] @ d[5]])
+    assert _rel(comp, exp) < 2e-6
+    dA2, dB3, dA3, W2, W3 = f(c2, c2), f(c2, c3), f(c3, c3), f(c2, cm), f(c3, cm)
+    s2, sc3, s3 = (T(rng.randn(n)) for n in (c2, c2, c3))          # float64, as mdf_bn_stats_fwd leaves the sums
+    g = [t.to(DEV) for t in (dA2, dB3, dA3, W2, W3, s2, sc3, s3)]
+    outs = [torch.empty(s, device=DEV) for s in ((c2, cm), (c3, cm), (cm, c2), (cm, c3), (cm,), (cm,))]
+    check(lib().mdf_fpn_compose_bwd(*[t.data_ptr() for t in dev], *[t.data_ptr() for t in g], c2, c3, cm, *[t.data_ptr() for t in outs], st),
+          "mdf_fpn_compose_bwd")
+    dA2, dB3, dA3, W2, W3 = (t.double() for t in (dA2, dB3, dA3, W2, W3))
+    s2f, sc3f, s3f = (t.float().double() for t in (s2, sc3, s3))
+    exp = [W2 + dA2 @ d[2].t() + torch.outer(s2f, d[3]) + dB3 @ d[4].t() + torch.outer(sc3f, d[5]),
+           W3 + dA3 @ d[4].t() + torch.outer(s3f, d[5]),
+           d[0].t() @ dA2, d[0].t() @ dB3 + d[1].t() @ dA3, d[0].t() @ s2f, d[0].t() @ sc3f + d[1].t() @ s3f]
+    for got, e in zip(outs, exp):
+        assert _rel(got, e) < 3e-6
+    # error convention: null pointer / bad shape -> MDF_EARG with a message, nothing launched
+    assert lib().mdf_fpn_compose_fwd(None, *[t.data_ptr() for t in dev[1:]], c2, c3, cm, comp.data_ptr(), st) != 0
+    assert b"null pointer" in lib().mdf_last_error()
+    assert lib().mdf_fpn_compose_fwd(*[t.data_ptr() for t in dev], 0, c3, cm, comp.data_ptr(), st) != 0
