@@ -113,9 +113,10 @@ int mdf_conv3d_pack_weights(const float* w, float* wpack, int Cin, int Cout, int
  *      align_corners=False, is added -- the FPN top-down step backbone.py:60,62 fused into the lateral conv).
  *   x [B,H,W,Cin] NHWC, or planar [B,Cin,H,W] when planar_in != 0 (Cin < 4 only: the RGB images as eval.py hands
  *   them over, so no layout copy is needed); y [B,Ho,Wo,Cout] NHWC; wpack from mdf_conv_pack_weights (Cin 3 or 1 is
- *   zero-padded to 4).  pixel_shuffle2 != 0 (Cout = 32, stride 1, no residual): y is nn.PixelShuffle(2) of the result,
- *   [B,2Ho,2Wo,8] NHWC (refine.py:19), and the weight rows must have been packed sub-pixel-major: row (dy*2+dx)*8 + oc =
- *   torch output channel oc*4 + dy*2 + dx.                                                                            */
+ *   zero-padded to 4).  pixel_shuffle2 != 0 (Cout = 32, or 32 -> 64 with k = 3; stride 1, no residual): y is nn.PixelShuffle(2)
+ *   of the result, [B,2Ho,2Wo,Cout/4] NHWC (refine.py:19), and the weight rows must have been packed sub-pixel-major: row
+ *   (dy*2+dx)*Cout/4 + oc = torch output channel oc*4 + dy*2 + dx.  (Training uses the same store for the input gradient of the
+ *   k5-s2 pyramid layers, a 3x3 conv over dy whose output rows are the four parity classes of dx.)                       */
 int mdf_conv2d_fwd(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
                    float res_scale, const float* res_up, float* y, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int relu,
                    int planar_in, int pixel_shuffle2, void* stream);

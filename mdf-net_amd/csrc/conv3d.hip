@@ -841,7 +841,7 @@ static int conv2d_entry(const float* x, const float* wpack, const float* alpha, 
   MDF_REQUIRE(res_up == nullptr || (stride == 1 && H % 2 == 0 && W % 2 == 0 && Cout % 4 == 0),
               "res_up needs stride 1, even H and W, Cout %% 4 == 0");
   MDF_REQUIRE(!planar_in || Cin_mem < 4, "planar (NCHW) input is supported for Cin < 4 only (the image layer)");
-  MDF_REQUIRE(!pixel_shuffle2 || (Cout == 32 && stride == 1 && !res && !res_up), "pixel_shuffle2 output is built for Cout = 32, stride 1, no residual");
+  MDF_REQUIRE(!pixel_shuffle2 || ((Cout == 32 || (Cout == 64 && Cin_mem == 32 && ksize == 3)) && stride == 1 && !res && !res_up && !stat), "pixel_shuffle2 output is built for Cout = 32 (and 32 -> 64 k3), stride 1, no residual, no epilogue sums");
   if (ksize == 1 && stride == 1 && !stat && !planar_in && !pixel_shuffle2) {   // 1x1 layers: streaming kernel (conv1x1.hip)
     const int rc1 = mdf_conv1x1_dispatch(x, wpack, alpha, beta, res, res_scale, res_up, y, B, H, W, Cin_mem, Cout, relu, stream);
     if (rc1 != MDF_EUNSUPPORTED) return rc1;

@@ -294,7 +294,14 @@ __device__ __forceinline__ void wino_epilogue(const f32x4 (&acc)[16][C::NTP], in
           o[k] = y[pr][r][k] * al_l[k] + be_l[k];
           if (p.relu) o[k] = fmaxf(o[k], 0.f);
         }
-        const size_t oi = (row_vox + ow) * COUT + c0;
+        size_t oi = (row_vox + ow) * COUT + c0;
+        if constexpr (C::NPL == 1 && ((C::CIN_ == 16 && COUT == 32) || (C::CIN_ == 32 && COUT == 64))) {
+          if (p.shuffle2) {   // input gradient of a k5-s2 layer (training): GEMM row = parity class * Cq + channel, stored at pixel (2h + py, 2w + px)
+            constexpr int CQ = COUT / 4;
+            const int sub = c0 / CQ, oc0 = c0 % CQ;
+            oi = ((2 * (row_vox / p.Wo) + (sub >> 1)) * (size_t)(2 * p.Wo) + 2 * ow + (sub & 1)) * CQ + oc0;
+          }
+        }
         if (p.res) {
           const float4 rr = *reinterpret_cast<const float4*>(p.res + oi);
           o[0] = rr.x + o[0] * p.res_scale; o[1] = rr.y + o[1] * p.res_scale;
@@ -925,7 +932,7 @@ extern "C" int mdf_release_stream(void* stream) {
     return !stat ? launch_lds<ci, ci, co, 3, 3, 1, 1, 2, 1>(p, (hipStream_t)stream) : (stat->mode == 1 ? launch_lds<ci, ci, co, 3, 3, 1, 1, 2, 1, 1>(p, (hipStream_t)stream) : launch_lds<ci, ci, co, 3, 3, 1, 1, 2, 1, 2>(p, (hipStream_t)stream)); \
   }
 #define LDS_CASE_WG2(ci, co)                                                                     \
-  if (use_wg && KD == 1 && KHW == 3 && stride == 1 && Cin == ci && Cin_mem == ci && Cout == co && !res_up && !shuffle2) { \
+  if (use_wg && KD == 1 && KHW == 3 && stride == 1 && Cin == ci && Cin_mem == ci && Cout == co && !res_up && (!shuffle2 || (ci == 16 && co == 32) || (ci == 32 && co == 64))) { \
     p.wpack = wpack + (size_t)9 * ci * (((co + 15) / 16) * 16);                                  \
     return !stat ? launch_lds<ci, ci, co, 1, 3, 1, 1, 2, 1>(p, (hipStream_t)stream) : (stat->mode == 1 ? launch_lds<ci, ci, co, 1, 3, 1, 1, 2, 1, 1>(p, (hipStream_t)stream) : launch_lds<ci, ci, co, 1, 3, 1, 1, 2, 1, 2>(p, (hipStream_t)stream)); \
   }
@@ -975,6 +982,7 @@ int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha
       }
     }
   }
+  if (shuffle2 && Cout == 64 && !use_wg) return mdf::fail(MDF_EUNSUPPORTED, "pixel-shuffle store for Cout = 64 is built into the Winograd form only (MDF_CONV_WINOGRAD=0 is set)");
   // 3-D stride-1 layers with 8 output channels: depth-pair Winograd
   { const bool use_wd = use_wg && (wd_mask & 1); LDS_CASE_WD(8) }
   { const bool use_wd = use_wg && (wd_mask & 2); LDS_CASE_WD(16) }

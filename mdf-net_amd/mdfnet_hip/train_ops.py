@@ -524,6 +524,10 @@ def conv2d_dgrad(conv, dy, stat=None, groups=1):
         if stat is not None:
             return ops.conv2d_train(dy, packs, cout, cin, 3, 1, False, 2, stat[2], groups, stat[0], stat[1])
         return ops.conv2d_nhwc(dy, packs, cout, cin, 3, 1)
+    if len(packs) == 1 and cin in (8, 16):
+        # the four parity classes are the rows of ONE launch: the conv's store interleaves them (pixel (2h + py, 2w + px), the
+        # PixelShuffle(2) store of the refinement net's 8 -> 32 conv) -- no [.,h,w,4*cin] tensor and no copy of the full-resolution map
+        return ops.conv2d_nhwc(dy, packs[0][0], cout, 4 * cin, 3, 1, pixel_shuffle2=True)
     zs = [ops.conv2d_nhwc(dy, wp, cout, n, 3, 1) for wp, n in packs]
     z = zs[0] if len(zs) == 1 else torch.cat(zs, dim=-1)
     b_, ho, wo, _ = z.shape
