@@ -232,6 +232,30 @@ def measured_traffic(kind="eval"):
     return {}, None
 
 
+def rocprof_conv_family():
+    """The conv family's time per forward by rocprofv3 --kernel-trace --stats of the SAME command (one view at a time), from the
+    summary committed under profiles/ (scripts/r03_profiles.sh): the cross-check the contract asks the live figure to agree with.
+    The live HIP-event brackets run ~6 % above it (an event pair serialises the launch against its neighbours even after the
+    empty-bracket cost is subtracted); rocprof's durations are the kernels' own.  -> dict or None"""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r03_bench_cfg2_kernel_stats.csv")
+    if not os.path.exists(path):
+        return None
+    fam = ("conv_lds_kernel", "conv3d_kernel", "conv_pair_kernel", "conv1x1_kernel", "refine_tail_kernel", "prob_fused_kernel")
+    ns, forwards, launches = 0, 0, 0
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if "conv_pair_kernel" in r["Name"]:
+                forwards = int(r["Calls"])                      # exactly one launch per forward
+            if any(k in r["Name"] for k in fam):
+                ns += int(r["TotalDurationNs"])
+                launches += int(r["Calls"])
+    if not forwards:
+        return None
+    return {"ms_per_step": round(ns / forwards / 1e6, 3), "launches_per_step": round(launches / forwards, 1), "forwards": forwards,
+            "source": "profiles/r03_bench_cfg2_kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py --in-flight 1, offline)"}
+
+
 def attach_traffic(kernels, traffic, source, fam_of):
     for k in kernels:
         key = next((v for pre, v in fam_of if k["kernel"].startswith(pre)), None)
@@ -612,6 +636,11 @@ def main():
                                    "ms_per_step": round(ms, 3),
                                    "launches_per_step": sum(k["launches_per_step"] for k in mf),
                                    "algorithmic_gflop_per_step": round(gf, 1)}
+                rp = rocprof_conv_family()
+                if rp:
+                    rp["achieved"] = round(gf / rp["ms_per_step"], 2)
+                    rp["frac"] = round(gf / rp["ms_per_step"] / PEAK_FP32_MFMA_TFLOPS, 4)
+                    rec["roofline"]["rocprof"] = rp
             rec["kernels"] = kernels
             rec["hip_kernels_ms_per_step"] = round(sum(k["ms_per_step"] for k in kernels), 3)
         if training:

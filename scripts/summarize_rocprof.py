@@ -10,7 +10,7 @@ os.makedirs(os.path.dirname(dst), exist_ok=True)
 shutil.copy(stats, dst + "_kernel_stats.csv")
 ours = ("conv_lds_kernel", "prob_head_tiled", "conv3d_kernel", "warp_kernel", "prob_head_kernel", "prob_from_partials", "regress_kernel", "confidence_kernel", "hypos_", "pack_weights",
         "corner_index", "conv2d_kernel", "refine_", "wgrad", "warp_train_kernel", "warp_bwd_kernel", "warp_vec_win", "warp_vec8", "bn_reduce", "bn_finalize", "bn_relu",
-        "slab_sum", "conv_pair_kernel", "conv1x1_kernel", "refine_tail_kernel", "prob_fused_kernel", "confidence_up2", "range_affine", "softmax_regress_bwd", "prob_conv_dgrad", "consistency_", "agg_", "pack_batch", "masked_smooth_l1", "adam_step")
+        "slab_sum", "conv_pair_kernel", "conv1x1_kernel", "refine_tail_kernel", "prob_fused_kernel", "confidence_up2", "range_affine", "softmax_regress_bwd", "prob_conv_dgrad", "consistency_", "agg_", "pack_batch", "masked_smooth_l1", "adam_step", "fpn_compose", "upsample2_bwd")
 unit = sys.argv[5] if len(sys.argv) > 5 else "forward"
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 tune = sum(float(r["TotalDurationNs"]) for r in rows if r["Name"].startswith("naive_conv"))
