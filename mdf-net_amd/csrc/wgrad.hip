@@ -247,6 +247,90 @@ __global__ __launch_bounds__(256) void wgrad_a1_kernel(const WgradParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// A = 1 with 8 or 16 `big` channels -- the `prob` conv as the model has it -- on the vector ALUs.  The sum is 0.4-0.9 GFLOP behind
+// 32-60 MB of operands: an HBM stream, not a GEMM.  The MFMA form above feeds every 16x16x4 step with two dword loads per lane (75 /
+// 63 / 36 us at cfg3: 0.4 TB/s).  Here a thread owns a voxel v of `big` and four of its channels: ONE 16-byte load of big[v], the 27
+// neighbours small[v - tap] (dword loads shared by the lanes of a voxel and contiguous along w: cache hits), 27 x 4 fused
+// multiply-adds into 108 accumulators, over a grid-stride loop; the lanes of a 16-lane row that own the same channel quad add up with
+// DPP row shifts (as ds_bpermute shuffles the reduction cost more than the loop: 39 -> 25 us), the 16 rows through LDS, and the block
+// writes one slab.  cfg3: 75 / 64 / 35 us -> 25 / 23 / 23 us.
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_shr(float v) {     // lane l reads lane l - n of its 16-lane row (0 where there is none)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+template <int BC>
+__global__ __launch_bounds__(256) void wgrad_a1_valu_kernel(const WgradParams p) {
+  zero_slice(p.zero_out, p.zero_n);
+  constexpr int NQ = BC / 4;               // channel quads per voxel = lanes per voxel
+  constexpr int VPB = 256 / NQ;            // voxels per block and iteration
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cq = tid % NQ;
+  const int nvox = p.B * p.Ds * p.Hs * p.Ws;            // (the entry point has checked that the operands fit 32-bit offsets)
+  float acc[27][4];
+#pragma unroll
+  for (int t = 0; t < 27; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[t][i] = 0.0f;
+  const int plane = p.Hs * p.Ws;
+  for (int v = blockIdx.x * VPB + tid / NQ; v < nvox; v += gridDim.x * VPB) {
+    const int w = v % p.Ws;
+    int r = v / p.Ws;
+    const int h = r % p.Hs; r /= p.Hs;
+    const int d = r % p.Ds;
+    const float4 bv = *reinterpret_cast<const float4*>(p.big + (size_t)v * BC + 4 * cq);
+    const float* sv0 = p.small_ + v;                     // small[v]; the taps are small[v - (kd-1)*plane - (kh-1)*Ws - (kw-1)]
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+      const int od = d - (kd - 1);         // dw[kd][kh][kw] += small[o] * big[o + (kd-1, kh-1, kw-1)]  with  o = v - tap
+      const bool dok = od >= 0 && od < p.Ds;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int oh = h - (kh - 1);
+        const bool hok = dok && oh >= 0 && oh < p.Hs;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int ow = w - (kw - 1);
+          const bool ok = hok && ow >= 0 && ow < p.Ws;
+          const int delta = (kd - 1) * plane + (kh - 1) * p.Ws + (kw - 1);
+          const float sv = sv0[ok ? -delta : 0];
+          const float a = ok ? sv : 0.0f;
+          const int t = kd * 9 + kh * 3 + kw;
+          acc[t][0] = fmaf(a, bv.x, acc[t][0]);
+          acc[t][1] = fmaf(a, bv.y, acc[t][1]);
+          acc[t][2] = fmaf(a, bv.z, acc[t][2]);
+          acc[t][3] = fmaf(a, bv.w, acc[t][3]);
+        }
+      }
+    }
+  }
+  // lanes of a 16-lane row that own the same channel quad: shifted adds on the vector ALU (DPP row_shr with zero fill -- an inclusive
+  // scan with steps NQ, 2NQ, .. whose last NQ lanes end up with the row's totals); the 16 rows of the block meet in LDS
+  __shared__ float red[16][NQ][108];
+  const int row = tid >> 4;
+#pragma unroll
+  for (int t = 0; t < 27; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float x = acc[t][i];
+      if constexpr (NQ == 2) x += dpp_row_shr<0x112>(x);
+      x += dpp_row_shr<0x114>(x);
+      x += dpp_row_shr<0x118>(x);
+      if ((tid & 15) >= 16 - NQ) red[row][(tid & 15) - (16 - NQ)][t * 4 + i] = x;
+    }
+  __syncthreads();
+  float* out = p.slab + (long long)blockIdx.x * BC * 27;                      // [A = 1][Bc][27]
+  for (int e = tid; e < BC * 27; e += 256) {
+    const int c = e / 27, t = e - c * 27;
+    const int k = t * 4 + (c & 3);
+    float s = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += red[r][c >> 2][k];
+    out[e] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // 2-D layers of the feature pyramid (net/unit/backbone.py:17-45: Conv2d k3 s1 / k5 s2, pad (k-1)/2), NHWC:
 //     dw[a][b][kh][kw] = sum over pixels o of  small[o][a] * big[s*o + (kh,kw) - pad][b]
 // Same split-K scheme; blockIdx.z = kernel row kh, a wave keeps the KS tap tiles of that row in registers.
@@ -480,6 +564,12 @@ extern "C" int64_t mdf_conv3d_wgrad_workspace(int B, int Ds, int Hs, int Ws, int
   const long long slab_cap = (16ll << 20) / ((long long)A * Bc * 27 * 4);
   if (g > slab_cap && slab_cap >= 16) g = slab_cap;
   if (g < 1) g = 1;
+  if (A == 1 && (Bc == 8 || Bc == 16)) {      // wgrad_a1_valu_kernel: one block per slab, a slab is 216 / 432 floats
+    const long long vpb = 256 / (Bc / 4);
+    long long gv = ((long long)B * Ds * Hs * Ws + vpb - 1) / vpb;
+    if (gv > 512) gv = 512;
+    if (gv > g) g = gv;
+  }
   return g * A * Bc * 27;   // floats
 }
 
@@ -507,7 +597,16 @@ static int conv3d_wgrad_impl(const float* small_, const float* big, float* dw, f
   p.zero_n = n;
   int gx_used = gx;
   int rc_lds = MDF_EUNSUPPORTED;
-  if (A == 1 && Bc <= 16 && stride == 1) {
+  static const bool a1_valu = [] { const char* e = getenv("MDF_WGRAD_A1_VALU"); return e ? atoi(e) != 0 : true; }();   // dev A/B
+  if (A == 1 && (Bc == 8 || Bc == 16) && stride == 1 && a1_valu) {
+    const long long vpb = 256 / (Bc / 4);
+    long long g = ((long long)B * Ds * Hs * Ws + vpb - 1) / vpb;     // at most one voxel group per block and iteration ...
+    if (g > 512) g = 512;                                            // ... and two blocks per CU (r03 sweep: 256 / 512 / 1024 / 2048 blocks -> 48 / 25 / 30 / 36 us @8x288x384: the per-block reduction)
+    if (g > gx) g = gx;                                              // (the workspace holds gx slabs)
+    gx_used = (int)g;
+    if (Bc == 8) hipLaunchKernelGGL(wgrad_a1_valu_kernel<8>, dim3(gx_used), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(wgrad_a1_valu_kernel<16>, dim3(gx_used), dim3(256), 0, (hipStream_t)stream, p);
+  } else if (A == 1 && Bc <= 16 && stride == 1) {
     hipLaunchKernelGGL(wgrad_a1_kernel, dim3(gx, 1, 3), dim3(256), 0, (hipStream_t)stream, p);
   } else {
     if (wgrad_use_lds()) {

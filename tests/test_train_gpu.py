@@ -822,3 +822,19 @@ def test_fpn_head_algebra_kernels_vs_float64():
     assert lib().mdf_fpn_compose_fwd(None, *[t.data_ptr() for t in dev[1:]], c2, c3, cm, comp.data_ptr(), st) != 0
     assert b"null pointer" in lib().mdf_last_error()
     assert lib().mdf_fpn_compose_fwd(*[t.data_ptr() for t in dev], 0, c3, cm, comp.data_ptr(), st) != 0
+
+
+@pytest.mark.parametrize("c,shape", [(8, (2, 5, 13, 37)), (16, (1, 9, 31, 70)), (8, (1, 1, 3, 5)), (16, (3, 2, 2, 2))])
+def test_prob_conv_weight_gradient_on_the_vector_alus(c, shape):
+    """dW of the `prob` conv (one output channel: wgrad.hip:wgrad_a1_valu_kernel, a thread per voxel and channel quad) against float64
+    autograd of F.conv3d: odd sizes, volumes smaller than a block's stride, every border tap."""
+    b, d, h, w = shape
+    torch.manual_seed(c + d + w)
+    x = torch.randn(b, c, d, h, w, dtype=torch.float64)
+    wt = torch.randn(1, c, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    dy = torch.randn(b, 1, d, h, w, dtype=torch.float64)
+    F.conv3d(x, wt, padding=1).backward(dy)
+    small = dy.float().permute(0, 2, 3, 4, 1).contiguous().to(DEV)           # [B,D,H,W,1]
+    big = x.float().permute(0, 2, 3, 4, 1).contiguous().to(DEV)              # [B,D,H,W,C]
+    dw = train_ops.conv3d_wgrad(small, big, 1, (1, c, 3, 3, 3))
+    assert _rel(dw, wt.grad) < 2e-5
