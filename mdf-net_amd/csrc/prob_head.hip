@@ -219,7 +219,8 @@ extern "C" int mdf_prob_from_partials_fwd(const float* partials, const float* hy
   MDF_REQUIRE(B > 0 && D > 0 && h > 0 && wd > 0, "bad shape");
   MDF_REQUIRE((reinterpret_cast<uintptr_t>(partials) & 15) == 0, "partials must be 16-byte aligned");
   const size_t n = (size_t)B * h * wd;
-  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  const unsigned bt = n < (size_t)256 * 1024 ? 64u : 256u;     // few pixels: one-wave blocks reach every CU (regress.hip:block_for)
+  dim3 grid((unsigned)((n + bt - 1) / bt)), block(bt);
   const float4* pp = reinterpret_cast<const float4*>(partials);
   if (D <= 8) hipLaunchKernelGGL((prob_from_partials_kernel<8>), grid, block, 0, (hipStream_t)stream, pp, hypos, hypos_per_pixel, prob, depth, B, D, h, wd);
   else if (D <= 24) hipLaunchKernelGGL((prob_from_partials_kernel<24>), grid, block, 0, (hipStream_t)stream, pp, hypos, hypos_per_pixel, prob, depth, B, D, h, wd);

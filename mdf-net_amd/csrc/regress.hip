@@ -173,8 +173,13 @@ __global__ void hypos_from_fit_kernel(int mode, const float* __restrict__ s, con
   }
 }
 
+// One thread per pixel: at 1/8 resolution (148 x 200) that is 29,600 threads -- 116 blocks of 256 on 256 CUs, i.e. 140 CUs idle and
+// four waves on each of the others.  Small problems therefore go out as one-wave blocks, which the dispatcher spreads over all CUs
+// (the kernels index with blockDim.x; nothing in them is block-cooperative).
+inline int block_for(size_t n) { return n < (size_t)256 * 1024 ? 64 : kThreads; }
 inline int grid_for(size_t n) {
-  size_t g = (n + kThreads - 1) / kThreads;
+  const size_t t = (size_t)block_for(n);
+  size_t g = (n + t - 1) / t;
   return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
 }
 
@@ -184,7 +189,7 @@ extern "C" int mdf_depth_regress_fwd(const float* prob, const float* hypos, int 
                                      int D, int h, int w, void* stream) {
   MDF_REQUIRE(prob && hypos && depth, "null pointer argument");
   MDF_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, "bad shape");
-  hipLaunchKernelGGL(depth_regress_kernel, dim3(grid_for((size_t)B * h * w)), dim3(kThreads), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(depth_regress_kernel, dim3(grid_for((size_t)B * h * w)), dim3(block_for((size_t)B * h * w)), 0, (hipStream_t)stream,
                      prob, hypos, hypos_per_pixel, depth, B, D, h * w);
   return mdf::check_launch("depth_regress_kernel");
 }
@@ -193,7 +198,7 @@ extern "C" int mdf_confidence_fwd(const float* prob, float* conf, int64_t* idx_o
                                   void* stream) {
   MDF_REQUIRE(prob && conf, "null pointer argument");
   MDF_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, "bad shape");
-  hipLaunchKernelGGL(confidence_kernel, dim3(grid_for((size_t)B * h * w)), dim3(kThreads), 0, (hipStream_t)stream, prob,
+  hipLaunchKernelGGL(confidence_kernel, dim3(grid_for((size_t)B * h * w)), dim3(block_for((size_t)B * h * w)), 0, (hipStream_t)stream, prob,
                      conf, idx_out, B, D, h * w);
   return mdf::check_launch("confidence_kernel");
 }
@@ -201,14 +206,14 @@ extern "C" int mdf_confidence_fwd(const float* prob, float* conf, int64_t* idx_o
 extern "C" int mdf_confidence_up2_fwd(const float* prob, float* conf2, int B, int D, int h, int w, void* stream) {
   MDF_REQUIRE(prob && conf2, "null pointer argument");
   MDF_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, "bad shape");
-  hipLaunchKernelGGL(confidence_up2_kernel, dim3(grid_for((size_t)B * h * w)), dim3(kThreads), 0, (hipStream_t)stream, prob, conf2, B, D, h, w);
+  hipLaunchKernelGGL(confidence_up2_kernel, dim3(grid_for((size_t)B * h * w)), dim3(block_for((size_t)B * h * w)), 0, (hipStream_t)stream, prob, conf2, B, D, h, w);
   return mdf::check_launch("confidence_up2_kernel");
 }
 
 extern "C" int mdf_range_affine_fwd(const float* x, const float* lo, const float* span, int mode, float* y, int B, long long n, void* stream) {
   MDF_REQUIRE(x && lo && span && y, "null pointer argument");
   MDF_REQUIRE(B > 0 && n > 0 && (mode == 0 || mode == 1), "bad shape / mode");
-  hipLaunchKernelGGL(range_affine_kernel, dim3(grid_for((size_t)B * n)), dim3(kThreads), 0, (hipStream_t)stream, x, lo, span, mode, y, B, (size_t)n);
+  hipLaunchKernelGGL(range_affine_kernel, dim3(grid_for((size_t)B * n)), dim3(block_for((size_t)B * n)), 0, (hipStream_t)stream, x, lo, span, mode, y, B, (size_t)n);
   return mdf::check_launch("range_affine_kernel");
 }
 
@@ -227,7 +232,7 @@ extern "C" int mdf_hypos_fit_fwd(int mode, const float* prob, const float* depth
   } else {
     return mdf::fail(MDF_EARG, "mode must be 1 (gauss1) or 2 (laplace), got %d", mode);
   }
-  hipLaunchKernelGGL(hypos_fit_kernel, dim3(grid_for((size_t)B * h * w)), dim3(kThreads), 0, (hipStream_t)stream, mode,
+  hipLaunchKernelGGL(hypos_fit_kernel, dim3(grid_for((size_t)B * h * w)), dim3(block_for((size_t)B * h * w)), 0, (hipStream_t)stream, mode,
                      prob, depth, hypos, hypos_per_pixel, fit_row, s_out, B, D, h * w);
   return mdf::check_launch("hypos_fit_kernel");
 }
@@ -238,7 +243,7 @@ extern "C" int mdf_hypos_from_fit_fwd(int mode, const float* s, const float* dep
   MDF_REQUIRE(B > 0 && D_out > 1 && h > 0 && w > 0, "bad shape");
   MDF_REQUIRE(mode == 1 || mode == 2, "mode must be 1 (gauss1) or 2 (laplace), got %d", mode);
   const size_t n = (size_t)B * h * w * (upsample ? 4 : 1);
-  hipLaunchKernelGGL(hypos_from_fit_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, mode, s, depth,
+  hipLaunchKernelGGL(hypos_from_fit_kernel, dim3(grid_for(n)), dim3(block_for(n)), 0, (hipStream_t)stream, mode, s, depth,
                      range, log_thresh, hypos_out, B, D_out, h, w, upsample);
   return mdf::check_launch("hypos_from_fit_kernel");
 }
