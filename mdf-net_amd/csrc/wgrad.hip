@@ -544,6 +544,10 @@ static int wgrad_target_blocks() {
   static const int n = [] { const char* e = getenv("MDF_WGRAD_BLOCKS"); return (e && atoi(e) > 0) ? atoi(e) : 1024; }();
   return n;
 }
+static long long wgrad_slab_cap_bytes() {     // partial-tile bytes per launch (written by the blocks, read again by the sum)
+  static const long long n = [] { const char* e = getenv("MDF_WGRAD_SLAB_MIB"); return (long long)((e && atoi(e) > 0) ? atoi(e) : 16) << 20; }();   // dev A/B
+  return n;
+}
 static bool wgrad_use_lds() {
   static const bool on = [] { const char* e = getenv("MDF_WGRAD_LDS"); return e ? atoi(e) != 0 : true; }();   // dev A/B
   return on;
@@ -561,7 +565,7 @@ extern "C" int64_t mdf_conv3d_wgrad_workspace(int B, int Ds, int Hs, int Ws, int
   // every block writes a partial tile set (A*Bc*27 floats: 442 KB for 64 x 64 channels) that is read again by the sum: <= 16 MiB of
   // them per launch (r03 sweep, scripts/diag_wgrad_sweep.sh: 64 x 64 @12x18x24 45 -> 37 us, 32 x 32 @24x36x48 50 -> 44 us with
   // half the blocks; the 16 x 16 layers are not touched by the cap)
-  const long long slab_cap = (16ll << 20) / ((long long)A * Bc * 27 * 4);
+  const long long slab_cap = wgrad_slab_cap_bytes() / ((long long)A * Bc * 27 * 4);
   if (g > slab_cap && slab_cap >= 16) g = slab_cap;
   if (g < 1) g = 1;
   if (A == 1 && (Bc == 8 || Bc == 16)) {      // wgrad_a1_valu_kernel: one block per slab, a slab is 216 / 432 floats
@@ -648,7 +652,7 @@ static long long wgrad2d_grid(int B, int Hs, int Ws, int A, int Bc, int ksize, i
   const int gy = (pairs * split + 3) / 4;
   long long g = wgrad_target_blocks() / (ksize * gy);
   if (g > items / split) g = items / split;
-  const long long slab_cap = (16ll << 20) / ((long long)A * Bc * ksize * ksize * 4);
+  const long long slab_cap = wgrad_slab_cap_bytes() / ((long long)A * Bc * ksize * ksize * 4);
   if (g > slab_cap && slab_cap >= 16) g = slab_cap;
   if (g < 1) g = 1;
   if (split_out) *split_out = split;
