@@ -79,9 +79,14 @@ __global__ void range_affine_kernel(const float* __restrict__ x, const float* __
 
 // mode 1: s = |-1 / sum_d row[b,d] * ln(max(p,1e-40))|          depthhypos.py:194-212
 // mode 2: s = 1 / |sum(x*y)/sum(x*x)|, x = |hyp - depth|          depthhypos.py:116-123
+// DT = D at compile time (48 / 24 / 8: the model's stages) or 0: with a runtime trip count the compiler issues the plane loads a few at
+// a time and a thread waits out D / 4 memory round trips in a launch that has one wave per SIMD; unrolled, they leave together.  The
+// arithmetic and its order are the same.
+template <int DT>
 __global__ void hypos_fit_kernel(int mode, const float* __restrict__ prob, const float* __restrict__ depth,
                                  const float* __restrict__ hypos, int per_pixel, const float* __restrict__ row,
-                                 float* __restrict__ s_out, int B, int D, int hw) {
+                                 float* __restrict__ s_out, int B, int D_rt, int hw) {
+  const int D = DT ? DT : D_rt;
   const size_t n = (size_t)B * hw;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const size_t b = i / hw, pix = i % hw;
@@ -91,16 +96,37 @@ __global__ void hypos_fit_kernel(int mode, const float* __restrict__ prob, const
       // < 400): sequential k loop, separate multiply and add in fp32.  The sum cancels heavily, so mirroring
       // the order (verified bit-exact on the goldens given torch's log) matters more than accuracy here.
       float acc = 0.0f;
-      for (int d = 0; d < D; ++d) acc = acc + row[b * D + d] * logf(fmaxf(p[(size_t)d * hw], 1e-40f));
+      if constexpr (DT != 0) {
+        float pv[DT];
+#pragma unroll
+        for (int d = 0; d < DT; ++d) pv[d] = p[(size_t)d * hw];
+#pragma unroll
+        for (int d = 0; d < DT; ++d) acc = acc + row[b * D + d] * logf(fmaxf(pv[d], 1e-40f));
+      } else {
+        for (int d = 0; d < D; ++d) acc = acc + row[b * D + d] * logf(fmaxf(p[(size_t)d * hw], 1e-40f));
+      }
       s_out[i] = fabsf(-1.0f / acc);
     } else {
       const float dep = depth[i];
       mdf::CascadeSum sxy, sxx;  // torch.sum(x*y, -1), torch.sum(x*x, -1)
-      for (int d = 0; d < D; ++d) {
-        const float x = fabsf(hyp_at(hypos, per_pixel, b, D, d, hw, pix) - dep);
-        const float y = logf(fmaxf(p[(size_t)d * hw], 1e-40f));
-        sxy.add(x * y);
-        sxx.add(x * x);
+      if constexpr (DT != 0) {
+        float pv[DT], hv[DT];
+#pragma unroll
+        for (int d = 0; d < DT; ++d) { pv[d] = p[(size_t)d * hw]; hv[d] = hyp_at(hypos, per_pixel, b, D, d, hw, pix); }
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          const float x = fabsf(hv[d] - dep);
+          const float y = logf(fmaxf(pv[d], 1e-40f));
+          sxy.add(x * y);
+          sxx.add(x * x);
+        }
+      } else {
+        for (int d = 0; d < D; ++d) {
+          const float x = fabsf(hyp_at(hypos, per_pixel, b, D, d, hw, pix) - dep);
+          const float y = logf(fmaxf(p[(size_t)d * hw], 1e-40f));
+          sxy.add(x * y);
+          sxx.add(x * x);
+        }
       }
       s_out[i] = 1.0f / fabsf(sxy.result() / sxx.result());
     }
@@ -232,8 +258,10 @@ extern "C" int mdf_hypos_fit_fwd(int mode, const float* prob, const float* depth
   } else {
     return mdf::fail(MDF_EARG, "mode must be 1 (gauss1) or 2 (laplace), got %d", mode);
   }
-  hipLaunchKernelGGL(hypos_fit_kernel, dim3(grid_for((size_t)B * h * w)), dim3(block_for((size_t)B * h * w)), 0, (hipStream_t)stream, mode,
-                     prob, depth, hypos, hypos_per_pixel, fit_row, s_out, B, D, h * w);
+#define MDF_HF(DT) hipLaunchKernelGGL(hypos_fit_kernel<DT>, dim3(grid_for((size_t)B * h * w)), dim3(block_for((size_t)B * h * w)), 0, (hipStream_t)stream, mode, \
+                                      prob, depth, hypos, hypos_per_pixel, fit_row, s_out, B, D, h * w)
+  if (D == 48) MDF_HF(48); else if (D == 24) MDF_HF(24); else if (D == 8) MDF_HF(8); else MDF_HF(0);
+#undef MDF_HF
   return mdf::check_launch("hypos_fit_kernel");
 }
 
