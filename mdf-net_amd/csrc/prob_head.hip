@@ -171,10 +171,13 @@ __global__ __launch_bounds__(256) void prob_head_tiled_kernel(const float* __res
 // (conv_lds_kernel<Cin,Cin,4,1,3,1,4>, 4th channel zero), so every input voxel is read once and the 27*Cin-deep
 // contraction runs on the matrix cores; this kernel is the light rest: combine, softmax over D, soft-argmin.
 // One thread per pixel; the D logits stay in registers (DMAX = 8/24/48), each partial is read once, prob written once.
-template <int DMAX>
+// FULL: D == DMAX is known to the compiler -- no `d < D` guard between the plane loads, so they are issued together (regress.hip:
+// hypos_fit_kernel has the measurement).
+template <int DMAX, bool FULL = false>
 __global__ __launch_bounds__(256) void prob_from_partials_kernel(const float4* __restrict__ part, const float* __restrict__ hypos,
                                                                  int per_pixel, float* __restrict__ prob, float* __restrict__ depth,
-                                                                 int B, int D, int h, int w) {
+                                                                 int B, int D_rt, int h, int w) {
+  const int D = FULL ? DMAX : D_rt;
   const size_t hw = (size_t)h * w, n = (size_t)B * hw;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -222,7 +225,10 @@ extern "C" int mdf_prob_from_partials_fwd(const float* partials, const float* hy
   const unsigned bt = n < (size_t)256 * 1024 ? 64u : 256u;     // few pixels: one-wave blocks reach every CU (regress.hip:block_for)
   dim3 grid((unsigned)((n + bt - 1) / bt)), block(bt);
   const float4* pp = reinterpret_cast<const float4*>(partials);
-  if (D <= 8) hipLaunchKernelGGL((prob_from_partials_kernel<8>), grid, block, 0, (hipStream_t)stream, pp, hypos, hypos_per_pixel, prob, depth, B, D, h, wd);
+  if (D == 48) hipLaunchKernelGGL((prob_from_partials_kernel<48, true>), grid, block, 0, (hipStream_t)stream, pp, hypos, hypos_per_pixel, prob, depth, B, D, h, wd);
+  else if (D == 24) hipLaunchKernelGGL((prob_from_partials_kernel<24, true>), grid, block, 0, (hipStream_t)stream, pp, hypos, hypos_per_pixel, prob, depth, B, D, h, wd);
+  else if (D == 8) hipLaunchKernelGGL((prob_from_partials_kernel<8, true>), grid, block, 0, (hipStream_t)stream, pp, hypos, hypos_per_pixel, prob, depth, B, D, h, wd);
+  else if (D <= 8) hipLaunchKernelGGL((prob_from_partials_kernel<8>), grid, block, 0, (hipStream_t)stream, pp, hypos, hypos_per_pixel, prob, depth, B, D, h, wd);
   else if (D <= 24) hipLaunchKernelGGL((prob_from_partials_kernel<24>), grid, block, 0, (hipStream_t)stream, pp, hypos, hypos_per_pixel, prob, depth, B, D, h, wd);
   else if (D <= 48) hipLaunchKernelGGL((prob_from_partials_kernel<48>), grid, block, 0, (hipStream_t)stream, pp, hypos, hypos_per_pixel, prob, depth, B, D, h, wd);
   else if (D <= 96) hipLaunchKernelGGL((prob_from_partials_kernel<96>), grid, block, 0, (hipStream_t)stream, pp, hypos, hypos_per_pixel, prob, depth, B, D, h, wd);
