@@ -129,7 +129,7 @@ def bn_relu_backward(dz, y, aux, gamma, n, c, groups=1, pool=None, red=None):
 # (it would ADD an unfinished gradient into an existing .grad).  The pending list holds the gradient's ADDRESS, not the tensor: a
 # second reference would make AccumulateGrad clone it instead of taking it (59 copies per step, and of unfinished data).
 DEFER_WGRAD_SUMS = bool(int(_os.environ.get("MDF_WGRAD_DEFER", "1")))      # dev A/B
-_PENDING_SUMS = {}          # device index -> [stream, [(work, dw, nslab, n), ...]]
+_PENDING_SUMS = {}          # device index -> [streams the partial tiles were launched on, [(work, dw, nslab, n), ...]]
 
 
 def sum_wgrad_jobs(jobs):
@@ -149,9 +149,12 @@ def _flush_wgrad_sums(dev_index):
     ent = _PENDING_SUMS.pop(dev_index, None)
     if not ent or not ent[1]:
         return
-    st, jobs = ent
-    with torch.cuda.stream(st):
-        sum_wgrad_jobs(jobs)
+    streams, jobs = ent
+    cur = torch.cuda.current_stream(torch.device("cuda", dev_index))
+    for st in streams:          # partial tiles may have been launched on other streams (a stream per stage, layers.STAGE_STREAMS): join them
+        if st != cur:
+            cur.wait_stream(st)
+    sum_wgrad_jobs(jobs)
 
 
 def _sum_later(work, dw, nslab, n, param):
@@ -160,9 +163,12 @@ def _sum_later(work, dw, nslab, n, param):
              and getattr(torch._C, "_current_graph_task_id", lambda: -1)() != -1)
     ent = _PENDING_SUMS.get(dev)
     if ent is None:
-        ent = _PENDING_SUMS[dev] = [torch.cuda.current_stream(dw.device), []]
+        ent = _PENDING_SUMS[dev] = [[], []]
         if defer:
             torch.autograd.Variable._execution_engine.queue_callback(lambda d=dev: _flush_wgrad_sums(d))
+    cur = torch.cuda.current_stream(dw.device)
+    if cur not in ent[0]:
+        ent[0].append(cur)
     ent[1].append((work, dw.data_ptr(), nslab, n))
     if not defer:
         _flush_wgrad_sums(dev)
