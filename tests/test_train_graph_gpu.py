@@ -96,16 +96,26 @@ def test_replayed_step_follows_its_inputs():
         assert torch.isfinite(gg).all() and _l2(gg, ge) < 1e-3
     for p, q in zip(mg.parameters(), before):
         assert torch.equal(p, q)
+    # a recording is bound to its shapes and to its control-plane layout: other shapes are refused, not replayed on stale addresses
+    sc = _scene(1)
+    with pytest.raises(RuntimeError, match="shapes differ"):
+        step(sc[0][:, :, :, : H // 2], sc[1], sc[2], sc[3], sc[4])
+    with pytest.raises(RuntimeError, match="layout changed"):
+        step.staging.upload([("cam0", torch.zeros(5))])
     # per-step losses differ from scene to scene by far more than the bar above, i.e. the comparison can tell a frozen input
     assert abs(_eager_step(me, crit, be, oe, _scene(1)) - _eager_step(me, crit, be, oe, _scene(2))) > 1e-2
 
 
 def test_replayed_training_tracks_eager_training():
-    """lr 1e-3: five steps each way from the same weights (two of them are the recording's warm-up steps on the example)."""
+    """Five steps each way from the same weights (two of them are the recording's warm-up steps on the example).  Adam turns the
+    summation-order noise of a near-zero gradient into a full +-lr step, so two runs of the SAME eager loop already drift apart by up to
+    2 lr per step and weight, and the loss follows (lr 1e-3: 1e-5 / 5e-4 / 5e-3 relative after 3 / 4 / 5 steps, measured); the test runs
+    at lr 1e-4, where the drift is ten times smaller, with bars that leave it a factor of ten."""
     crit = Loss().to(DEV)
     me, mg = _model(), _model()
     be, bg = ddp.FlatBucket(me), ddp.FlatBucket(mg)
-    oe, og = FlatAdam(be, lr=1e-3), FlatAdam(bg, lr=1e-3)
+    lr = 1e-4
+    oe, og = FlatAdam(be, lr=lr), FlatAdam(bg, lr=lr)
     s0 = _scene(0)
     losses_e = [_eager_step(me, crit, be, oe, s0) for _ in range(2)]
     step = GraphedTrainStep(mg, crit, bg, og, tuple(t.to(DEV) for t in s0[:4]) + ({k: v.to(DEV) for k, v in s0[4].items()},), warmup=2)
@@ -121,7 +131,7 @@ def test_replayed_training_tracks_eager_training():
     for a, b in zip(losses_e[2:], losses_g):
         assert abs(a - b) <= 5e-3 * abs(a)
     for (name, p), q in zip(mg.named_parameters(), me.parameters()):
-        assert float((p - q).abs().max()) <= 4e-3 + 1e-2 * float(q.abs().max()), name          # Adam moves a weight by <= lr per step
+        assert float((p - q).abs().max()) <= 2 * lr * 5 * 1.01, name          # Adam moves a weight by <= lr per step, either way
     for (name, b1), b2 in zip(mg.named_buffers(), me.buffers()):
         if name.endswith("num_batches_tracked"):
             assert int(b1) == int(b2), name
