@@ -44,9 +44,9 @@ __global__ __launch_bounds__(256) void fpn_compose_fwd_kernel(ComposeFwd p) {
     else if ((r -= nA3) < c2) { row = O2 + r * cm; col = b2; ld = 1; }
     else if ((r -= c2) < c2) { row = O2 + r * cm; col = b3; ld = 1; }
     else { r -= c2; row = O3 + r * cm; col = b3; ld = 1; }
-    float acc = 0.0f;
-    for (int k = 0; k < cm; ++k) acc = fmaf(row[k], col[k * ld], acc);
-    p.comp[e] = acc;
+    double acc = 0.0;     // the composed matrices stand in for two fp32 convs in a row: form them exactly, round once
+    for (int k = 0; k < cm; ++k) acc = fma((double)row[k], (double)col[k * ld], acc);
+    p.comp[e] = (float)acc;
   }
 }
 
