@@ -35,7 +35,10 @@ struct ProbCfg : Cfg<CIN, CIN, 4, 1, 3, 1, 1, 4> {
   static constexpr int NFILL = (Base::NG * PH * Base::PW + NTHR - 1) / NTHR;
 };
 
-template <int CIN, int NW>
+// DT = D at compile time (24 / 8: the stages this kernel serves) or 0.  With DT the pixel's hypotheses are requested BEFORE the walk over
+// the planes and wait in registers; read inside the last loop (runtime trip count, a division and a cascade sum per plane between two
+// loads) they were D memory round trips at the end of every tile.
+template <int CIN, int NW, int DT>
 __global__ __launch_bounds__(64 * NW) void prob_fused_kernel(const ProbParams p) {
   typedef ProbCfg<CIN, NW> C;
   constexpr int KPL = C::KPL, NG = C::NG, S = C::S, PW = C::PW, PH = C::PH, NTHR = C::NTHR;
@@ -102,6 +105,13 @@ __global__ __launch_bounds__(64 * NW) void prob_fused_kernel(const ProbParams p)
   const size_t pix = live ? (size_t)oh * p.W + ow : 0;
   float* pr = p.prob + (size_t)b * p.D * hw + pix;
   float* lg = lds + 2 * C::PLANE + tid;   // [D][NTHR]: this thread's logits
+  float hy[DT ? DT : 1];
+  if constexpr (DT != 0) {
+    if (p.depth && live) {
+#pragma unroll
+      for (int d = 0; d < DT; ++d) hy[d] = p.per_pixel ? p.hypos[((size_t)b * DT + d) * hw + pix] : p.hypos[(size_t)b * DT + d];
+    }
+  }
   float carry1 = 0.f, carry0 = 0.f;   // P0[d-1] + P1[d] (awaiting P2[d+1]);  P0[d] (feeds logit[d+1])
   float mx = -INFINITY;
   for (int d = 0; d < p.D; ++d) {
@@ -137,16 +147,25 @@ __global__ __launch_bounds__(64 * NW) void prob_fused_kernel(const ProbParams p)
     sum += e;
   }
   mdf::CascadeSum dep;   // regress.py:5-7 with ATen's summation order
-  for (int d = 0; d < p.D; ++d) {
-    const float pv = lg[d * NTHR] / sum;
-    pr[(size_t)d * hw] = pv;
-    if (p.depth) dep.add(pv * (p.per_pixel ? p.hypos[((size_t)b * p.D + d) * hw + pix] : p.hypos[(size_t)b * p.D + d]));
+  if constexpr (DT != 0) {
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const float pv = lg[d * NTHR] / sum;
+      pr[(size_t)d * hw] = pv;
+      if (p.depth) dep.add(pv * hy[d]);
+    }
+  } else {
+    for (int d = 0; d < p.D; ++d) {
+      const float pv = lg[d * NTHR] / sum;
+      pr[(size_t)d * hw] = pv;
+      if (p.depth) dep.add(pv * (p.per_pixel ? p.hypos[((size_t)b * p.D + d) * hw + pix] : p.hypos[(size_t)b * p.D + d]));
+    }
   }
   if (p.depth) p.depth[(size_t)b * hw + pix] = dep.result();
 }
 
-template <int CIN, int NW>
-int launch_prob_fused(ProbParams& p, hipStream_t st) {
+template <int CIN, int NW, int DT>
+int launch_prob_fused_d(ProbParams& p, hipStream_t st) {
   typedef ProbCfg<CIN, NW> C;
   const size_t kLds = ((size_t)2 * C::PLANE + (size_t)p.D * C::NTHR) * sizeof(float);
   if (kLds > 160 * 1024) return mdf::fail(MDF_EUNSUPPORTED, "fused prob head: D=%d does not fit the LDS (use the two-launch route)", p.D);
@@ -154,17 +173,24 @@ int launch_prob_fused(ProbParams& p, hipStream_t st) {
   p.tiles_w = (p.W + C::TWO - 1) / C::TWO;
   const long long tiles = (long long)p.B * p.tiles_h * p.tiles_w;
   if (tiles > 0x7fffffff) return mdf::fail(MDF_EARG, "prob head: too many tiles");
-  static bool attr_done_dev[64] = {};   // (the attribute is set to the device maximum once: the size depends on D)
+  static bool attr_done_dev[64] = {};   // (per instantiation; the attribute is set to the device maximum once: the size depends on D)
   int dev_id = 0;
   (void)hipGetDevice(&dev_id);
   bool& attr_done = attr_done_dev[(dev_id >= 0 && dev_id < 64) ? dev_id : 0];
   if (!attr_done || dev_id >= 64) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prob_fused_kernel<CIN, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prob_fused_kernel<CIN, NW, DT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return mdf::fail(MDF_EHIP, "hipFuncSetAttribute(dynamic LDS): %s", hipGetErrorString(e));
     attr_done = true;
   }
-  hipLaunchKernelGGL((prob_fused_kernel<CIN, NW>), dim3((unsigned)tiles), dim3(C::NTHR), kLds, st, p);
+  hipLaunchKernelGGL((prob_fused_kernel<CIN, NW, DT>), dim3((unsigned)tiles), dim3(C::NTHR), kLds, st, p);
   return mdf::check_launch("prob_fused_kernel");
+}
+
+template <int CIN, int NW>
+int launch_prob_fused(ProbParams& p, hipStream_t st) {
+  if (p.D == 24) return launch_prob_fused_d<CIN, NW, 24>(p, st);
+  if (p.D == 8) return launch_prob_fused_d<CIN, NW, 8>(p, st);
+  return launch_prob_fused_d<CIN, NW, 0>(p, st);
 }
 
 }  // namespace
