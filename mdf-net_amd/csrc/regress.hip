@@ -46,18 +46,37 @@ __global__ void confidence_kernel(const float* __restrict__ prob, float* __restr
 
 // the same with the nearest-neighbour x2 upsampling of core.py:76 (F.interpolate(conf, scale_factor=2, mode="nearest")) folded in:
 // every value goes to its 2x2 output pixels
-__global__ void confidence_up2_kernel(const float* __restrict__ prob, float* __restrict__ conf2, int B, int D, int h, int w) {
+template <int DT>   // D at compile time (8: the model's last stage) or 0: the plane loads leave together and the window sum reads registers
+__global__ void confidence_up2_kernel(const float* __restrict__ prob, float* __restrict__ conf2, int B, int D_rt, int h, int w) {
+  const int D = DT ? DT : D_rt;
   const int hw = h * w;
   const size_t n = (size_t)B * hw;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const size_t b = i / hw, pix = i % hw;
     const float* p = prob + b * D * hw + pix;
     mdf::CascadeSum ex;
-    for (int d = 0; d < D; ++d) ex.add(p[(size_t)d * hw] * (float)d);
-    long long idx = (long long)ex.result();
-    idx = idx < 0 ? 0 : (idx > D - 1 ? D - 1 : idx);
     float s = 0.0f;
-    for (int k = (int)idx - 1; k <= (int)idx + 2; ++k) s += (k >= 0 && k < D) ? p[(size_t)k * hw] : 0.0f;
+    if constexpr (DT != 0) {
+      float pv[DT];
+#pragma unroll
+      for (int d = 0; d < DT; ++d) pv[d] = p[(size_t)d * hw];
+#pragma unroll
+      for (int d = 0; d < DT; ++d) ex.add(pv[d] * (float)d);
+      long long idx = (long long)ex.result();
+      idx = idx < 0 ? 0 : (idx > D - 1 ? D - 1 : idx);
+      // the same four terms in the same order (k = idx-1 .. idx+2), selected from the registers
+      for (int k = (int)idx - 1; k <= (int)idx + 2; ++k) {
+        float v = 0.0f;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) v = (d == k) ? pv[d] : v;
+        s += v;
+      }
+    } else {
+      for (int d = 0; d < D; ++d) ex.add(p[(size_t)d * hw] * (float)d);
+      long long idx = (long long)ex.result();
+      idx = idx < 0 ? 0 : (idx > D - 1 ? D - 1 : idx);
+      for (int k = (int)idx - 1; k <= (int)idx + 2; ++k) s += (k >= 0 && k < D) ? p[(size_t)k * hw] : 0.0f;
+    }
     const int y = (int)(pix / w), x = (int)(pix % w);
     float* o = conf2 + (b * 2 * h + 2 * y) * (size_t)(2 * w) + 2 * x;
     *reinterpret_cast<float2*>(o) = make_float2(s, s);
@@ -232,7 +251,8 @@ extern "C" int mdf_confidence_fwd(const float* prob, float* conf, int64_t* idx_o
 extern "C" int mdf_confidence_up2_fwd(const float* prob, float* conf2, int B, int D, int h, int w, void* stream) {
   MDF_REQUIRE(prob && conf2, "null pointer argument");
   MDF_REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, "bad shape");
-  hipLaunchKernelGGL(confidence_up2_kernel, dim3(grid_for((size_t)B * h * w)), dim3(block_for((size_t)B * h * w)), 0, (hipStream_t)stream, prob, conf2, B, D, h, w);
+  if (D == 8) hipLaunchKernelGGL(confidence_up2_kernel<8>, dim3(grid_for((size_t)B * h * w)), dim3(block_for((size_t)B * h * w)), 0, (hipStream_t)stream, prob, conf2, B, D, h, w);
+  else hipLaunchKernelGGL(confidence_up2_kernel<0>, dim3(grid_for((size_t)B * h * w)), dim3(block_for((size_t)B * h * w)), 0, (hipStream_t)stream, prob, conf2, B, D, h, w);
   return mdf::check_launch("confidence_up2_kernel");
 }
 
