@@ -351,6 +351,15 @@ int mdf_masked_smooth_l1_finalize(const double* acc, int nscales, float* loss, f
 int mdf_masked_smooth_l1_bwd(const float* est, const float* gt, const void* floor_, int floor_f64, int floor_stride, int B,
                              long long per_batch, const float* dloss, const float* inv_count, float* dest, void* stream);
 
+/*      The same over all output scales in ONE launch each (Loss.forward sums four scales, net/loss.py:19-25): est / gt / dest are HOST
+ *      arrays of nscales (<= 8) device pointers, per_batch a host array of element counts; acc is [2*nscales] as above; a NULL dest[i]
+ *      skips scale i; inv_count is the [nscales] array mdf_masked_smooth_l1_finalize wrote.                                              */
+int mdf_masked_smooth_l1_reduce_multi(const float* const* est, const float* const* gt, const long long* per_batch, int nscales,
+                                      const void* floor_, int floor_f64, int floor_stride, int B, double* acc, void* stream);
+int mdf_masked_smooth_l1_bwd_multi(const float* const* est, const float* const* gt, const long long* per_batch, int nscales,
+                                   const void* floor_, int floor_f64, int floor_stride, int B, const float* dloss,
+                                   const float* inv_count, float* const* dest, void* stream);
+
 /* ---- feature-pyramid heads in training mode, the small algebra (net/unit/backbone.py:59-63: lat2, lat3, out2, out3, out4 -- 1x1 convs
  *      around two bilinear up-samplings, evaluated through the products O2 L2, O2 L3, O3 L3; train_ops.py:FPNHeadsComposedFn).
  *      Matrices are the Conv2d weights, row-major [out][in]: O2 [c2][cm], O3 [c3][cm], L2 [cm][c2], L3 [cm][c3], biases b2, b3 [cm].

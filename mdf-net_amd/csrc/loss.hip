@@ -77,6 +77,60 @@ __global__ __launch_bounds__(kT) void masked_smooth_l1_bwd_kernel(const float* _
   }
 }
 
+// ---- all scales in one launch: the scales travel by value (<= 8), blockIdx.z is the scale ------------------------------------
+constexpr int kMaxScales = 8;
+struct L1Scales {
+  const float* e[kMaxScales];
+  const float* gt[kMaxScales];
+  float* de[kMaxScales];          // backward only (NULL: this scale needs no gradient)
+  long long per_batch[kMaxScales];
+  int n;
+};
+
+__global__ __launch_bounds__(kT) void masked_smooth_l1_reduce_multi_kernel(L1Scales sc, const void* __restrict__ floor_, int floor_f64, int floor_stride,
+                                                                           double* __restrict__ acc) {
+  __shared__ double sh[4];
+  const int s_ = blockIdx.z, b = blockIdx.y;
+  const long long per_batch = sc.per_batch[s_];
+  if ((long long)blockIdx.x * kT >= per_batch) return;             // (the grid is sized for the largest scale; whole blocks leave)
+  const double fl = load_floor(floor_, floor_f64, (long long)b * floor_stride);
+  const float* eb = sc.e[s_] + (long long)b * per_batch;
+  const float* gb = sc.gt[s_] + (long long)b * per_batch;
+  double s = 0.0, c = 0.0;
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < per_batch; i += (long long)gridDim.x * kT) {
+    const float g = gb[i];
+    if ((double)g > fl) {
+      const float d = eb[i] - g, a = fabsf(d);
+      s += (double)(a < 1.0f ? 0.5f * d * d : a - 0.5f);
+      c += 1.0;
+    }
+  }
+  s = block_sum(s, sh);
+  c = block_sum(c, sh);
+  if (threadIdx.x == 0) {
+    atomicAdd(&acc[2 * s_], s);
+    atomicAdd(&acc[2 * s_ + 1], c);
+  }
+}
+
+__global__ __launch_bounds__(kT) void masked_smooth_l1_bwd_multi_kernel(L1Scales sc, const void* __restrict__ floor_, int floor_f64, int floor_stride,
+                                                                        const float* __restrict__ dloss, const float* __restrict__ inv_count) {
+  const int s_ = blockIdx.z, b = blockIdx.y;
+  float* de = sc.de[s_];
+  const long long per_batch = sc.per_batch[s_];
+  if (!de || (long long)blockIdx.x * kT >= per_batch) return;
+  const double fl = load_floor(floor_, floor_f64, (long long)b * floor_stride);
+  const float scale = dloss[0] * inv_count[s_];
+  const long long off = (long long)b * per_batch;
+  const float* e = sc.e[s_];
+  const float* gt = sc.gt[s_];
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < per_batch; i += (long long)gridDim.x * kT) {
+    const float g = gt[off + i];
+    const float d = e[off + i] - g;
+    de[off + i] = ((double)g > fl) ? scale * fminf(fmaxf(d, -1.0f), 1.0f) : 0.0f;
+  }
+}
+
 int grid_x(long long per_batch) {
   long long g = (per_batch + 4 * kT - 1) / (4 * kT);
   return (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
@@ -106,6 +160,42 @@ extern "C" int mdf_masked_smooth_l1_bwd(const float* est, const float* gt, const
   hipLaunchKernelGGL(masked_smooth_l1_bwd_kernel, dim3(grid_x(per_batch), B), dim3(kT), 0, (hipStream_t)stream, est, gt, floor_, floor_f64,
                      floor_stride, per_batch, dloss, inv_count, dest);
   return mdf::check_launch("masked_smooth_l1_bwd_kernel");
+}
+
+extern "C" int mdf_masked_smooth_l1_reduce_multi(const float* const* est, const float* const* gt, const long long* per_batch, int nscales,
+                                                 const void* floor_, int floor_f64, int floor_stride, int B, double* acc, void* stream) {
+  MDF_REQUIRE(est && gt && per_batch && floor_ && acc, "null pointer argument");
+  MDF_REQUIRE(nscales >= 1 && nscales <= kMaxScales && B > 0 && B <= 65535 && floor_stride >= 0, "bad argument (at most %d scales)", kMaxScales);
+  L1Scales sc{};
+  sc.n = nscales;
+  long long big = 0;
+  for (int i = 0; i < nscales; ++i) {
+    MDF_REQUIRE(est[i] && gt[i] && per_batch[i] > 0, "null pointer / empty scale %d", i);
+    sc.e[i] = est[i]; sc.gt[i] = gt[i]; sc.per_batch[i] = per_batch[i];
+    big = per_batch[i] > big ? per_batch[i] : big;
+  }
+  hipLaunchKernelGGL(masked_smooth_l1_reduce_multi_kernel, dim3(grid_x(big), B, nscales), dim3(kT), 0, (hipStream_t)stream, sc, floor_, floor_f64,
+                     floor_stride, acc);
+  return mdf::check_launch("masked_smooth_l1_reduce_multi_kernel");
+}
+
+extern "C" int mdf_masked_smooth_l1_bwd_multi(const float* const* est, const float* const* gt, const long long* per_batch, int nscales,
+                                              const void* floor_, int floor_f64, int floor_stride, int B, const float* dloss,
+                                              const float* inv_count, float* const* dest, void* stream) {
+  MDF_REQUIRE(est && gt && per_batch && floor_ && dloss && inv_count && dest, "null pointer argument");
+  MDF_REQUIRE(nscales >= 1 && nscales <= kMaxScales && B > 0 && B <= 65535 && floor_stride >= 0, "bad argument (at most %d scales)", kMaxScales);
+  L1Scales sc{};
+  sc.n = nscales;
+  long long big = 0;
+  for (int i = 0; i < nscales; ++i) {
+    MDF_REQUIRE(est[i] && gt[i] && per_batch[i] > 0, "null pointer / empty scale %d", i);
+    sc.e[i] = est[i]; sc.gt[i] = gt[i]; sc.de[i] = dest[i]; sc.per_batch[i] = per_batch[i];
+    if (dest[i]) big = per_batch[i] > big ? per_batch[i] : big;
+  }
+  if (big == 0) return MDF_OK;       // no scale wants a gradient
+  hipLaunchKernelGGL(masked_smooth_l1_bwd_multi_kernel, dim3(grid_x(big), B, nscales), dim3(kT), 0, (hipStream_t)stream, sc, floor_, floor_f64,
+                     floor_stride, dloss, inv_count);
+  return mdf::check_launch("masked_smooth_l1_bwd_multi_kernel");
 }
 
 // ---- Adam over all parameters in one launch (train.py:14: torch.optim.Adam(lr=1e-3), defaults otherwise) -------------------

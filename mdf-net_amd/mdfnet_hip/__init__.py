@@ -81,6 +81,9 @@ SIGNATURES = {
     "mdf_masked_smooth_l1_reduce": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_i64, c_fp, c_fp]),
     "mdf_masked_smooth_l1_finalize": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp]),
     "mdf_masked_smooth_l1_bwd": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_i64, c_fp, c_fp, c_fp, c_fp]),
+    "mdf_masked_smooth_l1_reduce_multi": (c_int, [ctypes.POINTER(c_fp), ctypes.POINTER(c_fp), ctypes.POINTER(c_i64), c_int, c_fp, c_int, c_int, c_int, c_fp, c_fp]),
+    "mdf_masked_smooth_l1_bwd_multi": (c_int, [ctypes.POINTER(c_fp), ctypes.POINTER(c_fp), ctypes.POINTER(c_i64), c_int, c_fp, c_int, c_int, c_int, c_fp, c_fp,
+                                               ctypes.POINTER(c_fp), c_fp]),
     "mdf_fpn_compose_fwd": (c_int, [c_fp] * 6 + [c_int] * 3 + [c_fp, c_fp]),
     "mdf_fpn_compose_bwd": (c_int, [c_fp] * 14 + [c_int] * 3 + [c_fp] * 7),
     "mdf_adam_job_bytes": (c_i64, []),

@@ -1143,11 +1143,19 @@ class LossTrainFn(torch.autograd.Function):
         f64, fstride = int(fl.dtype == torch.float64), fl.stride(0) if fl.dim() > 0 else 0
         acc = step_pool(dev).take(2 * ns)
         st = _stream(ests[0])
-        for s_, (e, g) in enumerate(zip(ests, gts)):
+        for e, g in zip(ests, gts):
             assert e.shape == g.shape and e.shape[0] == b, (e.shape, g.shape)
-            _abi("mdf_masked_smooth_l1_reduce", (e.data_ptr(), g.data_ptr(), fl.data_ptr(), f64, fstride, b, e.numel() // b,
-                                                 acc[2 * s_:].data_ptr(), st), tag=f"loss {tuple(e.shape)}",
-                 work={"bytes": 8.0 * e.numel(), "bound": "hbm"})
+        if ns <= 8:     # all scales in one launch (blockIdx.z = scale)
+            ep = (ctypes.c_void_p * ns)(*[e.data_ptr() for e in ests])
+            gp = (ctypes.c_void_p * ns)(*[g.data_ptr() for g in gts])
+            pb = (ctypes.c_int64 * ns)(*[e.numel() // b for e in ests])
+            _abi("mdf_masked_smooth_l1_reduce_multi", (ep, gp, pb, ns, fl.data_ptr(), f64, fstride, b, acc.data_ptr(), st), tag=f"loss {ns} scales",
+                 work={"bytes": 8.0 * sum(e.numel() for e in ests), "bound": "hbm"})
+        else:
+            for s_, (e, g) in enumerate(zip(ests, gts)):
+                _abi("mdf_masked_smooth_l1_reduce", (e.data_ptr(), g.data_ptr(), fl.data_ptr(), f64, fstride, b, e.numel() // b,
+                                                     acc[2 * s_:].data_ptr(), st), tag=f"loss {tuple(e.shape)}",
+                     work={"bytes": 8.0 * e.numel(), "bound": "hbm"})
         loss = torch.empty((), device=dev, dtype=torch.float32)
         inv = torch.empty(ns, device=dev, dtype=torch.float32)
         _abi("mdf_masked_smooth_l1_finalize", (acc.data_ptr(), ns, loss.data_ptr(), inv.data_ptr(), st))
@@ -1160,6 +1168,21 @@ class LossTrainFn(torch.autograd.Function):
         ests, gts, fl, f64, fstride, inv = ctx.saved
         dl = _f32c(dloss)
         out = [None]
+        ns = len(ests)
+        if ns <= 8:
+            b = ests[0].shape[0]
+            des = [torch.empty_like(e) if need else None for e, need in zip(ests, ctx.needs)]
+            if any(d is not None for d in des):
+                ep = (ctypes.c_void_p * ns)(*[e.data_ptr() for e in ests])
+                gp = (ctypes.c_void_p * ns)(*[g.data_ptr() for g in gts])
+                dp = (ctypes.c_void_p * ns)(*[None if d is None else d.data_ptr() for d in des])
+                pb = (ctypes.c_int64 * ns)(*[e.numel() // b for e in ests])
+                _abi("mdf_masked_smooth_l1_bwd_multi", (ep, gp, pb, ns, fl.data_ptr(), f64, fstride, b, dl.data_ptr(), inv.data_ptr(), dp, _stream(ests[0])),
+                     tag=f"loss bwd {ns} scales", work={"bytes": 12.0 * sum(e.numel() for e, d in zip(ests, des) if d is not None), "bound": "hbm"})
+            for d in des:
+                out += [d, None]
+            ctx.saved = None
+            return tuple(out)
         for s_, (e, g) in enumerate(zip(ests, gts)):
             de = None
             if ctx.needs[s_]:
