@@ -306,6 +306,12 @@ int mdf_upsample2_bilinear_bwd(const float* dfine, float* dcoarse, int B, int h,
 int mdf_prob_softmax_regress_bwd(const float* prob, const float* hypos, int hypos_per_pixel, const float* ddepth,
                                  const float* dprob, float* dlogit, int B, int D, int h, int w, void* stream);
 int mdf_prob_conv_dgrad(const float* dlogit, const float* w, float* dx, int B, int D, int h, int wd, int C, void* stream);
+/*      The same with the BatchNorm-backward sums of the regulariser's last layer taken on the way (dx is that layer's complete dz):
+ *      stat_y = the layer's raw conv output [B*D*h*wd][C], stat_aux = its (a, b, mean, invstd) [4C] as mdf_bn_finalize_fwd wrote them,
+ *      red = [nslices][2C] doubles zeroed by the caller (block b adds into copy b % nslices): sum dr | sum dr * xhat, the input of
+ *      mdf_bn_relu_bwd (instead of a pass of mdf_bn_relu_bwd_reduce over dx and stat_y).                                          */
+int mdf_prob_conv_dgrad_stat(const float* dlogit, const float* w, float* dx, int B, int D, int h, int wd, int C, const float* stat_y,
+                             const float* stat_aux, double* red, int nslices, void* stream);
 
 /* ---- training-mode VectorAggregate fused with the warp (homoaggregate.py:16-20,25-46 with the 1-channel
  *      BatchNorm3d in batch-statistics mode -- a global reduction per source view between similarity and view weight;

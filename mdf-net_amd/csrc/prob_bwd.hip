@@ -46,15 +46,36 @@ __global__ __launch_bounds__(256) void softmax_regress_bwd_kernel(const float* _
   }
 }
 
-template <int C>
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_shr(float v) {     // lane l reads lane l - n of its 16-lane row (0 where there is none)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+// STAT: dx is the COMPLETE gradient of the regulariser's last layer (nothing else consumes its output), so the sums its BatchNorm
+// backward needs -- sum dr, sum dr * xhat with dr = dx where the layer's ReLU was open -- are taken here, while dx is in registers,
+// instead of by a pass of their own over dx and the layer's raw output (mdf_bn_relu_bwd_reduce; same formulas, bn_train.hip).
+// stat_y = that raw output [n][C], stat_aux = (a, b, mean, invstd) [4C], red = [nslices][2C] doubles, zeroed by the caller.
+template <int C, bool STAT>
 __global__ __launch_bounds__(256) void prob_conv_dgrad_kernel(const float* __restrict__ dlogit, const float* __restrict__ w,
-                                                              float* __restrict__ dx, int B, int D, int H, int W) {
+                                                              float* __restrict__ dx, int B, int D, int H, int W,
+                                                              const float* __restrict__ stat_y, const float* __restrict__ stat_aux,
+                                                              double* __restrict__ red, int nslices) {
   __shared__ float wt[27 * C];   // [tap][c], tap order of the FORWARD kernel (kd,kh,kw)
+  __shared__ float ax[STAT ? 4 * C : 1];
+  __shared__ double rsum[STAT ? 16 : 1][2 * C];
   for (int i = threadIdx.x; i < 27 * C; i += 256) {
     const int c = i % C, tap = i / C;
     wt[i] = w[c * 27 + tap];     // torch [1,C,3,3,3]
   }
+  if constexpr (STAT) {
+    for (int i = threadIdx.x; i < 4 * C; i += 256) ax[i] = stat_aux[i];
+  }
   __syncthreads();
+  float ps[STAT ? C : 1], pq[STAT ? C : 1];
+  if constexpr (STAT) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) { ps[c] = 0.0f; pq[c] = 0.0f; }
+  }
   const int n = B * D * H * W;            // (< 2^31: checked by the entry point; 64-bit divisions cost more than the taps)
   for (int v = blockIdx.x * 256 + threadIdx.x; v < n; v += gridDim.x * 256) {
     const int x = v % W;
@@ -90,6 +111,41 @@ __global__ __launch_bounds__(256) void prob_conv_dgrad_kernel(const float* __res
     float4* o = reinterpret_cast<float4*>(dx + (size_t)v * C);
 #pragma unroll
     for (int c = 0; c < C; c += 4) o[c / 4] = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+    if constexpr (STAT) {
+      const float4* yp = reinterpret_cast<const float4*>(stat_y + (size_t)v * C);
+#pragma unroll
+      for (int c = 0; c < C; c += 4) {
+        const float4 yv4 = yp[c / 4];
+        const float yv[4] = {yv4.x, yv4.y, yv4.z, yv4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float dr = (fmaf(yv[k], ax[c + k], ax[C + c + k]) > 0.0f) ? acc[c + k] : 0.0f;
+          ps[c + k] += dr;
+          pq[c + k] = fmaf(dr, (yv[k] - ax[2 * C + c + k]) * ax[3 * C + c + k], pq[c + k]);
+        }
+      }
+    }
+  }
+  if constexpr (STAT) {
+    // the 16 lanes of a row add up with DPP row shifts (an inclusive scan: the row's last lane ends up with the total), the 16 rows
+    // of the block through LDS, and the block sends 2C doubles to its copy of the sums
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      float x = ps[c], y = pq[c];
+      x += dpp_row_shr<0x111>(x); y += dpp_row_shr<0x111>(y);
+      x += dpp_row_shr<0x112>(x); y += dpp_row_shr<0x112>(y);
+      x += dpp_row_shr<0x114>(x); y += dpp_row_shr<0x114>(y);
+      x += dpp_row_shr<0x118>(x); y += dpp_row_shr<0x118>(y);
+      if ((tid & 15) == 15) { rsum[tid >> 4][c] = (double)x; rsum[tid >> 4][C + c] = (double)y; }
+    }
+    __syncthreads();
+    if (tid < 2 * C) {
+      double t = 0.0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += rsum[r][tid];
+      atomicAdd(&red[(size_t)(blockIdx.x % nslices) * 2 * C + tid], t);
+    }
   }
 }
 
@@ -111,15 +167,31 @@ extern "C" int mdf_prob_softmax_regress_bwd(const float* prob, const float* hypo
   return mdf::check_launch("softmax_regress_bwd_kernel");
 }
 
-extern "C" int mdf_prob_conv_dgrad(const float* dlogit, const float* w, float* dx, int B, int D, int h, int wd, int C, void* stream) {
+static int prob_conv_dgrad_impl(const float* dlogit, const float* w, float* dx, int B, int D, int h, int wd, int C, const float* stat_y,
+                                const float* stat_aux, double* red, int nslices, void* stream) {
   MDF_REQUIRE(dlogit && w && dx, "null pointer argument");
   MDF_REQUIRE(B > 0 && D > 0 && h > 0 && wd > 0, "bad shape");
   const long long n = (long long)B * D * h * wd;
   MDF_REQUIRE(n < (1ll << 31), "volume must have fewer than 2^31 voxels");
   long long g = (n + 255) / 256;
   if (g > 4096) g = 4096;
-  if (C == 8) hipLaunchKernelGGL(prob_conv_dgrad_kernel<8>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, dlogit, w, dx, B, D, h, wd);
-  else if (C == 16) hipLaunchKernelGGL(prob_conv_dgrad_kernel<16>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, dlogit, w, dx, B, D, h, wd);
+  const bool stat = red != nullptr;
+#define MDF_PCD(CC, ST) hipLaunchKernelGGL((prob_conv_dgrad_kernel<CC, ST>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, dlogit, w, dx, B, D, h, wd, \
+                                           stat_y, stat_aux, red, nslices)
+  if (C == 8) { if (stat) MDF_PCD(8, true); else MDF_PCD(8, false); }
+  else if (C == 16) { if (stat) MDF_PCD(16, true); else MDF_PCD(16, false); }
   else return mdf::fail(MDF_EUNSUPPORTED, "prob head backward is built for C in {8,16}, got %d", C);
+#undef MDF_PCD
   return mdf::check_launch("prob_conv_dgrad_kernel");
+}
+
+extern "C" int mdf_prob_conv_dgrad(const float* dlogit, const float* w, float* dx, int B, int D, int h, int wd, int C, void* stream) {
+  return prob_conv_dgrad_impl(dlogit, w, dx, B, D, h, wd, C, nullptr, nullptr, nullptr, 1, stream);
+}
+
+extern "C" int mdf_prob_conv_dgrad_stat(const float* dlogit, const float* w, float* dx, int B, int D, int h, int wd, int C, const float* stat_y,
+                                        const float* stat_aux, double* red, int nslices, void* stream) {
+  MDF_REQUIRE(stat_y && stat_aux && red, "null pointer argument");
+  MDF_REQUIRE(nslices >= 1, "nslices must be >= 1");
+  return prob_conv_dgrad_impl(dlogit, w, dx, B, D, h, wd, C, stat_y, stat_aux, red, nslices, stream);
 }

@@ -73,6 +73,7 @@ SIGNATURES = {
     "mdf_upsample2_bilinear_bwd": (c_int, [c_fp, c_fp] + [c_int] * 5 + [c_fp]),
     "mdf_prob_softmax_regress_bwd": (c_int, [c_fp, c_fp, c_int, c_fp, c_fp, c_fp] + [c_int] * 4 + [c_fp]),
     "mdf_prob_conv_dgrad": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 5 + [c_fp]),
+    "mdf_prob_conv_dgrad_stat": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 5 + [c_fp, c_fp, c_fp, c_int, c_fp]),
     "mdf_warp_aggregate_vec_train": (c_int, [c_int, c_fp, ctypes.POINTER(c_fp), c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                              c_fp, ctypes.POINTER(c_fp), c_fp, c_fp] + [c_int] * 7 + [c_fp]),
     "mdf_aggregate_train_prepare": (c_int, [c_fp] * 4 + [c_i64, c_int, c_int, c_fp, c_fp, c_int, c_fp]),

@@ -227,8 +227,9 @@ def conv3d_dgrad(conv, transposed, dy, add_to=None, stat=None):
 
 
 # --------------------------------------------------------------------------- prob head backward
-def prob_head_backward(prob, hypos, ddepth, dprob, x_feat, weight):
-    """-> (dx_feat [B,D,h,w,C], dweight [1,C,3,3,3])."""
+def prob_head_backward(prob, hypos, ddepth, dprob, x_feat, weight, stat=None):
+    """-> (dx_feat [B,D,h,w,C], dweight [1,C,3,3,3]).  stat = (y_p, aux_p, red): dx is the complete dz of the layer that produced x_feat
+    (raw output y_p, BatchNorm constants aux_p); its backward sums are accumulated into red [STAT_SLICES][2C] on the way."""
     b, d, h, w = prob.shape
     c = x_feat.shape[-1]
     hyp, pp = (None, 0) if hypos is None else _hypos_arg(hypos, h, w)
@@ -239,8 +240,13 @@ def prob_head_backward(prob, hypos, ddepth, dprob, x_feat, weight):
                                           _stream(prob)), tag=f"softmax-bwd {d}x{h}x{w}",
          work={"bytes": 4.0 * prob.numel() * (3 if dprob is not None else 2), "bound": "hbm"})
     dx = torch.empty_like(x_feat)
-    _abi("mdf_prob_conv_dgrad", (dlogit.data_ptr(), _f32c(weight.detach()).data_ptr(), dx.data_ptr(), b, d, h, w, c, _stream(dx)),
-         tag=f"1->{c} dgrad {d}x{h}x{w}", work={"bytes": 4.0 * (dlogit.numel() + dx.numel()), "bound": "hbm"})
+    if stat is not None:
+        _abi("mdf_prob_conv_dgrad_stat", (dlogit.data_ptr(), _f32c(weight.detach()).data_ptr(), dx.data_ptr(), b, d, h, w, c, stat[0].data_ptr(),
+                                          stat[1].data_ptr(), stat[2].data_ptr(), stat[2].numel() // (2 * c), _stream(dx)),
+             tag=f"1->{c} dgrad {d}x{h}x{w} +sums2", work={"bytes": 4.0 * (dlogit.numel() + 2 * dx.numel()), "bound": "hbm"})
+    else:
+        _abi("mdf_prob_conv_dgrad", (dlogit.data_ptr(), _f32c(weight.detach()).data_ptr(), dx.data_ptr(), b, d, h, w, c, _stream(dx)),
+             tag=f"1->{c} dgrad {d}x{h}x{w}", work={"bytes": 4.0 * (dlogit.numel() + dx.numel()), "bound": "hbm"})
     dw = conv3d_wgrad(dlogit.view(b, d, h, w, 1), x_feat, 1, tuple(weight.shape), weight if isinstance(weight, torch.nn.Parameter) else None)
     return dx, dw
 
@@ -281,12 +287,13 @@ class Tape:
         self.layers.append((conv, bn, tr, stride, x, y, aux, res, z))
         return z
 
-    def backward(self, grads):
+    def backward(self, grads, red_of=None):
         """grads: {id(tensor): gradient} holding the gradient of the last layer's output; returns parameter grads
-        {param: grad} and leaves the input gradients in `grads`."""
+        {param: grad} and leaves the input gradients in `grads`.  red_of: {layer index: BatchNorm-backward sums already taken by the
+        kernel that produced that layer's dz} (the prob head's input-gradient launch for the last layer)."""
         pg = {}
         pool = step_pool(self.layers[0][4].device)
-        pending, red_of = dict(self.uses), {}
+        pending, red_of = dict(self.uses), dict(red_of or {})
         for li in reversed(range(len(self.layers))):
             conv, bn, tr, stride, x, y, aux, res, z = self.layers[li]
             dz = grads.pop(id(z))
@@ -341,9 +348,16 @@ class RegulariserTrainFn(torch.autograd.Function):
         module, tape = ctx.module, ctx.tape
         if dprob is None and ddepth is None:
             return (None,) * (3 + len(ctx.params))
-        dfeat, dwp = prob_head_backward(prob, ctx.hypos, ddepth, dprob, ctx.feat, module.prob.weight)
+        stat, red_of = None, None
+        last = len(tape.layers) - 1
+        if FUSE_BN_SUMS and last >= 0 and tape.layers[last][8] is ctx.feat and tape.uses.get(id(ctx.feat), 0) == 0 and ctx.feat.shape[-1] in (8, 16):
+            # the prob head is the only consumer of the last layer's output: its input-gradient launch takes that layer's backward sums
+            conv_l, _, _, _, _, y_l, aux_l, _, _ = tape.layers[last]
+            red = step_pool(ctx.feat.device).take(ops.STAT_SLICES * 2 * conv_l.out_channels)
+            stat, red_of = (y_l, aux_l, red), {last: red}
+        dfeat, dwp = prob_head_backward(prob, ctx.hypos, ddepth, dprob, ctx.feat, module.prob.weight, stat=stat)
         grads = {id(ctx.feat): dfeat}
-        pg = tape.backward(grads)
+        pg = tape.backward(grads, red_of=red_of)
         pg[module.prob.weight] = dwp
         dcost = ops.from_ndhwc(grads.pop(id(ctx.x0)))
         ctx.tape = None

@@ -197,7 +197,7 @@ def test_fused_bn_sums_equal_the_separate_passes(stage, seeded_sd, monkeypatch):
         reg.zero_grad()
         if fused:
             assert calls.get("mdf_bn_stats_fwd", 0) == 0 and calls.get("mdf_conv3d_train_fwd", 0) >= 10
-            assert calls.get("mdf_bn_relu_bwd_reduce", 0) == 1, calls          # only the last layer (its dz comes from the prob head)
+            assert calls.get("mdf_bn_relu_bwd_reduce", 0) == 0 and calls.get("mdf_prob_conv_dgrad_stat", 0) == 1, calls   # the last layer's sums ride in the prob head's input-gradient launch
         else:
             assert calls.get("mdf_conv3d_train_fwd", 0) == 0 and calls.get("mdf_bn_relu_bwd_reduce", 0) >= 10
     for i, (a, b_) in enumerate(zip(res[True], res[False])):
@@ -461,7 +461,7 @@ def test_training_step_on_gpu_vs_reference_golden(golden, seeded_sd):
         loss.backward()
     finally:
         train_ops._abi = orig
-    assert {"mdf_warp_aggregate_vec_train", "mdf_conv3d_wgrad_partial", "mdf_wgrad_sum_batch", "mdf_bn_relu_bwd", "mdf_prob_conv_dgrad"} <= set(used)
+    assert {"mdf_warp_aggregate_vec_train", "mdf_conv3d_wgrad_partial", "mdf_wgrad_sum_batch", "mdf_bn_relu_bwd", "mdf_prob_conv_dgrad_stat"} <= set(used)
     bucket.allreduce_gradients()
     for i, d in enumerate(out["depth"]):
         err = np.abs(d.detach().cpu().numpy() - g[f"depth{i}"])
