@@ -218,42 +218,46 @@ def profile_pass(model, inputs, steps=3):
     return family_table(recs, steps, lambda n, t: None if n == "mdf_conv3d_pack_weights" else family(n, t)), info
 
 
+def _newest_profile(suffix):
+    """profiles/rNN_<suffix> of the highest round present -> (path, name) or (None, None)."""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return (c[-1], "profiles/" + os.path.basename(c[-1])) if c else (None, None)
+
+
 def measured_traffic(kind="eval"):
     """HBM bytes per step per kernel family, measured offline with rocprofv3 PMC (FETCH_SIZE / WRITE_SIZE in separate
     passes, gfx950 corrections applied; scripts/summarize_traffic.py) and committed under profiles/: the newest round's file
     for this workload.  -> (families dict, file name)"""
-    names = {"eval": ["r03_traffic.json", "r02_traffic.json", "r01_traffic.json"],
-             "train": ["r03_train_traffic.json", "r02_train_traffic.json"]}[kind]
-    for name in names:
-        path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path):
-            with open(path) as f:
-                return json.load(f).get("families", {}), "profiles/" + name
+    path, name = _newest_profile({"eval": "traffic.json", "train": "train_traffic.json"}[kind])
+    if path:
+        with open(path) as f:
+            return json.load(f).get("families", {}), name
     return {}, None
 
 
 def rocprof_conv_family():
     """The conv family's time per forward by rocprofv3 --kernel-trace --stats of the SAME command (one view at a time), from the
-    summary committed under profiles/ (scripts/r03_profiles.sh): the cross-check the contract asks the live figure to agree with.
-    The live HIP-event brackets run ~6 % above it (an event pair serialises the launch against its neighbours even after the
-    empty-bracket cost is subtracted); rocprof's durations are the kernels' own.  -> dict or None"""
+    newest summary committed under profiles/ (scripts/r04_profiles.sh): the cross-check the contract asks the live figure to
+    agree with.  The family is every kernel mdfnet_hip/kernel_families.py files under `mfma_conv` (exact function names, with a
+    CPU test that no `__global__` of csrc/ is unclassified -- the r03 figure missed `convtr_all_kernel`).  -> dict or None"""
     import csv
-    path = os.path.join(ROOT, "profiles", "r03_bench_cfg2_kernel_stats.csv")
-    if not os.path.exists(path):
+    from mdfnet_hip import kernel_families as KF
+    path, name = _newest_profile("bench_cfg2_kernel_stats.csv")
+    if not path:
         return None
-    fam = ("conv_lds_kernel", "conv3d_kernel", "conv_pair_kernel", "conv1x1_kernel", "refine_tail_kernel", "prob_fused_kernel")
     ns, forwards, launches = 0, 0, 0
     with open(path) as f:
         for r in csv.DictReader(f):
-            if "conv_pair_kernel" in r["Name"]:
+            if KF.function_name(r["Name"]) == "conv_pair_kernel":
                 forwards = int(r["Calls"])                      # exactly one launch per forward
-            if any(k in r["Name"] for k in fam):
+            if KF.family(r["Name"]) == KF.MFMA_CONV:
                 ns += int(r["TotalDurationNs"])
                 launches += int(r["Calls"])
     if not forwards:
         return None
     return {"ms_per_step": round(ns / forwards / 1e6, 3), "launches_per_step": round(launches / forwards, 1), "forwards": forwards,
-            "source": "profiles/r03_bench_cfg2_kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py --in-flight 1, offline)"}
+            "source": name + " (rocprofv3 --kernel-trace --stats of bench.py --in-flight 1, offline)"}
 
 
 def attach_traffic(kernels, traffic, source, fam_of):
@@ -640,6 +644,11 @@ def main():
                 if rp:
                     rp["achieved"] = round(gf / rp["ms_per_step"], 2)
                     rp["frac"] = round(gf / rp["ms_per_step"] / PEAK_FP32_MFMA_TFLOPS, 4)
+                    if rp["launches_per_step"] != rec["roofline"]["launches_per_step"]:
+                        rp["warning"] = (f"launch count differs from the live pass ({rp['launches_per_step']} vs "
+                                         f"{rec['roofline']['launches_per_step']}): the committed profile is of another tree or a "
+                                         "kernel of the family is missing from mdfnet_hip/kernel_families.py")
+                        print("bench.py: WARNING " + rp["warning"], file=sys.stderr)
                     rec["roofline"]["rocprof"] = rp
             rec["kernels"] = kernels
             rec["hip_kernels_ms_per_step"] = round(sum(k["ms_per_step"] for k in kernels), 3)

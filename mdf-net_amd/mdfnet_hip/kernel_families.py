@@ -1,0 +1,80 @@
+"""Which measurement family every `__global__` kernel of csrc/*.hip belongs to -- the ONE table behind bench.py's rocprof
+cross-check, scripts/summarize_traffic.py (PMC bytes per family) and scripts/summarize_rocprof.py ("hand-written" time).
+
+A kernel is looked up by its exact function name (templates, namespaces and the parameter list of a rocprof `Name` column are
+stripped first), never by substring: round 3 lost `convtr_all_kernel` from three substring filters after a rename and reported
+the conv family 6.6 % too fast.  tests/test_kernel_families_cpu.py asserts that the keys of KERNEL_FAMILY are exactly the
+`__global__` names in csrc/, so a new or renamed kernel fails the CPU suite until it is classified here."""
+import re
+
+# family keys (the names the profiles/*.json files carry)
+MFMA_CONV = "mfma_conv"                    # everything reached through mdf_conv{2d,3d}[_train]_fwd, prob_fused, refine_tail
+WARP = "warp_aggregate"                    # eval warp + aggregation
+WARP_TRAIN = "aggregate_train_passes"
+WARP_SCATTER = "aggregate_scatter"
+WGRAD = "wgrad"
+BN = "batchnorm_train"
+PROB = "prob_head"
+HEADS = "heads"
+FILTER = "consistency_filter"
+CONTROL = "control"                        # weight packing, Adam, loss, finalisers: launch-bound one-block kernels
+
+KERNEL_FAMILY = {
+    # conv_lds.hip / conv3d.hip / conv_pair.hip / conv1x1.hip / refine_tail.hip / prob_fused.hip
+    "conv_lds_kernel": MFMA_CONV, "conv3d_kernel": MFMA_CONV, "convtr_all_kernel": MFMA_CONV, "conv_pair_kernel": MFMA_CONV,
+    "conv1x1_kernel": MFMA_CONV, "refine_tail_kernel": MFMA_CONV, "prob_fused_kernel": MFMA_CONV,
+    "pack_weights_kernel": CONTROL, "pack_batch_kernel": CONTROL,
+    # warp_aggregate.hip
+    "warp_kernel": WARP, "warp_vec8_kernel": WARP, "warp_vec_win_kernel": WARP, "corner_index_kernel": WARP,
+    # warp_aggregate_train.hip
+    "warp_train_kernel": WARP_TRAIN, "warp_bwd_kernel": WARP_SCATTER,
+    "agg_prepare_kernel": CONTROL, "agg_finalize_kernel": CONTROL, "agg_bwd_finalize_kernel": WARP_SCATTER,
+    # wgrad.hip / wgrad_lds.hip
+    "wgrad_kernel": WGRAD, "wgrad_a1_kernel": WGRAD, "wgrad_a1_valu_kernel": WGRAD, "wgrad2d_kernel": WGRAD,
+    "wgrad_lds_kernel": WGRAD, "slab_sum_kernel": WGRAD, "slab_sum_batch_kernel": WGRAD,
+    # bn_train.hip
+    "bn_reduce_kernel": BN, "bn_finalize_kernel": BN, "bn_relu_apply_kernel": BN, "bn_finalize_apply_kernel": BN,
+    "bn_relu_bwd_kernel": BN,
+    # prob_head.hip / prob_bwd.hip / upsample_bwd.hip
+    "prob_head_kernel": PROB, "prob_head_tiled_kernel": PROB, "prob_from_partials_kernel": PROB,
+    "softmax_regress_bwd_kernel": PROB, "prob_conv_dgrad_kernel": PROB, "upsample2_bwd_kernel": PROB,
+    # regress.hip / fpn_compose.hip
+    "depth_regress_kernel": HEADS, "confidence_kernel": HEADS, "confidence_up2_kernel": HEADS, "range_affine_kernel": HEADS,
+    "hypos_fit_kernel": HEADS, "hypos_from_fit_kernel": HEADS, "fpn_compose_fwd_kernel": HEADS, "fpn_compose_bwd_kernel": HEADS,
+    # consistency.hip
+    "consistency_fuse_kernel": FILTER,
+    # loss.hip
+    "masked_smooth_l1_reduce_kernel": CONTROL, "masked_smooth_l1_finalize_kernel": CONTROL, "masked_smooth_l1_bwd_kernel": CONTROL,
+    "masked_smooth_l1_reduce_multi_kernel": CONTROL, "masked_smooth_l1_bwd_multi_kernel": CONTROL, "adam_step_kernel": CONTROL,
+}
+
+def function_name(rocprof_name):
+    """`void (anonymous namespace)::conv_lds_kernel<16, 8, ...>(LdsConvParams)` -> `conv_lds_kernel`."""
+    s = rocprof_name.strip()
+    if s.startswith("void "):
+        s = s[5:]
+    s = s.replace("(anonymous namespace)::", "")
+    head = re.split(r"[<(]", s, maxsplit=1)[0]
+    return head.split("::")[-1].strip()
+
+
+def family(rocprof_name):
+    """Family of a kernel as rocprofv3 names it, or None for a kernel that is not one of csrc/'s (ATen, MIOpen, RCCL ...)."""
+    return KERNEL_FAMILY.get(function_name(rocprof_name))
+
+
+def is_ours(rocprof_name):
+    return function_name(rocprof_name) in KERNEL_FAMILY
+
+
+def globals_in_sources(csrc_dir):
+    """Every `__global__` function name declared in csrc_dir/*.hip (the test's ground truth)."""
+    import os
+    names = {}
+    for f in sorted(os.listdir(csrc_dir)):
+        if not f.endswith(".hip"):
+            continue
+        text = open(os.path.join(csrc_dir, f)).read()
+        for m in re.finditer(r"__global__\b[\s\S]*?\bvoid\s+([A-Za-z_][A-Za-z_0-9]*)\s*\(", text):
+            names.setdefault(m.group(1), f)
+    return names

@@ -8,19 +8,21 @@ stats = glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True)[
 rows = list(csv.DictReader(open(stats)))
 os.makedirs(os.path.dirname(dst), exist_ok=True)
 shutil.copy(stats, dst + "_kernel_stats.csv")
-ours = ("conv_lds_kernel", "prob_head_tiled", "conv3d_kernel", "warp_kernel", "prob_head_kernel", "prob_from_partials", "regress_kernel", "confidence_kernel", "hypos_", "pack_weights",
-        "corner_index", "conv2d_kernel", "refine_", "wgrad", "warp_train_kernel", "warp_bwd_kernel", "warp_vec_win", "warp_vec8", "bn_reduce", "bn_finalize", "bn_relu",
-        "slab_sum", "conv_pair_kernel", "conv1x1_kernel", "refine_tail_kernel", "prob_fused_kernel", "confidence_up2", "range_affine", "softmax_regress_bwd", "prob_conv_dgrad", "consistency_", "agg_", "pack_batch", "masked_smooth_l1", "adam_step", "fpn_compose", "upsample2_bwd")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mdf-net_amd"))
+from mdfnet_hip.kernel_families import is_ours, family, MFMA_CONV      # noqa: E402  (exact function names, CPU-tested against csrc/)
 unit = sys.argv[5] if len(sys.argv) > 5 else "forward"
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 tune = sum(float(r["TotalDurationNs"]) for r in rows if r["Name"].startswith("naive_conv"))
-mine = sum(float(r["TotalDurationNs"]) for r in rows if any(k in r["Name"] for k in ours))
+mine = sum(float(r["TotalDurationNs"]) for r in rows if is_ours(r["Name"]))
+conv = sum(float(r["TotalDurationNs"]) for r in rows if family(r["Name"]) == MFMA_CONV)
+nconv = sum(int(r["Calls"]) for r in rows if family(r["Name"]) == MFMA_CONV)
 with open(dst + ".md", "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats summary\n\ncommand: `{cmd}`\n\n")
     f.write(f"{unit} passes in the run (warm-up + timed): {steps}\n\n")
     f.write(f"* all kernels: {tot/1e6:.2f} ms; MIOpen find-mode `naive_conv*` (first call only): {tune/1e6:.2f} ms\n")
     f.write(f"* steady state per {unit}: {(tot-tune)/steps/1e6:.3f} ms GPU-busy, of which hand-written HIP kernels "
-            f"{mine/steps/1e6:.3f} ms\n\n| kernel | calls | calls/fwd | total ms | avg us | min us | max us |\n|---|---|---|---|---|---|---|\n")
+            f"{mine/steps/1e6:.3f} ms, of which the fp32-MFMA conv family (every launch of mdf_conv*_fwd, the one-launch prob head "
+            f"and the refine tail) {conv/steps/1e6:.3f} ms in {nconv/steps:.1f} launches\n\n| kernel | calls | calls/fwd | total ms | avg us | min us | max us |\n|---|---|---|---|---|---|---|\n")
     for r in rows[:45]:
         name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:110]
         f.write(f"| `{name}` | {r['Calls']} | {int(r['Calls'])/steps:.1f} | {float(r['TotalDurationNs'])/1e6:.3f} | "
