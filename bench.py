@@ -14,6 +14,12 @@ Rank 0 prints ONE JSON line; it also carries
   kernels       the same for every hand-written kernel family + the stock (MIOpen) remainder
   cpu_baseline  the oracle (CPU restatement of the reference, kind "port") timed on this box's host cores on a
                 bounded sample of the same workload (rank 0, N=1 only)
+  training      BASELINE configs[2].  N=1: one GPU's training step (768x576x5, batch 1) with its per-family table; N>1: EVERY rank
+                runs that step data-parallel with the flat-bucket gradient exchange over RCCL -- aggregate samples/s, the
+                collective's ms per step, and the direct (all-to-all + all-gather) exchange as a second figure
+  cfg4          BASELINE configs[3]: 1920x1056 with 7 and 11 views, views/s (rank 0, N=1)
+  cfg5_scan     BASELINE configs[4], one scan: 49 items with the cross-item feature cache + the fused consistency filter (rank 0, N=1)
+The headline `value` / `config` are the eval figures for every N; the blocks above are extra keys of the same line.
 """
 import argparse
 import json
@@ -433,6 +439,247 @@ def training_graph(steps, blocks, timeout=240.0):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+def _throughput(dev, fn_factory, n_items, in_flight, warm):
+    """views/s of `n_items` calls issued through the eval driver's InFlight queue (all work completes inside the timed region)."""
+    from mdfnet_hip.pipeline import InFlight
+    pipe = InFlight(dev, in_flight)
+    for i in range(warm):
+        pipe.submit(fn_factory(i))
+    pipe.drain()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n_items):
+        pipe.submit(fn_factory(i))
+    pipe.drain()
+    torch.cuda.synchronize()
+    return n_items / (time.perf_counter() - t0)
+
+
+def cfg4_block(dev, in_flight, items=12):
+    """BASELINE.json configs[3]: Tanks&Temples-shaped eval, 1920x1056, metric depth range, 7 views (config.py:119 of the reference
+    sets nviews per set; load/tankseval.py:36 crops to 1920x1056) and 11 views.  Reported NEXT to the headline (rank 0, N=1)."""
+    from mdfnet_hip import synth, hostmirror
+    model = build(dev)
+    rec = {"workload": "Tanks&Temples-shaped eval 1920x1056, depth range [0.5, 10], hypotheses (48,24,8), batch 1, synthetic tensors, "
+                       "seeded weights; fresh camera tensors every item, images resident", "items_timed": items, "dtype": "f32"}
+    with torch.no_grad():
+        for nv in (7, 11):
+            imgs = synth.make_images(1920, 1056, nv, batch=1, seed=5).to(dev)
+            intr, extr, dr = synth.make_cameras(1920, 1056, nv, batch=1, rot_deg=2.0, seed=6, depth_range=(0.5, 10.0), baseline=0.25)
+
+            def item(i, imgs=imgs, cams=(extr, intr, dr)):
+                host = tuple(t.clone() for t in cams)
+                devs = tuple(t.to(dev, non_blocking=True) for t in host)
+                for d_, h_ in zip(devs, host):
+                    hostmirror.put(d_, h_)
+                return lambda: model(imgs, *devs)
+            one = _throughput(dev, item, items, 1, 3)
+            many = _throughput(dev, item, items, in_flight, 2 * in_flight + 1) if in_flight > 1 else one
+            rec[f"{nv}_views"] = {"views_per_s": round(many, 2), "ms_per_view": round(1e3 / many, 3), "items_in_flight": in_flight,
+                                  "one_at_a_time_views_per_s": round(one, 2)}
+            del imgs
+    rec["peak_memory_gib"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
+    return rec
+
+
+def scan_cameras(width, height, nviews, seed=7, rot_deg=2.0, step=40.0):
+    """One synthetic DTU-like scan: `nviews` cameras on a line, 40 mm apart, small seeded rotations (so an item's 4 sources have the
+    +-40 / +-80 mm baselines of the headline scene) -> intrinsics [1,V,3,3], extrinsics [1,V,4,4], range [1,2]; pair lists as
+    pair.txt's: the 10 nearest views, nearest first."""
+    import numpy as np
+    from mdfnet_hip import synth
+    intr, extr, dr = synth.make_cameras(width, height, nviews, batch=1, rot_deg=0.0, seed=seed)
+    rng = np.random.RandomState(seed)
+    for v in range(nviews):
+        e = np.eye(4)
+        e[0, 3] = step * (v - nviews // 2)
+        e[1, 3] = 3.0 * ((v % 5) - 2)
+        e[:3, :3] = synth._rot(rng, rot_deg)
+        extr[0, v] = torch.from_numpy(e.astype(np.float32))
+    pairs = []
+    for r in range(nviews):
+        order = sorted((v for v in range(nviews) if v != r), key=lambda v: (abs(v - r), v))
+        pairs.append(order[:10])
+    return intr, extr, dr, pairs
+
+
+def cfg5_scan_block(dev, in_flight, nviews=49, nsrc_model=4):
+    """BASELINE.json configs[4], one scan's share: every view of a 49-view DTU-shaped scan as the reference view of a 5-view item at
+    1600x1184 through eval.py's issue pattern (items in flight, cross-item feature cache: each image goes through the feature pyramid
+    once -- SURVEY 8(f) N3), then the consistency filter + fusion of the scan's 49 depth maps against 10 source views each, one fused
+    launch per reference view (mdf_consistency_fuse_fwd; reference: tools/filter/dynamic_filter_gpu.py:12-164).  File IO excluded,
+    images resident, cameras fresh per item.  Reported NEXT to the headline (rank 0, N=1)."""
+    import sys as _sys
+    _sys.path.insert(0, os.path.join(ROOT, "mdf-net_amd"))
+    from eval import FeatureCache
+    from mdfnet_hip import synth, hostmirror, ops
+    model = build(dev)
+    imgs_all = synth.make_images(WIDTH, HEIGHT, nviews, batch=1, seed=9).to(dev)
+    intr, extr, dr, pairs = scan_cameras(WIDTH, HEIGHT, nviews)
+    depth = [None] * nviews
+    conf = [None] * nviews
+
+    def run_scan(cache_on, flight):
+        from mdfnet_hip.pipeline import InFlight
+        cache = FeatureCache() if cache_on else None
+
+        def done(tag, out):
+            depth[tag], conf[tag] = out["depth"][0], out["confidence"][0]
+        pipe = InFlight(dev, flight, done=done)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for r in range(nviews):
+                ids = [r] + pairs[r][:nsrc_model]
+                host = (extr[:, ids].clone(), intr[:, ids].clone(), dr.clone())
+                devs = tuple(t.to(dev, non_blocking=True) for t in host)
+                for d_, h_ in zip(devs, host):
+                    hostmirror.put(d_, h_)
+                im = imgs_all[:, ids]
+                if cache_on:
+                    pipe.submit(lambda im=im, c=devs, k=[("scan", v) for v in ids]: model(im, *c, feature_cache=cache, view_keys=k), tag=r, keep=devs)
+                else:
+                    pipe.submit(lambda im=im, c=devs: model(im, *c), tag=r, keep=devs)
+            pipe.drain()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    run_scan(True, in_flight)                         # warm-up (allocator pools of every stream, the cache's steady state)
+    t_plain = run_scan(False, in_flight)
+    t_cache = run_scan(True, in_flight)
+
+    def run_filter():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        kept = 0.0
+        res = []
+        for r in range(nviews):
+            src = pairs[r]
+            res.append(ops.consistency_fuse(depth[r], conf[r], intr[0, r], extr[0, r], [depth[v] for v in src],
+                                            [intr[0, v] for v in src], [extr[0, v] for v in src]))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        kept = float(torch.stack([x["final_mask"].float().mean() for x in res]).mean())
+        return dt, kept
+    run_filter()
+    ops.profile_begin()
+    t_filter, kept = run_filter()
+    launches = [x for x in ops.profile_end() if x[0] == "mdf_consistency_fuse_fwd"]
+    k_us = 1e3 * sum(x[2] for x in launches) / max(1, len(launches))
+    k_bytes = launches[0][3]["bytes"] if launches else 0.0
+    return {"workload": f"one DTU-shaped scan: {nviews} reference views x 5-view items at {WIDTH}x{HEIGHT} (hypotheses 48/24/8) + consistency "
+                        f"filter of the {nviews} depth maps against 10 source views each; synthetic tensors, seeded weights, no file IO",
+            "model": {"views_per_s": round(nviews / t_cache, 2), "ms_per_view": round(1e3 * t_cache / nviews, 3),
+                      "feature_cache": True, "items_in_flight": in_flight,
+                      "without_feature_cache_views_per_s": round(nviews / t_plain, 2)},
+            "filter": {"us_per_view_wall": round(1e6 * t_filter / nviews, 1), "kernel_us_per_view": round(k_us, 1),
+                       "kernel_gbs": round(k_bytes / (k_us * 1e-6) / 1e9, 1) if k_us else None,
+                       "kernel_frac_of_hbm_peak": round(k_bytes / (k_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4) if k_us else None,
+                       "algorithmic_bytes_per_view": round(k_bytes), "nsrc": 10, "final_mask_keeps": round(kept, 4),
+                       "note": "depth maps are the model's own (random weights: no two views agree, so the masks are nearly empty and "
+                               "the gathers incoherent); wall includes the host-side matrix set-up and mask conversions per view"},
+            "scan_views_per_s": round(nviews / (t_cache + t_filter), 2), "dtype": "f32"}
+
+
+def training_ddp_block(dev, world, rank, steps, blocks):
+    """BASELINE.json configs[2] over N ranks (called by EVERY rank when WORLD_SIZE > 1): data-parallel training step at 768x576x5,
+    batch 1 per rank = global batch N, the gradients of all replicas averaged by ONE collective over the flat 4.83-MB bucket per step
+    (mdfnet_hip/ddp.py; RCCL over xGMI when the backend is nccl) -- the data-parallel exchange of the reference's
+    nn.DataParallel (train.py:24-26).  Each block = EXACTLY `steps` steps between barrier + synchronize brackets, MAX over ranks.
+    Reports the aggregate samples/s, the collective's time inside the step (HIP events around it on the launch stream: includes
+    waiting for the slowest rank), the collective alone, and the same step with the two-step direct exchange
+    (MDF_GRAD_EXCHANGE=direct: all-to-all of shards + all-gather of the owners' sums) as a second figure."""
+    import statistics
+    from mdfnet_hip import synth, ddp
+    from mdfnet_hip.optim import FlatAdam
+    from net import loss as loss_mod
+    model = build(dev).train()
+    bucket = ddp.FlatBucket(model)
+    bucket.broadcast_parameters(0)
+    opt = FlatAdam(bucket, lr=1e-3)
+    crit = loss_mod.Loss().to(dev)
+    imgs, extr, intr, dr = (t.to(dev) for t in synth.make_scene(TRAIN_W, TRAIN_H, TRAIN_V, batch=1, rot_deg=2.0, seed=3 + rank))
+    g = torch.Generator(device="cpu").manual_seed(11 + rank)
+    gt = {str(k): (torch.rand(1, TRAIN_H >> k, TRAIN_W >> k, generator=g) * 400 + 480).to(dev) for k in (3, 2, 1, 0)}
+    on_gpu = dist.get_backend() == "nccl"
+
+    def step(mode, ev=None):
+        out = model(imgs, extr, intr, dr)
+        loss = crit(out, gt, dr)
+        bucket.zero_grad()
+        loss.backward()
+        if mode is None:
+            bucket.gather()                              # no exchange: what one rank does alone
+        else:
+            if ev is not None:
+                ev[0].record()
+            bucket.allreduce_gradients(mode)
+            if ev is not None:
+                ev[1].record()
+        opt.step()
+        return loss.detach()
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], device=dev if on_gpu else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(mode):
+        for _ in range(3):
+            last = step(mode)
+        times, coll = [], []
+        for _ in range(blocks):
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                last = step(mode, evs[i] if mode is not None else None)
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            times.append(max_over_ranks((time.perf_counter() - t0) / steps))
+            if mode is not None:
+                coll.append(sum(a.elapsed_time(b) for a, b in evs) / steps)
+        assert torch.isfinite(last).item()
+        med = statistics.median(times)
+        r = {"ms_per_step": round(1e3 * med, 3), "samples_per_s": round(world / med, 2),
+             "ms_per_step_blocks": [round(1e3 * t, 3) for t in times], "loss_last": round(float(last), 3)}
+        if coll:
+            r["exchange_ms_in_step"] = round(max_over_ranks(statistics.median(coll)), 3)
+        return r
+
+    def collective_alone(mode, reps=50):
+        for _ in range(5):
+            bucket.allreduce_gradients(mode)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            bucket.allreduce_gradients(mode)
+        torch.cuda.synchronize()
+        return round(1e3 * max_over_ranks((time.perf_counter() - t0) / reps), 4)
+
+    rec = {"workload": f"BlendedMVS-shaped data-parallel training step {TRAIN_W}x{TRAIN_H}, {TRAIN_V} views, batch 1 per rank = global batch "
+                       f"{world} (BASELINE configs[2]): forward + masked smooth-L1 loss + backward + ONE flat-bucket gradient exchange "
+                       f"({bucket.flat.numel()} fp32 = {bucket.flat.numel() * 4 / 1e6:.2f} MB) + Adam on every rank; synthetic tensors, seeded weights",
+           "n_gpus": world, "backend": ("rccl" if on_gpu else dist.get_backend()), "steps": steps, "blocks": blocks, "dtype": "f32",
+           "scaling": "weak", "timing": "per block: barrier + synchronize, K steps, synchronize + barrier; max over ranks; median block"}
+    rec["allreduce"] = timed("allreduce")
+    rec["allreduce"]["collective_alone_ms"] = collective_alone("allreduce")
+    rec["samples_per_s"] = rec["allreduce"]["samples_per_s"]
+    rec["ms_per_step"] = rec["allreduce"]["ms_per_step"]
+    rec["no_exchange"] = timed(None)
+    try:
+        rec["direct"] = timed("direct")
+        rec["direct"]["collective_alone_ms"] = collective_alone("direct")
+    except Exception as e:      # noqa: BLE001  (a backend without all_to_all on device tensors: reported, the default figure stands)
+        rec["direct"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+    return rec
+
+
 def cpu_baseline(timed_views=3):
     """Oracle (CPU port of the reference algorithm) on the host cores; bounded sample of the same workload: BASELINE.md
     section 3's protocol -- 1 full-size warm-up view + 3 timed full-size views, median."""
@@ -486,7 +733,10 @@ def main():
                          "MEDIAN block is reported, all of them under `blocks_ms_per_step`")
     ap.add_argument("--rank-timeout", type=float, default=1500.0,
                     help="self-launched multi-rank runs (plain `python bench.py --gpus N`): seconds after which all ranks are stopped")
-    ap.add_argument("--no-training", action="store_true", help="skip the BASELINE configs[2] training-step block (rank 0, N=1)")
+    ap.add_argument("--no-training", action="store_true", help="skip the BASELINE configs[2] training-step block (N=1: one GPU's step; "
+                                                               "N>1: the data-parallel step with the gradient exchange, all ranks)")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the cfg4 (1920x1056, 7 / 11 views) and cfg5_scan (49-view scan + "
+                                                                    "consistency filter) blocks (rank 0, N=1)")
     ap.add_argument("--train-steps", type=int, default=20)
     ap.add_argument("--train-stock-steps", type=int, default=2, help="steps of the stock PyTorch-ROCm autograd baseline (0 = skip)")
     ap.add_argument("--no-train-graph", action="store_true", help="skip the hipGraph-replayed variant of the training step (a child process)")
@@ -595,10 +845,20 @@ def main():
     kernels, cpu, prof_info, training = None, None, None, None
     if rank == 0 and not args.no_profile:
         kernels, prof_info = profile_pass(model, inputs)
+    extra = {}
+    if rank == 0 and world == 1 and not args.no_extra_configs:
+        torch.cuda.empty_cache()
+        extra["cfg4"] = cfg4_block(dev, args.in_flight)
+        torch.cuda.empty_cache()
+        extra["cfg5_scan"] = cfg5_scan_block(dev, args.in_flight)
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_training:
         training = training_block(dev, args.train_steps, max(1, args.blocks), args.train_stock_steps)
         if not args.no_train_graph:
             training["graph_replay"] = training_graph(args.train_steps, max(1, args.blocks))
+    if world > 1 and not args.no_training:
+        barrier()                      # rank 0's profile pass is over: every rank enters the training leg together
+        training = training_ddp_block(dev, world, rank, args.train_steps, max(1, args.blocks))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
     if rank == 0:
@@ -654,6 +914,7 @@ def main():
             rec["hip_kernels_ms_per_step"] = round(sum(k["ms_per_step"] for k in kernels), 3)
         if training:
             rec["training"] = training
+        rec.update(extra)
         if cpu:
             rec["cpu_baseline"] = cpu
         print(json.dumps(rec), flush=True)

@@ -45,6 +45,10 @@ class GraphedTrainStep:
         if not controlplane.builtin_slots(model):
             raise RuntimeError("GraphedTrainStep needs the builtin slot set (scale_cam, HyposByFit): other slots compute their "
                                "control plane where the recording cannot follow")
+        if warmup < 1:
+            # the weight re-pack launch (train_ops.PackPlan.run) and the per-layer pack caches are keyed on parameter versions: only
+            # after one eager optimizer step does a step START with "the weights have moved", which is what every replay must do
+            raise ValueError("GraphedTrainStep needs warmup >= 1: a step recorded before any optimizer step would never re-pack weights")
         self.model, self.crit, self.bucket, self.opt = model, criterion, bucket, optimizer
         dev = imgs.device
         self.device = dev
@@ -103,6 +107,9 @@ class GraphedTrainStep:
         dev = self.device
         self._upload(*host)                                 # (values for the recording pass: it executes nothing, but the host-side
         torch.cuda.synchronize(dev)                         #  slot code reads the mirrors)
+        from . import train_ops
+        self._pool = train_ops.step_pool(dev)               # its buffer's address is in the recording: not replaced while this
+        self._pool.held_by_recording += 1                   # object lives (ZeroPool.take raises instead)
         self.graph_a = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_a, stream=self.stream):
             self.loss = self._forward_backward()
@@ -113,6 +120,11 @@ class GraphedTrainStep:
             with torch.cuda.graph(self.graph_b, stream=self.stream, pool=self.graph_a.pool()):
                 self.opt.step(hyper=self.hyper)
         torch.cuda.synchronize(dev)
+
+    def __del__(self):
+        pool = self.__dict__.get("_pool")
+        if pool is not None:
+            pool.held_by_recording -= 1
 
     # ---- one step --------------------------------------------------------------------------------------------------------
     def __call__(self, imgs, extrinsics, intrinsics, depth_range, gt):

@@ -36,9 +36,14 @@ class ZeroPool:
     def __init__(self, device, n=16384):
         self.device, self.n = device, n
         self.buf, self.off = torch.zeros(n, device=device, dtype=torch.float64), 0
+        self.held_by_recording = 0          # graphstep: number of live hipGraph recordings that hold self.buf's address
 
     def take(self, k):
         if self.off + k > self.n:
+            if self.held_by_recording:
+                # replacing the buffer would free memory every replay still fills and accumulates into
+                raise RuntimeError("the step's reduction pool overflowed while a recorded training step holds its buffer: call "
+                                   "slots outside a training step with their own ZeroPool, or enlarge train_ops.step_pool")
             self.buf, self.off = torch.zeros(max(self.n, k), device=self.device, dtype=torch.float64), 0
         v = self.buf[self.off:self.off + k]
         self.off += k
@@ -157,9 +162,23 @@ def _flush_wgrad_sums(dev_index):
     sum_wgrad_jobs(jobs)
 
 
+def drop_stale_wgrad_sums(dev_index=None):
+    """A backward pass that raised (out of memory, a user interrupt) never ran the engine's final callback: its pending jobs hold
+    addresses of tensors that are gone.  They are dropped -- never flushed -- at the start of the next step (prepack) so that the
+    next pass queues a fresh callback and nothing is summed into freed memory."""
+    if dev_index is None:
+        _PENDING_SUMS.clear()
+    else:
+        _PENDING_SUMS.pop(dev_index, None)
+
+
 def _sum_later(work, dw, nslab, n, param):
     dev = dw.device.index
-    defer = (DEFER_WGRAD_SUMS and param is not None and param.grad is None
+    # deferred only when AccumulateGrad is certain to TAKE the returned tensor over: a trainable dense parameter without a
+    # gradient yet and without tensor hooks (a frozen weight's dw is dropped and its block re-used within the same backward pass; a
+    # hooked or already-populated .grad gets a clone or a sum of the unfinished tensor) -- ADVICE r03
+    defer = (DEFER_WGRAD_SUMS and param is not None and param.requires_grad and param.grad is None
+             and not getattr(param, "_backward_hooks", None) and not getattr(param, "_post_accumulate_grad_hooks", None)
              and getattr(torch._C, "_current_graph_task_id", lambda: -1)() != -1)
     ent = _PENDING_SUMS.get(dev)
     if ent is None:
@@ -804,6 +823,7 @@ def prepack(model):
         plan = model.__dict__["_mdf_pack_plan"] = PackPlan(model)
     plan.run()
     step_pool(plan.device).reset()
+    drop_stale_wgrad_sums(plan.device.index)
 
 
 # --------------------------------------------------------------------------- FPN heads (1x1 convs + top-down adds) in training mode

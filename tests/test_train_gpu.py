@@ -426,6 +426,49 @@ def test_regulariser_training_forward_backward(stage, weights, seeded_sd):
     print(f"stage {stage}: worst parameter-gradient L2 error vs float64 {worst:.2e}")
 
 
+def test_frozen_or_hooked_weight_does_not_take_the_deferred_sum_route(seeded_sd):
+    """the deferred weight-gradient sum keeps only the ADDRESS of dw.  For a frozen conv weight autograd drops the returned
+    tensor (its block is re-used within the same backward pass), for a hooked parameter AccumulateGrad clones it: both must be summed
+    at once.  One layer frozen + one hooked: every other gradient equals the all-trainable run's, the hooked one is complete, and a
+    backward pass that raised leaves no pending job behind for the next step."""
+    import copy
+    from mdfnet_hip import train_ops
+    torch.manual_seed(5)
+    m = build_model()
+    m.load_state_dict(seeded_sd)
+    base = copy.deepcopy(m.Regular[1]).to(DEV).train()
+    test = copy.deepcopy(m.Regular[1]).to(DEV).train()
+    g, d, h, w = 16, 24, 24, 40
+    cost = torch.rand(1, g, d, h, w, device=DEV)
+    hyp = (425 + 510 * torch.rand(1, 1, h, w, device=DEV)) + torch.linspace(-20, 20, d, device=DEV).reshape(1, d, 1, 1)
+    dd = torch.randn(1, h, w, device=DEV)
+    names = [k for k, p in test.named_parameters() if p.dim() == 5]
+    frozen, hooked = names[2], names[4]
+    params = dict(test.named_parameters())
+    params[frozen].requires_grad_(False)
+    seen = {}
+    params[hooked].register_hook(lambda gr: seen.__setitem__("hook", gr.clone()))
+    for reg in (base, test):
+        c = cost.clone().requires_grad_(True)
+        _, depth = reg(c, hyp)
+        depth.backward(dd)
+        reg.dcost = c.grad
+    torch.cuda.synchronize()
+    assert not train_ops._PENDING_SUMS
+    assert params[frozen].grad is None
+    for (k, pb), (_, pt) in zip(base.named_parameters(), test.named_parameters()):
+        if k == frozen:
+            continue
+        assert pt.grad is not None and torch.isfinite(pt.grad).all(), k
+        assert _l2(pt.grad, pb.grad) < 2e-5, (k, _l2(pt.grad, pb.grad))
+    assert _l2(seen["hook"], dict(base.named_parameters())[hooked].grad) < 2e-5        # complete when the hook saw it
+    assert _l2(test.dcost, base.dcost) < 2e-5
+    # stale jobs of a pass that never reached the engine's callback are dropped, not flushed
+    train_ops._PENDING_SUMS[0] = [[], [("stale",)]]
+    train_ops.drop_stale_wgrad_sums(0)
+    assert not train_ops._PENDING_SUMS
+
+
 # ----------------------------------------------------------------------------------------------- whole model
 def _step(m, dev, g):
     from net.loss import Loss
