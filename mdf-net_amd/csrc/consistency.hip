@@ -22,13 +22,15 @@ struct ViewMats {   // per source view, row-major
 };
 static_assert(sizeof(ViewMats) == 68 * sizeof(float), "ViewMats layout");
 
-__device__ __forceinline__ void mm3(const float* __restrict__ m, float x0, float x1, float x2, float& o0, float& o1, float& o2) {
+template <typename P>   // P: pointer to the nine floats (constant address space in the kernel: scalar loads)
+__device__ __forceinline__ void mm3(P m, float x0, float x1, float x2, float& o0, float& o1, float& o2) {
   o0 = __fmaf_rn(m[2], x2, __fmaf_rn(m[1], x1, __fmul_rn(m[0], x0)));
   o1 = __fmaf_rn(m[5], x2, __fmaf_rn(m[4], x1, __fmul_rn(m[3], x0)));
   o2 = __fmaf_rn(m[8], x2, __fmaf_rn(m[7], x1, __fmul_rn(m[6], x0)));
 }
 // rows 0..2 of a 4x4 times [x0,x1,x2,1]
-__device__ __forceinline__ void mm4(const float* __restrict__ m, float x0, float x1, float x2, float& o0, float& o1, float& o2) {
+template <typename P>
+__device__ __forceinline__ void mm4(P m, float x0, float x1, float x2, float& o0, float& o1, float& o2) {
   o0 = __fmaf_rn(m[3], 1.0f, __fmaf_rn(m[2], x2, __fmaf_rn(m[1], x1, __fmul_rn(m[0], x0))));
   o1 = __fmaf_rn(m[7], 1.0f, __fmaf_rn(m[6], x2, __fmaf_rn(m[5], x1, __fmul_rn(m[4], x0))));
   o2 = __fmaf_rn(m[11], 1.0f, __fmaf_rn(m[10], x2, __fmaf_rn(m[9], x1, __fmul_rn(m[8], x0))));
@@ -48,6 +50,53 @@ struct FuseParams {
   int n_src, h, w, nconditions;
 };
 
+// Uniform (per-view) data is read through the CONSTANT address space: the matrices live in a device buffer the kernel never
+// writes, but behind a plain pointer the compiler cannot know that and fetched all 68 floats per view with 14 vector loads per
+// lane -- 14 KB through the texture path per wave and view, which (not HBM, not the ALUs) was what the kernel waited for.  As
+// addrspace(4) loads with a uniform address they are s_load_dwordx16 into SGPRs.
+typedef const __attribute__((address_space(4))) float* cfloat_p;
+
+struct Taps {                 // stage A of one source view: where the reference pixel lands + the four source depths around it
+  float xs, ys;               // source pixel coordinates (:214)
+  float w_nw, w_ne, w_sw, w_se;
+  float l_nw, l_ne, l_sw, l_se;
+  bool in_nw, in_ne, in_sw, in_se;   // tap inside the map (carried over the loop edge as lane masks in SGPRs, not as data)
+};
+
+__device__ __forceinline__ Taps project(cfloat_p M, const float* __restrict__ ds, float xf, float yf, float d, float mw, float mh,
+                                        float half_w, float half_h, int w) {
+  Taps t;
+  // reference pixel -> reference camera -> source camera -> source pixel      (:205-214)
+  float c0, c1, c2, s0, s1, s2, q0, q1, q2;
+  mm3(M + 0, __fmul_rn(xf, d), __fmul_rn(yf, d), d, c0, c1, c2);
+  mm4(M + 9, c0, c1, c2, s0, s1, s2);
+  mm3(M + 25, s0, s1, s2, q0, q1, q2);
+  t.xs = __fdiv_rn(q0, q2);
+  t.ys = __fdiv_rn(q1, q2);
+  // bilinear_sampler (data_io.py:117-131): pixel coords -> [-1,1] -> grid_sample(align_corners=True, zeros)
+  const float gx = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, t.xs), mw), 1.0f);
+  const float gy = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, t.ys), mh), 1.0f);
+  const float ix = __fmul_rn(__fadd_rn(gx, 1.0f), half_w);
+  const float iy = __fmul_rn(__fadd_rn(gy, 1.0f), half_h);
+  const float x0f = floorf(ix), y0f = floorf(iy);
+  const float fw = __fsub_rn(ix, x0f), fe = __fsub_rn(1.0f, fw), fn = __fsub_rn(iy, y0f), fs = __fsub_rn(1.0f, fn);
+  const float x1f = x0f + 1.0f, y1f = y0f + 1.0f;
+  const bool bx0 = (x0f >= 0.f) && (x0f <= mw), bx1 = (x1f >= 0.f) && (x1f <= mw);
+  const bool by0 = (y0f >= 0.f) && (y0f <= mh), by1 = (y1f >= 0.f) && (y1f <= mh);
+  t.in_nw = bx0 && by0; t.in_ne = bx1 && by0; t.in_sw = bx0 && by1; t.in_se = bx1 && by1;
+  const int xa = (int)fminf(fmaxf(x0f, 0.f), mw), xb = (int)fminf(fmaxf(x1f, 0.f), mw);
+  const int ya = (int)fminf(fmaxf(y0f, 0.f), mh), yb = (int)fminf(fmaxf(y1f, 0.f), mh);
+  t.w_nw = __fmul_rn(fs, fe); t.w_ne = __fmul_rn(fs, fw); t.w_sw = __fmul_rn(fn, fe); t.w_se = __fmul_rn(fn, fw);
+  // the four taps are loaded unconditionally (the corners are clamped into the map) and out-of-bounds ones replaced by 0 by the
+  // consumer; 32-bit offsets from the map's (uniform) base
+  const unsigned ra = (unsigned)(ya * w), rb = (unsigned)(yb * w);      // (clamped: 0 <= index < h*w < 2^31)
+  t.l_nw = ds[ra + (unsigned)xa]; t.l_ne = ds[ra + (unsigned)xb]; t.l_sw = ds[rb + (unsigned)xa]; t.l_se = ds[rb + (unsigned)xb];
+  return t;
+}
+
+// One thread owns a reference pixel and walks the source views in a two-stage software pipeline: the projection of view v + 1 and
+// its four gathers are issued BEFORE the back-projection / divide chain of view v, so a gather's latency is covered by ~150
+// vector instructions of the same wave instead of by other waves only.
 __global__ __launch_bounds__(256) void consistency_fuse_kernel(const FuseParams p) {
   const int hw = p.h * p.w;
   const int pix = blockIdx.x * blockDim.x + threadIdx.x;
@@ -55,69 +104,57 @@ __global__ __launch_bounds__(256) void consistency_fuse_kernel(const FuseParams 
   const int yi = pix / p.w, xi = pix - yi * p.w;
   const float xf = (float)xi, yf = (float)yi;
   const float d = p.depth_ref[pix];
-  float cnt[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) cnt[i] = 0.f;
+  // The nine masks of a view are nested: thr_dist[i] and thr_rel[i] grow with i, so mask i implies mask i + 1 and a view is
+  // described by k = the first index whose mask holds (9 = none; a NaN compares false everywhere, as in torch).  hist packs the
+  // ten possible k into 5-bit bins (n_src <= 16): cnt[i] of the reference code = views with k <= i.
+  unsigned long long hist = 0ull;
   int nvalid = 0;
   float acc = 0.f;
   const float mw = (float)(p.w - 1), mh = (float)(p.h - 1);
+  const cfloat_p mats = (cfloat_p)(const float*)p.mats;
+  Taps cur = project(mats, p.src[0], xf, yf, d, mw, mh, p.half_w, p.half_h, p.w);
   for (int v = 0; v < p.n_src; ++v) {
-    const ViewMats& M = p.mats[v];
-    // reference pixel -> reference camera -> source camera -> source pixel      (:205-214)
-    float c0, c1, c2, s0, s1, s2, q0, q1, q2;
-    mm3(M.kr_inv, __fmul_rn(xf, d), __fmul_rn(yf, d), d, c0, c1, c2);
-    mm4(M.t_rs, c0, c1, c2, s0, s1, s2);
-    mm3(M.k_s, s0, s1, s2, q0, q1, q2);
-    const float xs = __fdiv_rn(q0, q2), ys = __fdiv_rn(q1, q2);
-    // bilinear_sampler (data_io.py:117-131): pixel coords -> [-1,1] -> grid_sample(align_corners=True, zeros)
-    const float gx = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, xs), mw), 1.0f);
-    const float gy = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, ys), mh), 1.0f);
-    const float ix = __fmul_rn(__fadd_rn(gx, 1.0f), p.half_w);
-    const float iy = __fmul_rn(__fadd_rn(gy, 1.0f), p.half_h);
-    const float x0f = floorf(ix), y0f = floorf(iy);
-    const float fw = __fsub_rn(ix, x0f), fe = __fsub_rn(1.0f, fw), fn = __fsub_rn(iy, y0f), fs = __fsub_rn(1.0f, fn);
-    const float x1f = x0f + 1.0f, y1f = y0f + 1.0f;
-    const bool bx0 = (x0f >= 0.f) && (x0f <= mw), bx1 = (x1f >= 0.f) && (x1f <= mw);
-    const bool by0 = (y0f >= 0.f) && (y0f <= mh), by1 = (y1f >= 0.f) && (y1f <= mh);
-    const int xa = (int)fminf(fmaxf(x0f, 0.f), mw), xb = (int)fminf(fmaxf(x1f, 0.f), mw);
-    const int ya = (int)fminf(fmaxf(y0f, 0.f), mh), yb = (int)fminf(fmaxf(y1f, 0.f), mh);
-    const float* ds = p.src[v];
-    // the four taps are loaded unconditionally (the corners are clamped into the map) and out-of-bounds ones replaced by 0
-    // afterwards; the empty asm pins the loads -- with a bare select the compiler sinks each load under its condition, i.e.
-    // four branch + wait pairs per view in a dependent chain
-    float l_nw = ds[ya * p.w + xa], l_ne = ds[ya * p.w + xb], l_sw = ds[yb * p.w + xa], l_se = ds[yb * p.w + xb];
-    asm volatile("" : "+v"(l_nw), "+v"(l_ne), "+v"(l_sw), "+v"(l_se));
-    const float t_nw = (bx0 && by0) ? l_nw : 0.f, t_ne = (bx1 && by0) ? l_ne : 0.f;
-    const float t_sw = (bx0 && by1) ? l_sw : 0.f, t_se = (bx1 && by1) ? l_se : 0.f;
-    const float samp = __fmaf_rn(t_se, __fmul_rn(fn, fw), __fmaf_rn(t_sw, __fmul_rn(fn, fe),
-                       __fmaf_rn(t_ne, __fmul_rn(fs, fw), __fmul_rn(t_nw, __fmul_rn(fs, fe)))));
+    const cfloat_p M = mats + 68 * v;
+    Taps nxt = cur;
+    if (v + 1 < p.n_src) nxt = project(M + 68, p.src[v + 1], xf, yf, d, mw, mh, p.half_w, p.half_h, p.w);
+    // (the empty asm pins the loads: with a bare select the compiler sinks each load under its condition, i.e. four
+    //  branch + wait pairs per view in a dependent chain)
+    asm volatile("" : "+v"(cur.l_nw), "+v"(cur.l_ne), "+v"(cur.l_sw), "+v"(cur.l_se));
+    const float t_nw = cur.in_nw ? cur.l_nw : 0.f, t_ne = cur.in_ne ? cur.l_ne : 0.f;
+    const float t_sw = cur.in_sw ? cur.l_sw : 0.f, t_se = cur.in_se ? cur.l_se : 0.f;
+    const float samp = __fmaf_rn(t_se, cur.w_se, __fmaf_rn(t_sw, cur.w_sw, __fmaf_rn(t_ne, cur.w_ne, __fmul_rn(t_nw, cur.w_nw))));
     // back to the reference view with the SAMPLED source depth                  (:226-236)
     float b0, b1, b2, r0, r1, r2, u0, u1, u2;
-    mm3(M.ks_inv, __fmul_rn(xs, samp), __fmul_rn(ys, samp), samp, b0, b1, b2);
-    mm4(M.t_sr, b0, b1, b2, r0, r1, r2);
-    mm3(M.k_r, r0, r1, r2, u0, u1, u2);
+    mm3(M + 34, __fmul_rn(cur.xs, samp), __fmul_rn(cur.ys, samp), samp, b0, b1, b2);
+    mm4(M + 43, b0, b1, b2, r0, r1, r2);
+    mm3(M + 59, r0, r1, r2, u0, u1, u2);
     const float xr = __fdiv_rn(u0, u2), yr = __fdiv_rn(u1, u2);
     // :179-183
     const float dx = __fsub_rn(xr, xf), dy = __fsub_rn(yr, yf);
     const float dist = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
     const float rel = __fdiv_rn(fabsf(__fsub_rn(r2, d)), d);
-    unsigned bits = 0;
+    int kd = 0, kr = 0;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-      const bool m = (dist < p.thr_dist[i]) && (rel < p.thr_rel[i]);   // NaN compares false, as in torch
-      cnt[i] += m ? 1.f : 0.f;
-      bits |= (m ? 1u : 0u) << i;
+      kd += (dist < p.thr_dist[i]) ? 0 : 1;                             // NaN compares false, as in torch
+      kr += (rel < p.thr_rel[i]) ? 0 : 1;
     }
-    const bool last = (bits >> 8) & 1u;
+    const int k = kd > kr ? kd : kr;                                    // masks k .. 8 hold
+    hist += 1ull << (5 * k);
+    const bool last = k <= 8;
     const float rep = last ? r2 : 0.f;                                  // depth_reprojected[~mask] = 0   (:189)
     nvalid += last ? 1 : 0;
     acc = __fadd_rn(acc, rep);
-    if (p.view_masks) p.view_masks[(size_t)v * hw + pix] = (unsigned short)bits;
+    if (p.view_masks) p.view_masks[(size_t)v * hw + pix] = (unsigned short)((0x1FFu << k) & 0x1FFu);
     if (p.rep_out) p.rep_out[(size_t)v * hw + pix] = rep;
+    cur = nxt;
   }
-  int geo = 0;
+  int geo = 0, run = 0;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) geo += (cnt[i] >= (float)(i + 2)) ? 1 : 0;       // :93-94
+  for (int i = 0; i < 9; ++i) {
+    run += (int)((hist >> (5 * i)) & 31ull);                            // = cnt[i]
+    geo += (run >= i + 2) ? 1 : 0;                                      // :93-94
+  }
   p.depth_avg[pix] = __fdiv_rn(__fadd_rn(acc, d), (float)(nvalid + 1));        // :98
   const bool geo_m = geo >= p.nconditions, photo_m = p.conf[pix] > p.photo_threshold;
   p.masks[pix] = photo_m;

@@ -103,14 +103,86 @@ def gen_train(model, sd, ref_loss):
     for i, d in enumerate(out["depth"]):
         tg[f"depth{i}"] = npy(d)
     params = dict(model.named_parameters())
-    for k in ("Backbone.conv01.0.conv.weight", "Homoaggre.0.depth_weight.0.conv.weight",
-              "Homoaggre.2.depth_weight.1.bias", "Regular.2.prob.weight", "Regular.0.conv01.0.conv.weight",
-              "Refine.conv2.2.weight"):
+    for k in TRAIN_GRAD_KEYS:
         tg["grad:" + k] = npy(params[k].grad)
     for k in gt:
         tg["gt" + k] = npy(gt[k])
     np.savez_compressed(os.path.join(OUT, "train_tiny.npz"), **tg)
     print("train loss", float(loss))
+
+
+TRAIN_GRAD_KEYS = ("Backbone.conv01.0.conv.weight", "Homoaggre.0.depth_weight.0.conv.weight", "Homoaggre.2.depth_weight.1.bias",
+                   "Regular.2.prob.weight", "Regular.0.conv01.0.conv.weight", "Refine.conv2.2.weight")
+
+
+def train_f64(sd32, gt):
+    """The training golden's step (same inputs, same weights) through the ORACLE in float64 (oracle.mvs_oracle.precision): loss,
+    the four depth maps and every parameter gradient.  The yardstick of the training-parity tests -- an fp32 implementation is judged
+    by its distance from THIS relative to the reference's own fp32 distance from it -- not a parity target: the
+    reference never computes in float64.  -> (loss, [depth], {name: grad}) as float64 numpy."""
+    sys.path.insert(0, ROOT)
+    from oracle import mvs_oracle as O
+    dt = torch.float64
+    imgs, extr, intr, dr = synth.make_scene(96, 64, 3, batch=2, rot_deg=3.0, seed=31)
+    sd = {k: (v.to(dt).clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k
+              else (v.to(dt) if v.dtype == torch.float32 else v.clone())) for k, v in sd32.items()}
+    with O.precision(dt):
+        out = O.core_forward(sd, imgs.to(dt), extr.to(dt), intr.to(dt), dr.to(dt), training=True)
+        loss = O.mvs_loss(out["depth"], {k: torch.as_tensor(v).to(dt) for k, v in gt.items()}, dr.to(dt))
+    loss.backward()
+    grads = {k: v.grad.numpy() for k, v in sd.items() if getattr(v, "grad", None) is not None}
+    return float(loss), [d.detach().numpy() for d in out["depth"]], grads
+
+
+def fp32_spread(sd32, gt, depths64, grads64, draws=4, metric="l2"):
+    """How far from the float64 result does the reference-class fp32 implementation land?  ONE run is one sample of a noisy quantity:
+    the peaked softmaxes and ReLU / mask decisions make several gradients (all of Regular.2, the Homoaggre weight nets) move by 3-10x
+    their typical error when any rounding changes.  So: the fp32 oracle on the unperturbed inputs and on `draws` copies whose images are
+    moved by one fp32 ulp (relative 2^-23, random sign, torch seeds 0..draws-1), each compared with the float64 result of the
+    UNPERTURBED inputs.  -> (per stage: max mean |d depth|, per tensor: max distance); distance = L2-relative or max-relative."""
+    sys.path.insert(0, ROOT)
+    from oracle import mvs_oracle as O
+    imgs, extr, intr, dr = synth.make_scene(96, 64, 3, batch=2, rot_deg=3.0, seed=31)
+    gtt = {k: torch.as_tensor(v) for k, v in gt.items()}
+
+    def dist(a, r):
+        a, r = np.asarray(a, np.float64), np.asarray(r, np.float64)
+        if metric == "l2":
+            return float(np.linalg.norm(a - r) / max(np.linalg.norm(r), 1e-30))
+        return float(np.abs(a - r).max() / max(np.abs(r).max(), 1e-30))
+    dmax, gmax = [0.0] * 4, {k: 0.0 for k in grads64}
+    for t in range(-1, draws):
+        im = imgs
+        if t >= 0:
+            torch.manual_seed(t)
+            im = imgs * (1.0 + (torch.randint(0, 2, imgs.shape).float() * 2 - 1) * 2.0 ** -23)
+        sd = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v.clone()) for k, v in sd32.items()}
+        out = O.core_forward(sd, im, extr, intr, dr, training=True)
+        O.mvs_loss(out["depth"], gtt, dr).backward()
+        for i, d in enumerate(out["depth"]):
+            dmax[i] = max(dmax[i], float(np.abs(d.detach().numpy() - depths64[i]).mean()))
+        for k in gmax:
+            gmax[k] = max(gmax[k], dist(sd[k].grad.numpy(), grads64[k]))
+    return dmax, gmax
+
+
+def gen_train_f64(sd):
+    g = np.load(os.path.join(OUT, "train_tiny.npz"))
+    loss, depths, grads = train_f64(sd, {k: g["gt" + k] for k in ("3", "2", "1", "0")})
+    tg = {"loss": np.float64(loss)}
+    for i, d in enumerate(depths):
+        tg[f"depth{i}"] = d
+        print(f"depth{i}: reference fp32 golden vs float64: mean |d| {np.abs(g[f'depth{i}'] - d).mean():.3e}")
+    for k in TRAIN_GRAD_KEYS:
+        tg["grad:" + k] = grads[k]
+        print(f"grad:{k}: reference fp32 golden vs float64: max rel {np.abs(g['grad:' + k] - grads[k]).max() / np.abs(grads[k]).max():.2e}")
+    dmax, gmax = fp32_spread(sd, {k: g["gt" + k] for k in ("3", "2", "1", "0")}, depths, {k: grads[k] for k in TRAIN_GRAD_KEYS}, metric="maxrel")
+    for i, v in enumerate(dmax):
+        tg[f"spread:depth{i}"] = np.float64(v)
+    for k, v in gmax.items():
+        tg["spread:grad:" + k] = np.float64(v)
+        print(f"spread:grad:{k}: fp32 oracle, unperturbed + 4 one-ulp draws: max rel distance from float64 up to {v:.2e}")
+    np.savez_compressed(os.path.join(OUT, "train_tiny_f64.npz"), **tg)
 
 
 def gen_io():
@@ -206,6 +278,12 @@ def main():
         return gen_io()
     if "--only-filter" in sys.argv:
         return gen_filter()
+    if "--only-train-f64" in sys.argv:      # needs train_tiny.npz (its ground-truth maps); no reference import: the oracle in float64
+        import contextlib as _c
+        with _c.redirect_stdout(io.StringIO()):
+            import config as own_config
+            shapes = own_config.build_model().state_dict()
+        return gen_train_f64(synth.seeded_state_dict(shapes, seed=1))
     cfg, base, agg, regress, dh, scale, ref_loss = load_reference()
     model = cfg.model
     sd = synth.seeded_state_dict(model.state_dict(), seed=1)
@@ -324,6 +402,7 @@ def main():
     e2e("e2e_5view.npz", 320, 256, 5, 1, 5.0, 21, False)
 
     gen_train(model, sd, ref_loss)
+    gen_train_f64(sd)
     gen_io()
     gen_filter()
     for f in sorted(os.listdir(OUT)):

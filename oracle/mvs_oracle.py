@@ -29,13 +29,33 @@ import torch
 import torch.nn.functional as F
 
 BN_EPS = 1e-5
+# Working precision of every function below: float32 = the reference's arithmetic (what the goldens pin).  `precision(torch.float64)`
+# runs the SAME restatement in float64 -- the yardstick of the training-parity tests (how far is an fp32 implementation from the
+# exact result of this algorithm on these inputs?), never a parity target of its own.
+WORK = torch.float32
+
+
+class precision:
+    """with precision(torch.float64): every cast / constant of the oracle uses that dtype (inputs and weights are the caller's)."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global WORK
+        self.prev, WORK = WORK, self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        global WORK
+        WORK = self.prev
 
 
 # --------------------------------------------------------------------------- helpers
 def _fma(a, b, c):
     """fp32 fused multiply-add emulated through fp64 (product of two f32 is exact in f64;
     the single f64 add + final f32 rounding differs from a true fma only in ~2^-29 of cases)."""
-    return (a.double() * b.double() + c.double()).float()
+    return (a.double() * b.double() + c.double()).to(WORK)
 
 
 def _sub(sd, prefix):
@@ -78,7 +98,7 @@ def homo_warping(src_fea, src_proj, ref_proj, depth_hypos):
     with torch.no_grad():
         proj = relative_projection(src_proj, ref_proj)
         rot, trans = proj[:, :3, :3], proj[:, :3, 3:4]
-        gy, gx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32),
+        gy, gx = torch.meshgrid(torch.arange(h, dtype=WORK), torch.arange(w, dtype=WORK),
                                 indexing="ij")
         pix = torch.stack((gx.reshape(-1), gy.reshape(-1), torch.ones(h * w)))  # [3,hw], integer pixel centres
         rot_xyz = torch.matmul(rot, pix.unsqueeze(0).expand(b, 3, h * w))       # base.py:110
@@ -105,7 +125,7 @@ def warp_positions(proj, depth_hypos, h, w):
       ix = fma(xn + 1, w/2, -0.5)                             (ATen vectorised unnormalise, FMA-contracted)
     """
     b, d = depth_hypos.shape[:2]
-    gy, gx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    gy, gx = torch.meshgrid(torch.arange(h, dtype=WORK), torch.arange(w, dtype=WORK), indexing="ij")
     x, y = gx.reshape(1, -1), gy.reshape(1, -1)
     one = torch.ones_like(x)
     r = proj[:, :3, :3]
@@ -119,10 +139,10 @@ def warp_positions(proj, depth_hypos, h, w):
     px3, py3, pz3 = (rows[i].unsqueeze(1) * dep + t[:, i].reshape(b, 1, 1) for i in range(3))
     px = px3 / pz3
     py = py3 / pz3
-    xn = px / torch.tensor((w - 1) / 2, dtype=torch.float32) - 1
-    yn = py / torch.tensor((h - 1) / 2, dtype=torch.float32) - 1
-    ix = _fma(xn + 1, torch.tensor(w / 2, dtype=torch.float32).expand_as(xn), torch.tensor(-0.5).expand_as(xn))
-    iy = _fma(yn + 1, torch.tensor(h / 2, dtype=torch.float32).expand_as(yn), torch.tensor(-0.5).expand_as(yn))
+    xn = px / torch.tensor((w - 1) / 2, dtype=WORK) - 1
+    yn = py / torch.tensor((h - 1) / 2, dtype=WORK) - 1
+    ix = _fma(xn + 1, torch.tensor(w / 2, dtype=WORK).expand_as(xn), torch.tensor(-0.5).expand_as(xn))
+    iy = _fma(yn + 1, torch.tensor(h / 2, dtype=WORK).expand_as(yn), torch.tensor(-0.5).expand_as(yn))
     return ix, iy
 
 
@@ -274,7 +294,7 @@ def confidence_regress(prob):
     b, d, h, w = prob.shape
     with torch.no_grad():
         win = 4 * F.avg_pool3d(F.pad(prob.unsqueeze(1), (0, 0, 0, 0, 1, 2)), (4, 1, 1), stride=1).squeeze(1)
-        ramp = torch.arange(d, dtype=torch.float32).reshape(1, d, 1, 1).expand(b, d, 1, 1)
+        ramp = torch.arange(d, dtype=WORK).reshape(1, d, 1, 1).expand(b, d, 1, 1)
         idx = depth_regression(prob, ramp).long()
         return torch.gather(win, 1, idx.unsqueeze(1)).squeeze(1)
 
@@ -282,7 +302,7 @@ def confidence_regress(prob):
 def confidence_index(prob):
     """The int64 index used by confidence_regress (regress.py:15-17), exposed for index parity."""
     b, d = prob.shape[:2]
-    ramp = torch.arange(d, dtype=torch.float32).reshape(1, d, 1, 1).expand(b, d, 1, 1)
+    ramp = torch.arange(d, dtype=WORK).reshape(1, d, 1, 1).expand(b, d, 1, 1)
     return depth_regression(prob, ramp).long()
 
 
@@ -290,8 +310,8 @@ def confidence_index(prob):
 def uniform_hypos(depth_range, ndepths):
     """net/unit/depthhypos.py:31-38 -> [B,D,1,1]."""
     b = depth_range.shape[0]
-    dmin = depth_range[:, 0].float().reshape(b, 1, 1, 1)
-    dmax = depth_range[:, 1].float().reshape(b, 1, 1, 1)
+    dmin = depth_range[:, 0].to(WORK).reshape(b, 1, 1, 1)
+    dmax = depth_range[:, 1].to(WORK).reshape(b, 1, 1, 1)
     step = (dmax - dmin) / (ndepths - 1)
     hyp = dmin.unsqueeze(1) + torch.arange(0, ndepths).reshape(1, -1) * step.unsqueeze(1)
     return hyp.reshape(b, ndepths, 1, 1)
@@ -344,7 +364,7 @@ def hypos_by_fit(depth, depth_range, prob, prev_hypos, ndepths, curve, prob_thre
     if depth is None:
         return uniform_hypos(depth_range, ndepths)
     b = depth_range.shape[0]
-    dmin, dmax = depth_range[:, 0].float(), depth_range[:, 1].float()
+    dmin, dmax = depth_range[:, 0].to(WORK), depth_range[:, 1].to(WORK)
     thr = torch.tensor(prob_thresh)
     with torch.no_grad():
         s = gauss1_fit(prob, prev_hypos) if curve == "gauss1" else laplace_fit(depth, prob, prev_hypos)
@@ -395,8 +415,8 @@ def refine_net2(depth, depth_range, p):
     """net/unit/refine.py:25-46: normalise to [0,1], conv -> 3x Res(x + 0.1*conv(relu(conv(x)))) -> conv,
     skip add, conv -> PixelShuffle(2) -> conv, de-normalise.  [B,h,w] -> [B,2h,2w]."""
     b = depth.shape[0]
-    dmin = depth_range[:, 0].float().reshape(b, 1, 1, 1)
-    dmax = depth_range[:, 1].float().reshape(b, 1, 1, 1)
+    dmin = depth_range[:, 0].to(WORK).reshape(b, 1, 1, 1)
+    dmax = depth_range[:, 1].to(WORK).reshape(b, 1, 1, 1)
     x = (depth.unsqueeze(1).detach() - dmin) / (dmax - dmin)
     x0 = F.conv2d(x, p["conv0.weight"], None, 1, 1)
     y = x0
@@ -428,7 +448,7 @@ def core_forward(sd, imgs, extrinsics, intrinsics, depth_range, training=False,
                  ndepths=(48, 24, 8), ngroups=(32, 16, 8), keep=False, warp=homo_warping):
     """net/core.py:30-78 composed as config.py:186-218 wires it.
     Returns the output dict; with keep=True also every per-stage intermediate."""
-    views = torch.unbind(imgs.float(), 1)
+    views = torch.unbind(imgs.to(WORK), 1)
     bb = _sub(sd, "Backbone.")
     feats = [fpn_4scales(v, bb, training) for v in views]
     depth = hyp = prob = None

@@ -163,3 +163,25 @@ def test_training_forward_backward(golden, seeded_sd):
             ref = g[k]
             got = sd[k[5:]].grad.numpy()
             np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-4 * float(np.abs(ref).max() + 1e-12))
+
+
+def test_float64_yardstick_fixture(golden, seeded_sd):
+    """tests/golden/train_tiny_f64.npz (oracle/gen_golden.py:gen_train_f64): the training golden's step through the oracle in
+    float64 is reproduced here to float64 rounding, the oracle's float32 mode is untouched by the precision switch, and the
+    reference's fp32 golden sits at the recorded ~1.4e-3 mm from it on stage 0 (the yardstick of tests/test_train_gpu.py)."""
+    from oracle import gen_golden
+    g, g64 = golden("train_tiny.npz"), golden("train_tiny_f64.npz")
+    assert O.WORK == torch.float32
+    loss, depths, grads = gen_golden.train_f64(seeded_sd, {k: g["gt" + k] for k in ("3", "2", "1", "0")})
+    assert O.WORK == torch.float32                       # the context manager restored it
+    assert abs(loss - float(g64["loss"])) <= 1e-9 * abs(loss)
+    for i, d in enumerate(depths):
+        assert d.dtype == np.float64 and np.abs(d - g64[f"depth{i}"]).max() < 1e-6      # host BLAS may order float64 sums differently
+        e_ref = np.abs(g[f"depth{i}"] - g64[f"depth{i}"]).mean()
+        assert 2e-4 < e_ref < (5e-3 if i < 3 else 3e-2), (i, e_ref)
+        assert float(g64[f"spread:depth{i}"]) >= e_ref * 0.999
+    for k in gen_golden.TRAIN_GRAD_KEYS:
+        r = g64["grad:" + k]
+        assert np.abs(grads[k] - r).max() <= 1e-6 * np.abs(r).max(), k
+        e_ref = np.abs(g["grad:" + k] - r).max() / np.abs(r).max()
+        assert e_ref < 5e-3 and float(g64["spread:grad:" + k]) >= e_ref * 0.999, (k, e_ref)
