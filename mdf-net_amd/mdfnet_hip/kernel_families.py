@@ -78,3 +78,20 @@ def globals_in_sources(csrc_dir):
         for m in re.finditer(r"__global__\b[\s\S]*?\bvoid\s+([A-Za-z_][A-Za-z_0-9]*)\s*\(", text):
             names.setdefault(m.group(1), f)
     return names
+
+
+def fetch_size_factor(rocprof_name):
+    """FETCH_SIZE (KiB) -> bytes correction on gfx950.  The counter tallies a 128-B request as 64 B, so any access whose lanes form
+    contiguous runs of >= 128 B reads HALF its bytes (streaming 16 B/lane, 128-B and 256-B texel gathers, even a dword walk of a
+    cache line: all measured at 0.500), while 64-B requests are counted exactly (64-B texels, lanes of neighbouring texels on
+    different rows: measured at 1.000) -- scripts/micro/fetch_calib.hip, profiles/r04_fetch_calibration.md.  The only kernels here
+    whose dominant reads are 64-B texels are the aggregation kernels at C = 16 (stage 2: a texel is 16 channels x 4 B): factor 1 for
+    them, 2 for everything else.  (r03 doubled them too and so reported the eval aggregation's reads 1.57x its algorithmic bytes;
+    with the calibrated factor they are 1.05x.)  One factor per kernel is an approximation: the C = 16 kernel's reference map and
+    per-pixel hypotheses ARE streamed (45 of its 167 MB at cfg2), so factor 1 under-counts that kernel's reads by up to 13 %."""
+    fn = function_name(rocprof_name)
+    if fn in ("warp_kernel", "warp_vec8_kernel", "warp_vec_win_kernel", "warp_train_kernel", "warp_bwd_kernel"):
+        m = re.search(fn + r"<\s*(\d+)", rocprof_name)
+        if m and int(m.group(1)) == 16:
+            return 1.0
+    return 2.0

@@ -8,7 +8,7 @@ fetch_dir, write_dir, forwards, out = sys.argv[1], sys.argv[2], int(sys.argv[3])
 
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mdf-net_amd"))
-from mdfnet_hip.kernel_families import family      # noqa: E402  (the one table of kernel -> family; exact names)
+from mdfnet_hip.kernel_families import family, fetch_size_factor      # noqa: E402  (the one table of kernel -> family; exact names)
 
 
 def load(d, counter):
@@ -20,7 +20,9 @@ def load(d, counter):
             continue
         fam = family(r["Kernel_Name"])
         if fam:
-            acc[fam] += float(r["Counter_Value"])
+            # FETCH_SIZE: per-kernel factor (2 = 128-B requests tallied as 64 B; 1 for the 64-B-texel gathers: calibrated, see
+            # kernel_families.fetch_size_factor); WRITE_SIZE is exact
+            acc[fam] += float(r["Counter_Value"]) * (fetch_size_factor(r["Kernel_Name"]) if counter == "FETCH_SIZE" else 1.0)
             n[fam] += 1
     return acc, n
 
@@ -28,10 +30,11 @@ def load(d, counter):
 fe, nf = load(fetch_dir, "FETCH_SIZE")
 wr, nw = load(write_dir, "WRITE_SIZE")
 res = {"method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py; KiB -> bytes; FETCH_SIZE x2 "
-                 "(gfx950 counts 128-B requests as 64 B for wide coalesced reads); per forward = total / forwards",
+                 "(gfx950 counts 128-B requests as 64 B) except x1 for the 64-B-texel gathers of the C = 16 aggregation kernels "
+                 "(calibrated: profiles/r04_fetch_calibration.md); per forward = total / forwards",
        "forwards": forwards, "families": {}}
 for fam in sorted(set(fe) | set(wr)):
-    rd = fe.get(fam, 0.0) * 1024 * 2 / forwards
+    rd = fe.get(fam, 0.0) * 1024 / forwards          # (the gfx950 factor is already applied per kernel in load())
     wt = wr.get(fam, 0.0) * 1024 / forwards
     res["families"][fam] = {"read_bytes_per_forward": rd, "write_bytes_per_forward": wt, "hbm_bytes_per_forward": rd + wt,
                             "launches_per_forward": nf.get(fam, 0) // forwards}
