@@ -63,9 +63,16 @@ def _sub(sd, prefix):
     return {k[n:]: v for k, v in sd.items() if k.startswith(prefix)}
 
 
+BN_TRACE = None      # a list while oracle/train_check.py:bn_trace() is active: (prefix, batch mean, unbiased batch variance) per training-mode call
+
+
 def _bn(x, p, pre, training):
-    """BatchNorm{2,3}d; eval uses running stats, training uses batch stats
-    (running-stat update side effects are not modelled: oracle is functional)."""
+    """BatchNorm{2,3}d; eval uses running stats, training uses batch stats.  The oracle is functional: the running-stat update of
+    nn.BatchNorm is not performed, but the batch statistics it would be made from are recorded in BN_TRACE when that is a list."""
+    if training and BN_TRACE is not None:
+        with torch.no_grad():
+            dims = [0] + list(range(2, x.dim()))
+            BN_TRACE.append((pre, x.mean(dims), x.var(dims, unbiased=True)))
     return F.batch_norm(x, None if training else p[pre + "running_mean"],
                         None if training else p[pre + "running_var"],
                         p[pre + "weight"], p[pre + "bias"], training, 0.1, BN_EPS)

@@ -1,9 +1,11 @@
 """GPU: the TRAINING path on the hand-written kernels (mdfnet_hip/train_ops.py; BASELINE config 3, train.py:36-45).
 
 Checkers: the reference's training golden directly (loss, depths, gradients; host-side values pinned); torch autograd over the
-ORACLE's training forward for all 158 parameter gradients of the whole model; and, per operator, torch's own nn modules
-(Conv / BatchNorm / grid_sample through the slots' CPU training route, mdfnet_hip/stockops.py, itself pinned to the golden by
-tests/test_train_cpu.py) in fp32 and float64.  Tolerances are summation-order level: fp32 sums over 1e5..1e7 voxels."""
+ORACLE's training forward for all 158 parameter gradients of the whole model; and, per slot (aggregation, regulariser, feature
+pyramid, refinement net), autograd over the oracle's functional restatement in fp32 and in float64 (oracle/train_check.py) -- the
+product package's own CPU route (mdfnet_hip/stockops.py) is not a checker here.  Single conv / BatchNorm layers are compared with
+torch's nn modules (third-party L0 arithmetic).  The yardstick throughout is the float64 result: an fp32 implementation is judged by
+its distance from it relative to the fp32 oracle's own (tests/golden/train_tiny_f64.npz for the reference's golden step)."""
 import numpy as np
 import pytest
 import torch
@@ -231,50 +233,45 @@ def test_prob_head_backward(c, d):
 @pytest.mark.parametrize("stage,b,h,w,nviews,per_pixel", [(0, 2, 12, 20, 3, False), (1, 1, 24, 36, 4, True), (2, 1, 32, 48, 5, True)])
 def test_vector_aggregate_training_forward_backward(stage, b, h, w, nviews, per_pixel):
     """Homoaggre[s] in training mode (batch-statistics BatchNorm3d(1) per source-view call, running stats, gradient to
-    reference and source features and to the five head parameters) vs autograd over the stock ops on the CPU."""
+    reference and source features and to the five head parameters) vs autograd over the ORACLE's vector_aggregate (oracle/train_check.py)."""
     from net.unit.homoaggregate import VectorAggregate
     from net.unit.scale import scale_cam
+    from oracle import train_check as TC
     c, g, d = ((64, 32, 48), (32, 16, 24), (16, 8, 8))[stage]
     torch.manual_seed(stage)
     mod = VectorAggregate(g)
     with torch.no_grad():
         for p in mod.parameters():
             p.add_(0.3 * torch.randn_like(p))
-    ref = VectorAggregate(g)
-    ref.load_state_dict(mod.state_dict())
+    sd = {k: v.clone() for k, v in mod.state_dict().items()}
     intr, extr, dr = synth.make_cameras(w * 2 ** (3 - stage), h * 2 ** (3 - stage), nviews, batch=b, rot_deg=2.0, seed=stage + 7)
     rp, sps = scale_cam(intr, extr, stage)
-    feats = [torch.randn(b, c, h, w, requires_grad=True) for _ in range(nviews)]
+    feats = [torch.randn(b, c, h, w) for _ in range(nviews)]
     if per_pixel:
         hyp = (425 + 510 * torch.rand(b, 1, h, w)) + torch.linspace(-20, 20, d).reshape(1, d, 1, 1)
     else:
         hyp = torch.linspace(425, 935, d).reshape(1, d, 1, 1).repeat(b, 1, 1, 1)
-    import copy
-    ref.train()
-    ref64 = copy.deepcopy(ref).double()
-    cost_ref = ref(feats, rp, sps, hyp)                       # CPU tensors in training mode: stock ops + autograd
-    dcost = torch.randn_like(cost_ref)
-    cost_ref.backward(dcost)
-    f64 = [f.detach().double().requires_grad_(True) for f in feats]
-    cost64 = ref64(f64, rp.double(), tuple(s_.double() for s_ in sps), hyp.double())     # float64 yardstick (same sample positions
-    cost64.backward(dcost.double())                                                       #  up to fp64-vs-fp32 rounding of the grid)
-    mod.train().to(DEV)
-    fd = [f.detach().to(DEV).requires_grad_(True) for f in feats]
+    dcost = torch.randn(b, g, d, h, w)
+    r32 = TC.aggregate(sd, g, feats, rp, sps, hyp, dcost, torch.float32)       # the oracle's VectorAggregate, autograd, fp32
+    r64 = TC.aggregate(sd, g, feats, rp, sps, hyp, dcost, torch.float64)       # ... and in float64 (same sample positions up to
+    mod.train().to(DEV)                                                         #     fp64-vs-fp32 rounding of the grid)
+    fd = [f.to(DEV).requires_grad_(True) for f in feats]
     cost = mod(fd, rp.to(DEV), tuple(s.to(DEV) for s in sps), hyp.to(DEV))
-    assert cost.shape == cost_ref.shape and _rel(cost, cost_ref) < 2e-5
+    assert cost.shape == r32["cost"].shape and _rel(cost, r32["cost"]) < 2e-5
     cost.backward(dcost.to(DEV))
-    bn, rbn = mod.depth_weight[0].bn, ref.depth_weight[0].bn
-    assert _rel(bn.running_mean, rbn.running_mean) < 1e-5 and _rel(bn.running_var, rbn.running_var) < 1e-4
-    assert int(bn.num_batches_tracked) == int(rbn.num_batches_tracked) == nviews - 1
-    print(f"\nstage {stage}: cost L2 error vs float64: HIP {_l2(cost, cost64):.1e} | fp32 CPU autograd {_l2(cost_ref, cost64):.1e}; "
-          f"d ref-feature: HIP {_l2(fd[0].grad, f64[0].grad):.1e} | CPU {_l2(feats[0].grad, f64[0].grad):.1e}; "
-          f"d src-feature: HIP {_l2(fd[1].grad, f64[1].grad):.1e} | CPU {_l2(feats[1].grad, f64[1].grad):.1e}")
-    for i, (a, r_) in enumerate(zip(fd, feats)):
-        assert _rel(a.grad, r_.grad) < 2e-4, f"feature {i}"
-    for (k, pa), (_, pr) in zip(mod.named_parameters(), ref.named_parameters()):
+    bn = mod.depth_weight[0].bn
+    want = r32["buffers"]
+    assert _rel(bn.running_mean, want["depth_weight.0.bn.running_mean"]) < 1e-5 and _rel(bn.running_var, want["depth_weight.0.bn.running_var"]) < 1e-4
+    assert int(bn.num_batches_tracked) == int(want["depth_weight.0.bn.num_batches_tracked"]) == nviews - 1
+    print(f"\nstage {stage}: cost L2 error vs float64: HIP {_l2(cost, r64['cost']):.1e} | fp32 oracle {_l2(r32['cost'], r64['cost']):.1e}; "
+          f"d ref-feature: HIP {_l2(fd[0].grad, r64['dfeats'][0]):.1e} | oracle {_l2(r32['dfeats'][0], r64['dfeats'][0]):.1e}; "
+          f"d src-feature: HIP {_l2(fd[1].grad, r64['dfeats'][1]):.1e} | oracle {_l2(r32['dfeats'][1], r64['dfeats'][1]):.1e}")
+    for i, (a_, r_) in enumerate(zip(fd, r32["dfeats"])):
+        assert _rel(a_.grad, r_) < 2e-4, f"feature {i}"
+    for k, pa in mod.named_parameters():
         # the scalar head parameters are sums of ~1e5 signed terms that cancel to ~1e-5 of sum|terms|: fp32 noise of EITHER
-        # side (the CPU autograd reference included) is ~1e-3 of the result
-        assert _rel(pa.grad, pr.grad) < (5e-4 if pa.numel() > 1 else 1e-2), k
+        # side (the fp32 oracle included) is ~1e-3 of the result
+        assert _rel(pa.grad, r32["grads"][k]) < (5e-4 if pa.numel() > 1 else 1e-2), k
 
 
 def _aggregate_case(stage, width, height, nviews, seed, hyp_spread=20.0):
@@ -374,78 +371,72 @@ def test_aggregate_backward_nonfinite_gradient_does_not_fault(stage):
 @pytest.mark.parametrize("stage", [0, 1, 2])
 def test_regulariser_training_forward_backward(stage, weights, seeded_sd):
     """Regular[s] + soft-argmin in training mode: outputs, input gradient, every parameter gradient and the BatchNorm running
-    statistics against the same modules in float64 (torch's nn modules on the CPU: the yardstick), judged by what fp32 itself can do:
-    the fp32 CPU run of the same modules on the same input AND on three copies of the input moved by one fp32 ulp, each compared with
-    the float64 result of the unperturbed input.  The HIP path may be at most 1.5 x as far from float64 as the farthest of those
+    statistics against the ORACLE in float64 (oracle/train_check.py: autograd over oracle.mvs_oracle.regular under precision(f64)),
+    judged by what fp32 itself can do: the fp32 oracle on the same input AND on three copies of the input moved by one fp32 ulp, each
+    compared with the float64 result of the unperturbed input.  The HIP path may be at most 1.5 x as far from float64 as the farthest of those
     fp32 runs -- no floors, no per-configuration factors.
     default_init: torch's default initialisation, a well-conditioned chain.  seeded_peaked: the golden recipe (prob conv scaled up so
     that volumes are peaked): the softmax amplifies rounding anywhere in the 11-layer chain ~1e3x."""
+    from oracle import train_check as TC
     torch.manual_seed(11 + stage)
     m = build_model()
     if weights == "seeded_peaked":
         m.load_state_dict(seeded_sd)
     import copy
-    reg_ref = m.Regular[stage].train()
-    reg64 = copy.deepcopy(reg_ref).double().train()
-    reg = copy.deepcopy(reg_ref).to(DEV)
+    sd = m.Regular[stage].state_dict()
+    reg = copy.deepcopy(m.Regular[stage]).to(DEV).train()
     g, d, h, w = ((32, 48, 12, 20), (16, 24, 24, 40), (8, 8, 48, 56))[stage]
     torch.manual_seed(stage + 3)
     cost = torch.rand(2, g, d, h, w)
     hyp = (425 + 510 * torch.rand(2, 1, h, w)) + torch.linspace(-20, 20, d).reshape(1, d, 1, 1)
     dd = torch.randn(2, h, w)
-    cost64 = cost.double().requires_grad_(True)
-    prob64, depth64 = reg64(cost64, hyp.double())
-    depth64.backward(dd.double())
-    want = {"prob": prob64, "depth": depth64, "dcost": cost64.grad}
-    want.update({k: p.grad for k, p in reg64.named_parameters()})
+    want = TC.regulariser(sd, cost, hyp, dd, torch.float64)            # the oracle in float64: the yardstick
 
-    def errors(prob, depth, dcost, params):
-        e = {"prob": _l2(prob, want["prob"]), "depth": _l2(depth, want["depth"]), "dcost": _l2(dcost, want["dcost"])}
-        e.update({k: _l2(g_, want[k]) for k, g_ in params})
+    def errors(r):
+        e = {k: _l2(r[k], want[k]) for k in ("prob", "depth", "dcost")}
+        e.update({k: _l2(g_, want["grads"][k]) for k, g_ in r["grads"].items()})
         return e
 
-    # fp32 on the CPU: unperturbed (its buffers are the running-statistics reference) + three one-ulp draws
-    spread, first = {}, None
-    for t in range(-1, 3):
-        r = copy.deepcopy(reg_ref).train()
-        c = cost.clone()
+    # the fp32 oracle: unperturbed (its buffers are the running-statistics reference) + eight draws with the input AND the parameters
+    # moved by one fp32 ulp (gen_golden.one_ulp): the error of a gradient is quantised by which near-zero ReLU units flip, and one run
+    # samples one combination (scripts: the stage-0 golden-weight case takes 2.3e-5 / 5.2e-4 / 2.3e-3 on dcost over such draws)
+    from oracle.gen_golden import one_ulp
+    spread, first, cpu = {}, None, None
+    for t in range(-1, 8):
+        c, sdt = cost, sd
         if t >= 0:
-            torch.manual_seed(100 + t)
-            c = c * (1.0 + (torch.randint(0, 2, c.shape).float() * 2 - 1) * 2.0 ** -23)
-        c.requires_grad_(True)
-        pr, de = r(c, hyp)
-        de.backward(dd)
-        e = errors(pr, de, c.grad, [(k, p.grad) for k, p in r.named_parameters()])
+            torch.manual_seed(200 + t)
+            sdt = {k: (v * one_ulp(v.shape) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+            c = cost * one_ulp(cost.shape)
+        r = TC.regulariser(sdt, c, hyp, dd, torch.float32)
+        e = errors(r)
         spread = {k: max(spread.get(k, 0.0), v) for k, v in e.items()}
         if first is None:
-            first, cpu_buffers, cpu_dcost, cpu_grads = e, dict(r.named_buffers()), c.grad, {k: p.grad for k, p in r.named_parameters()}
+            first, cpu = e, r
     cd = cost.to(DEV).requires_grad_(True)
     prob, depth = reg(cd, hyp.to(DEV))
     depth.backward(dd.to(DEV))
-    got = errors(prob, depth, cd.grad, [(k, p.grad) for k, p in reg.named_parameters()])
     assert all(p.grad is not None for p in reg.parameters())
+    got = errors({"prob": prob, "depth": depth, "dcost": cd.grad, "grads": {k: p.grad for k, p in reg.named_parameters()}})
     rows = sorted(((got[k] / max(spread[k], 1e-30), got[k], first[k], spread[k], k) for k in got), reverse=True)
-    print(f"\nstage {stage} {weights}: L2 error vs float64, HIP | fp32 CPU unperturbed | fp32 CPU worst of 4: "
+    print(f"\nstage {stage} {weights}: L2 error vs float64, HIP | fp32 oracle unperturbed | fp32 oracle worst of 9: "
           + ", ".join(f"{k} {got[k]:.1e} | {first[k]:.1e} | {spread[k]:.1e}" for k in ("prob", "depth", "dcost")))
     print(f"   worst HIP / fp32-worst ratios: {[(f'{q:.2f}', f'{a:.1e}', f'{c_:.1e}', k) for q, a, _, c_, k in rows[:4]]}; "
           f"median HIP / fp32-unperturbed {float(np.median([got[k] / max(first[k], 1e-30) for k in got])):.2f}")
-    # Three bars.  (1) typical accuracy: the median tensor is no farther from float64 than 1.5 x the fp32 CPU run (measured 0.06-0.26:
-    # the centred softmax backward of prob_bwd.hip makes the HIP gradients 4-16 x MORE accurate than autograd's fp32).  (2) every
-    # tensor within 1.5 x the fp32 spread, EXCEPT (3) for events that are not rounding: a ReLU whose pre-activation is within rounding
-    # of zero opens in one implementation and not in another, which moves the gradients downstream of it by a fixed amount -- seen on
-    # [0-seeded_peaked]: dcost and conv01 / conv12.0 sit 2.2e-3 .. 4.4e-3 from float64 (fp32 CPU 3-8e-4), the SAME values to three
-    # digits with the BatchNorm sums fused or separate, weight-gradient sums deferred or not, softmax backward centred or straight,
-    # while the other 28 tensors are at 0.06 x the CPU's error.  Such tensors may be at most a quarter of the set and within 10 x.
+    # Bars: (1) typical accuracy -- the median tensor is no farther from float64 than 1.5 x the unperturbed fp32 oracle (measured
+    # 0.06-0.26: the centred softmax backward of prob_bwd.hip makes the HIP gradients 4-16 x MORE accurate than fp32 autograd);
+    # (2) every tensor within 1.5 x the fp32 spread.  Should the HIP path hit a combination of ReLU flips none of the nine fp32 runs
+    # hit, (2) is relaxed to: at most a quarter of the tensors beyond, none beyond 10 x (a wrong kernel is off by orders of magnitude).
     bad = [(k, a, c_) for q, a, _, c_, k in rows if q > 1.5]
     print(f"   tensors beyond 1.5 x the fp32 spread: {len(bad)} of {len(rows)}")
     assert len(bad) <= len(rows) // 4, bad
     assert rows[0][0] <= 10.0, rows[:3]
     assert float(np.median([got[k] / max(first[k], 1e-30) for k in got])) <= 1.5
-    assert _l2(cd.grad, cpu_dcost) < 1e-2
+    assert _l2(cd.grad, cpu["dcost"]) < 1e-2
     for k, pa in reg.named_parameters():
-        assert _l2(pa.grad, cpu_grads[k]) < 2e-2, (k, _l2(pa.grad, cpu_grads[k]))
-    for k, ba in reg.named_buffers():
-        assert _rel(ba.float(), cpu_buffers[k].float()) < 1e-4, k
+        assert _l2(pa.grad, cpu["grads"][k]) < 2e-2, (k, _l2(pa.grad, cpu["grads"][k]))
+    for k, ba in reg.named_buffers():                       # running statistics: nn.BatchNorm's update from the oracle's batch statistics
+        assert _rel(ba.float(), cpu["buffers"][k].float()) < 1e-4, k
 
 
 def test_frozen_or_hooked_weight_does_not_take_the_deferred_sum_route(seeded_sd):
@@ -555,7 +546,7 @@ def test_training_step_on_gpu_vs_reference_golden(golden, seeded_sd):
         rel = np.abs(mine - g["grad:" + k]).max() / np.abs(g["grad:" + k]).max()
         print(f"grad:{k}: max rel err vs float64: HIP {e_hip:.2e}, reference fp32 {e_ref:.2e} (ratio {e_hip / e_ref:.2f}); HIP vs reference fp32 {rel:.2e}")
         # the reference's run is ONE sample of a noisy quantity (peaked softmaxes, ReLU and mask decisions): `spread` is the farthest
-        # the fp32 oracle lands from float64 over the unperturbed inputs and four one-ulp draws of the images (gen_golden.fp32_spread)
+        # the fp32 oracle lands from float64 over the unperturbed inputs and six one-ulp draws of images and parameters (gen_golden.fp32_spread)
         spread = max(e_ref, float(g64["spread:grad:" + k]))
         ratios.append(e_hip / e_ref)
         fails += [(k, e_hip, e_ref, spread)] if e_hip > 1.5 * spread else []
@@ -606,10 +597,10 @@ def test_all_parameter_gradients_vs_the_oracle(golden, seeded_sd):
         e_ref = np.abs(b.detach().numpy() - d64[i]).mean()
         print(f"depth{i}: mean |d| vs float64: HIP {e_hip:.3e}, fp32 oracle {e_ref:.3e} (ratio {e_hip / e_ref:.2f})")
         assert e_hip <= 1.5 * e_ref, (i, e_hip, e_ref)
-    # per tensor: (a) never farther from float64 than 1.5 x the farthest fp32-oracle run (unperturbed + four one-ulp draws of the
-    # images, this host: gen_golden.fp32_spread) -- several gradients are discontinuous at rounding level, one fp32 run is one sample;
+    # per tensor: (a) never farther from float64 than 1.5 x the farthest fp32-oracle run (unperturbed + six one-ulp draws of the
+    # images and parameters, this host: gen_golden.fp32_spread) -- several gradients are discontinuous at rounding level, one fp32 run is one sample;
     # (b) typically as close as the fp32 oracle: median of e_hip / e_oracle <= 1.5 over the 158 tensors
-    _, spread = gen_golden.fp32_spread(seeded_sd, {k: g["gt" + k] for k in ("3", "2", "1", "0")}, d64, g64, draws=4, metric="l2")
+    _, spread = gen_golden.fp32_spread(seeded_sd, {k: g["gt" + k] for k in ("3", "2", "1", "0")}, d64, g64, draws=6, metric="l2")
     rows = []
     for k, pa in m.named_parameters():
         assert sd[k].grad is not None, k
@@ -676,60 +667,61 @@ def test_conv2d_input_and_weight_gradients(cin, cout, k, stride):
 
 def test_feature_pyramid_training_forward_backward():
     """FPN_4Scales in training mode, 3 views x batch 2 in one pass with per-view BatchNorm statistics: outputs, every
-    parameter gradient and the running statistics vs V separate calls of the stock modules on the CPU (fp32) and in float64."""
-    import copy
+    parameter gradient and the running statistics vs V separate calls of the ORACLE's fpn_4scales in fp32 and in float64
+    (oracle/train_check.py); the HIP path may be at most 1.5 x as far from float64 as the fp32 oracle."""
     from net.unit.backbone import FPN_4Scales
+    from oracle import train_check as TC
     torch.manual_seed(5)
-    ref = FPN_4Scales().train()
-    ref64 = copy.deepcopy(ref).double()
-    mod = copy.deepcopy(ref).to(DEV)
+    mod = FPN_4Scales().train()
+    sd = {k: v.clone() for k, v in mod.state_dict().items()}
+    mod = mod.to(DEV)
     b, v, h, w = 2, 3, 64, 96
     imgs = torch.rand(b, v, 3, h, w)
-    outs_ref = [ref(imgs[:, i]) for i in range(v)]
-    gouts = [[torch.randn_like(t) for t in o] for o in outs_ref]
-    sum((t * g).sum() for o, go in zip(outs_ref, gouts) for t, g in zip(o, go)).backward()
-    outs64 = [ref64(imgs[:, i].double()) for i in range(v)]
-    sum((t * g.double()).sum() for o, go in zip(outs64, gouts) for t, g in zip(o, go)).backward()
+    gouts = [[torch.randn(b, cc, h >> k, w >> k) for cc, k in ((64, 3), (32, 2), (16, 1))] for _ in range(v)]
+    r32 = TC.pyramid(sd, imgs, gouts, torch.float32)
+    r64 = TC.pyramid(sd, imgs, gouts, torch.float64)
     outs = mod.forward_views(imgs.to(DEV))
     sum((t * g.to(DEV)).sum() for o, go in zip(outs, gouts) for t, g in zip(o, go)).backward()
     for i in range(v):
-        for a, r_, r64 in zip(outs[i], outs_ref[i], outs64[i]):
-            assert a.shape == r_.shape and _l2(a, r64) <= max(3 * _l2(r_, r64), 2e-6)
-    worst = 0.0
-    for (k, pa), (_, pr), (_, p64) in zip(mod.named_parameters(), ref.named_parameters(), ref64.named_parameters()):
+        for a_, r_, r64_ in zip(outs[i], r32["outs"][i], r64["outs"][i]):
+            assert a_.shape == r_.shape and _l2(a_, r64_) <= 1.5 * _l2(r_, r64_), (i, _l2(a_, r64_), _l2(r_, r64_))
+    rows = []
+    for k, pa in mod.named_parameters():
         assert pa.grad is not None, k
-        e_hip, e_cpu = _l2(pa.grad, p64.grad), _l2(pr.grad, p64.grad)
-        worst = max(worst, e_hip)
-        assert e_hip <= max(3 * e_cpu, 2e-5), (k, e_hip, e_cpu)
-    for (k, ba), (_, br) in zip(mod.named_buffers(), ref.named_buffers()):
-        assert _rel(ba.float(), br.float()) < 1e-4, k
-    print(f"\nfeature pyramid: worst parameter-gradient L2 error vs float64 {worst:.2e}")
+        rows.append((_l2(pa.grad, r64["grads"][k]), _l2(r32["grads"][k], r64["grads"][k]), k))
+    ratios = sorted(((eh / max(ec, 1e-30), eh, ec, k) for eh, ec, k in rows), reverse=True)
+    print(f"\nfeature pyramid: parameter gradients, L2 error vs float64: worst HIP / fp32 oracle {[(f'{q:.2f}', f'{eh:.1e}', f'{ec:.1e}', k) for q, eh, ec, k in ratios[:4]]}; "
+          f"median ratio {float(np.median([q for q, *_ in ratios])):.2f}")
+    assert ratios[0][0] <= 1.5, ratios[:4]
+    for k, ba in mod.named_buffers():
+        assert _rel(ba.float(), r32["buffers"][k].float()) < 1e-4, k
 
 
 def test_refine_net_training_forward_backward():
-    """RefineNet2 in training mode (no BatchNorm; detached input): output and every weight gradient vs the stock modules on the
-    CPU (fp32) and in float64."""
-    import copy
+    """RefineNet2 in training mode (no BatchNorm; detached input): output and every weight gradient vs the ORACLE's refine_net2 in
+    fp32 and in float64 (oracle/train_check.py); at most 1.5 x as far from float64 as the fp32 oracle."""
     from net.unit.refine import RefineNet2
+    from oracle import train_check as TC
     torch.manual_seed(9)
-    ref = RefineNet2().train()
-    ref64 = copy.deepcopy(ref).double()
-    mod = copy.deepcopy(ref).to(DEV)
+    mod = RefineNet2().train()
+    sd = {k: v.clone() for k, v in mod.state_dict().items()}
+    mod = mod.to(DEV)
     b, h, w = 2, 48, 72
     depth = 425 + 510 * torch.rand(b, h, w)
     dr = torch.tensor([[425.0, 935.0], [425.0, 935.0]], dtype=torch.float64)
     gout = torch.randn(b, 2 * h, 2 * w)
-    out_ref = ref(depth, dr)
-    (out_ref * gout).sum().backward()
-    out64 = ref64(depth.double(), dr)
-    (out64 * gout.double()).sum().backward()
+    r32 = TC.refine(sd, depth, dr, gout, torch.float32)
+    r64 = TC.refine(sd, depth, dr, gout, torch.float64)
     out = mod(depth.to(DEV), dr.to(DEV))
     (out * gout.to(DEV)).sum().backward()
-    assert out.shape == out_ref.shape and _l2(out, out64) <= max(3 * _l2(out_ref, out64), 1e-6)
-    for (k, pa), (_, pr), (_, p64) in zip(mod.named_parameters(), ref.named_parameters(), ref64.named_parameters()):
+    assert out.shape == r32["out"].shape and _l2(out, r64["out"]) <= 1.5 * _l2(r32["out"], r64["out"])
+    worst = 0.0
+    for k, pa in mod.named_parameters():
         assert pa.grad is not None, k
-        e_hip, e_cpu = _l2(pa.grad, p64.grad), _l2(pr.grad, p64.grad)
-        assert e_hip <= max(3 * e_cpu, 2e-5), (k, e_hip, e_cpu)
+        e_hip, e_cpu = _l2(pa.grad, r64["grads"][k]), _l2(r32["grads"][k], r64["grads"][k])
+        worst = max(worst, e_hip / max(e_cpu, 1e-30))
+        assert e_hip <= 1.5 * e_cpu, (k, e_hip, e_cpu)
+    print(f"\nrefine net: worst HIP / fp32 oracle distance from float64 over the parameter gradients: {worst:.2f}")
 
 
 def test_batched_weight_packing_equals_the_per_layer_packs(seeded_sd):
