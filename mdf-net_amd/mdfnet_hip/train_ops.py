@@ -156,7 +156,7 @@ def _flush_wgrad_sums(dev_index):
         return
     streams, jobs = ent
     cur = torch.cuda.current_stream(torch.device("cuda", dev_index))
-    for st in streams:          # partial tiles may have been launched on other streams (a stream per stage, layers.STAGE_STREAMS): join them
+    for st in streams:          # partial tiles may have been launched on other streams: join them
         if st != cur:
             cur.wait_stream(st)
     sum_wgrad_jobs(jobs)
@@ -172,14 +172,24 @@ def drop_stale_wgrad_sums(dev_index=None):
         _PENDING_SUMS.pop(dev_index, None)
 
 
+def _can_defer(param):
+    """True when the sum of a weight gradient's partial tiles may wait for the end of the backward pass (see _sum_later)."""
+    return (DEFER_WGRAD_SUMS and param is not None and param.requires_grad and param.grad is None
+            and not getattr(param, "_backward_hooks", None) and not getattr(param, "_post_accumulate_grad_hooks", None)
+            and getattr(torch._C, "_current_graph_task_id", lambda: -1)() != -1)
+
+
+# (r04, measured and dropped: the deferred weight gradients on a SIDE stream that forks from the backward chain per layer and joins
+#  before the one sum launch -- eager step 8.5 -> 9.4-9.6 ms, recorded step 8.44 -> 8.70 ms with 6.4 ms of host time per replay: the
+#  weight-gradient kernels fill the chip, so running them beside the input-gradient chain only slows that chain.  HISTORY.md.)
+
+
 def _sum_later(work, dw, nslab, n, param):
     dev = dw.device.index
     # deferred only when AccumulateGrad is certain to TAKE the returned tensor over: a trainable dense parameter without a
     # gradient yet and without tensor hooks (a frozen weight's dw is dropped and its block re-used within the same backward pass; a
     # hooked or already-populated .grad gets a clone or a sum of the unfinished tensor) -- ADVICE r03
-    defer = (DEFER_WGRAD_SUMS and param is not None and param.requires_grad and param.grad is None
-             and not getattr(param, "_backward_hooks", None) and not getattr(param, "_post_accumulate_grad_hooks", None)
-             and getattr(torch._C, "_current_graph_task_id", lambda: -1)() != -1)
+    defer = _can_defer(param)
     ent = _PENDING_SUMS.get(dev)
     if ent is None:
         ent = _PENDING_SUMS[dev] = [[], []]
