@@ -1,0 +1,16 @@
+# round-4 measurement artefacts (run on the GPU box through gpurun; outputs under gpurun_out/, summaries copied to profiles/ afterwards
+# by scripts/r04_collect.sh here).  Every rocprofv3 command profiles `python3 <script>` directly (no env / shell hop behind `--`).
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+set -e
+EVAL="bench.py --in-flight 1 --steps 20 --warmup 3 --blocks 1 --no-cpu-baseline --no-profile --no-training --no-extra-configs"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r4_prof_eval -- python3 $EVAL > gpurun_out/r4_prof_eval.log 2>&1
+export MDF_TRAIN_NOPROFILE=1 MDF_TRAIN_STEPS=20
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r4_prof_train -- python3 scripts/bench_train.py > gpurun_out/r4_prof_train.log 2>&1
+EVALP="bench.py --in-flight 1 --steps 5 --warmup 2 --blocks 1 --no-cpu-baseline --no-profile --no-training --no-extra-configs"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/r4_pmc_e_fetch -- python3 $EVALP > gpurun_out/r4_pmc_e_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/r4_pmc_e_write -- python3 $EVALP > gpurun_out/r4_pmc_e_write.log 2>&1
+export MDF_TRAIN_STEPS=3
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/r4_pmc_t_fetch -- python3 scripts/bench_train.py > gpurun_out/r4_pmc_t_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/r4_pmc_t_write -- python3 scripts/bench_train.py > gpurun_out/r4_pmc_t_write.log 2>&1
+echo profiles done
