@@ -14,7 +14,9 @@ L = [("s0.conv01.0", 32, 16, "s1", 48, 148, 200), ("s0.conv01.1", 16, 16, "s1", 
      ("s1.conv01", 16, 8, "s1", 24, 296, 400), ("s1.conv12.0", 8, 16, "s2", 24, 296, 400),
      ("s1.conv12.1", 16, 16, "s1", 12, 148, 200), ("s1.conv23.1", 32, 32, "s1", 6, 74, 100),
      ("s1.trconv21T", 16, 8, "tr", 12, 148, 200),
-     ("s2.conv01", 8, 8, "s1", 8, 592, 800), ("s2.conv12.1", 16, 16, "s1", 4, 296, 400)]
+     ("s2.conv01", 8, 8, "s1", 8, 592, 800), ("s2.conv12.1", 16, 16, "s1", 4, 296, 400), ("s2.trconv21T", 16, 8, "tr", 4, 296, 400)]
+if "--tr" in sys.argv:
+    L = [l for l in L if l[3] == "tr"]
 dev = "cuda:0"
 check = "--check" in sys.argv
 tot_ms = tot_fl = 0.0
@@ -27,12 +29,16 @@ for name, ci, co, mode, D, H, W in L:
     wp = ops.pack_conv3d_weight(wt, tr)
     al, be = torch.rand(co, device=dev) + 0.5, torch.randn(co, device=dev) * 0.1
     st = 1 if mode == "s1" else 2
-    y = ops.conv3d_ndhwc(x, wp, ci, co, st, tr, al, be, True)
+    # --res: the transposed layers with their skip tensor, as in the regularisers (x1 + relu(bn(convT(x2))), regular.py:67)
+    skip = torch.randn(1, 2 * D, 2 * H, 2 * W, co, device=dev) if (tr and "--res" in sys.argv) else None
+    y = ops.conv3d_ndhwc(x, wp, ci, co, st, tr, al, be, True, skip)
     if check:
         import torch.nn.functional as F
         xc = x.permute(0, 4, 1, 2, 3)
         ref = F.conv_transpose3d(xc, wt, None, 2, 1, 1) if tr else F.conv3d(xc, wt, None, st, 1)
         ref = F.relu(ref * al.view(1, -1, 1, 1, 1) + be.view(1, -1, 1, 1, 1)).permute(0, 2, 3, 4, 1)
+        if skip is not None:
+            ref = ref + skip
         err = (y - ref).abs().max().item()
     torch.cuda.synchronize()
     n = 10
@@ -40,7 +46,7 @@ for name, ci, co, mode, D, H, W in L:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(n):
-            ops.conv3d_ndhwc(x, wp, ci, co, st, tr, al, be, True)
+            ops.conv3d_ndhwc(x, wp, ci, co, st, tr, al, be, True, skip)
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n
     ab = os.environ.get("MDF_AB")   # e.g. MDF_AB=MDF_CONV_ITEMS_PER_BLOCK MDF_AB_VALS=2,3,6 : interleaved in ONE process
