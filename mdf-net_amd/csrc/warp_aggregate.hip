@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kThreads) void warp_kernel(const Params p) {
       if (MODE == kVec) {
         const float o0 = acc[0] / wsum, o1 = acc[1] / wsum;  // homoaggregate.py:46
         if (p.out_ndhwc) {
-          *reinterpret_cast<float2*>(p.out + vox * G + 2 * sub) = make_float2(o0, o1);
+          { typedef float f2v __attribute__((ext_vector_type(2))); f2v ov = {o0, o1}; __builtin_nontemporal_store(ov, reinterpret_cast<f2v*>(p.out + vox * G + 2 * sub)); }   // (non-temporal: see warp_vec8_kernel)
         } else {
           const size_t cs = (size_t)p.D * hw;
           float* o = p.out + ((size_t)b * G * p.D + d) * hw + pix;
@@ -343,7 +343,9 @@ __global__ __launch_bounds__(kThreads) void warp_vec8_kernel(const Params p) {
       const size_t vox = ((size_t)b * p.D + d0 + dd) * hw + pix;
       const float o0 = acc[0][0] / wsum, o1 = acc[0][1] / wsum, o2 = acc[1][0] / wsum, o3 = acc[1][1] / wsum;   // homoaggregate.py:46
       if (p.out_ndhwc) {
-        *reinterpret_cast<float4*>(p.out + vox * G + 4 * sub) = make_float4(o0, o1, o2, o3);
+        // written once, read by another launch: a non-temporal store keeps the 121-182 MB of a cost volume from sweeping the source
+        // texels out of this XCD's 4-MB L2 (r04: -1 % per launch, bit-identical)
+        { typedef float f4v __attribute__((ext_vector_type(4))); f4v ov = {o0, o1, o2, o3}; __builtin_nontemporal_store(ov, reinterpret_cast<f4v*>(p.out + vox * G + 4 * sub)); }
       } else {
         const size_t cs = (size_t)p.D * hw;
         float* o = p.out + ((size_t)b * G * p.D + d0 + dd) * hw + pix;

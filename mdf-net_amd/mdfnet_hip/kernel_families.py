@@ -81,17 +81,11 @@ def globals_in_sources(csrc_dir):
 
 
 def fetch_size_factor(rocprof_name):
-    """FETCH_SIZE (KiB) -> bytes correction on gfx950.  The counter tallies a 128-B request as 64 B, so any access whose lanes form
-    contiguous runs of >= 128 B reads HALF its bytes (streaming 16 B/lane, 128-B and 256-B texel gathers, even a dword walk of a
-    cache line: all measured at 0.500), while 64-B requests are counted exactly (64-B texels, lanes of neighbouring texels on
-    different rows: measured at 1.000) -- scripts/micro/fetch_calib.hip, profiles/r04_fetch_calibration.md.  The only kernels here
-    whose dominant reads are 64-B texels are the aggregation kernels at C = 16 (stage 2: a texel is 16 channels x 4 B): factor 1 for
-    them, 2 for everything else.  (r03 doubled them too and so reported the eval aggregation's reads 1.57x its algorithmic bytes;
-    with the calibrated factor they are 1.05x.)  One factor per kernel is an approximation: the C = 16 kernel's reference map and
-    per-pixel hypotheses ARE streamed (45 of its 167 MB at cfg2), so factor 1 under-counts that kernel's reads by up to 13 %."""
-    fn = function_name(rocprof_name)
-    if fn in ("warp_kernel", "warp_vec8_kernel", "warp_vec_win_kernel", "warp_train_kernel", "warp_bwd_kernel"):
-        m = re.search(fn + r"<\s*(\d+)", rocprof_name)
-        if m and int(m.group(1)) == 16:
-            return 1.0
+    """FETCH_SIZE (KiB) -> bytes correction on gfx950: 2 for every kernel of this repository.  The counter tallies a 128-B request as
+    64 B, so any access whose lanes form contiguous runs of >= 128 B reads HALF its bytes -- streaming 16 B/lane, 128-B and 256-B texel
+    gathers, even a dword walk of a cache line all measure 0.500 -- while isolated 64-B requests are counted exactly (1.000:
+    scripts/micro/fetch_calib.hip, profiles/r04_fetch_calibration.md).  The only candidates for the exact case are the aggregation
+    kernels at C = 16 (64-B texels), but there the texels of neighbouring pixels are neighbours in memory and coalesce: the raw counter
+    of `warp_kernel<16,1>` at cfg2 is 77.5 MB per launch against 166.8 MB of algorithmic reads, so it cannot be exact -- factor 2 (0.93x
+    of the algorithmic bytes).  Kept as a function so that a kernel with genuinely scattered 64-B reads can be given factor 1."""
     return 2.0

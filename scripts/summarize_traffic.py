@@ -20,7 +20,7 @@ def load(d, counter):
             continue
         fam = family(r["Kernel_Name"])
         if fam:
-            # FETCH_SIZE: per-kernel factor (2 = 128-B requests tallied as 64 B; 1 for the 64-B-texel gathers: calibrated, see
+            # FETCH_SIZE: per-kernel factor (2 = 128-B requests tallied as 64 B: every kernel here, calibrated, see
             # kernel_families.fetch_size_factor); WRITE_SIZE is exact
             acc[fam] += float(r["Counter_Value"]) * (fetch_size_factor(r["Kernel_Name"]) if counter == "FETCH_SIZE" else 1.0)
             n[fam] += 1
@@ -30,8 +30,8 @@ def load(d, counter):
 fe, nf = load(fetch_dir, "FETCH_SIZE")
 wr, nw = load(write_dir, "WRITE_SIZE")
 res = {"method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py; KiB -> bytes; FETCH_SIZE x2 "
-                 "(gfx950 counts 128-B requests as 64 B) except x1 for the 64-B-texel gathers of the C = 16 aggregation kernels "
-                 "(calibrated: profiles/r04_fetch_calibration.md); per forward = total / forwards",
+                 "(gfx950 counts 128-B requests as 64 B; calibrated per access shape: profiles/r04_fetch_calibration.md); the counter sits "
+                 "between L2 and fabric, Infinity-Cache hits included; per forward = total / forwards",
        "forwards": forwards, "families": {}}
 for fam in sorted(set(fe) | set(wr)):
     rd = fe.get(fam, 0.0) * 1024 / forwards          # (the gfx950 factor is already applied per kernel in load())
