@@ -616,7 +616,8 @@ def consistency_fuse(depth_ref, conf, k_ref, e_ref, src_depths, src_ks, src_es, 
                                       None if vm is None else vm.data_ptr(), None if rep is None else rep.data_ptr(),
                                       _stream(depth_avg),),
          tag=f"{w}x{h} nsrc{len(srcs)}", work={"bytes": 4.0 * h * w * (len(srcs) + 3) + 3.0 * h * w, "bound": "hbm"})
-    out = {"depth_avg": depth_avg, "photo_mask": masks[0].bool(), "geo_mask": masks[1].bool(), "final_mask": masks[2].bool()}
+    mb = masks.view(torch.bool)         # the kernel writes 0 / 1 bytes: a reinterpretation, not three conversion launches per view
+    out = {"depth_avg": depth_avg, "photo_mask": mb[0], "geo_mask": mb[1], "final_mask": mb[2]}
     if per_view:
         bits = vm.to(torch.int32) & 0xFFFF
         out["view_masks"] = torch.stack([((bits >> i) & 1).bool() for i in range(9)], dim=1)
