@@ -80,23 +80,34 @@ def test_stagewise_vs_reference_trace(golden, model, seeded_sd):
         hooks.append(model.Homoaggre[st].register_forward_hook(lambda m, i, o, st=st: tr.__setitem__(f"cost{st}", o)))
         hooks.append(model.Regular[st].register_forward_hook(lambda m, i, o, st=st: tr.__setitem__(f"prob{st}", o[0] if isinstance(o, tuple) else o)))   # (prob, depth) when fused
         hooks.append(model.Depth_hypos[st].register_forward_hook(lambda m, i, o, st=st: tr.__setitem__(f"hypos{st}", o)))
-    with torch.no_grad():
-        model(imgs.to(DEV), extr.to(DEV), intr.to(DEV), dr.to(DEV))
-    for hk in hooks:
-        hk.remove()
     _, live = O.core_forward(seeded_sd, imgs, extr, intr, dr, keep=True, warp=O.homo_warping_explicit)
-    print()
-    # hypotheses (mm): the tight leg is the live oracle on this host (2e-3); against the golden -- another host's BLAS / libm in the curve
-    # fit -- the MAXIMUM over the 9216 hypotheses of a stage sits at 5.5e-3 .. 6.3e-3 depending on which fp32-equivalent form the backbone
-    # convs run in (direct k5 kernel vs Winograd over the parity images; the mean is 3.8e-4 in both, the final depth error unchanged)
-    for st in range(3):
-        for k, tol_gold, tol_live in (("hypos", 8e-3, 2e-3), ("cost", 2e-5, 2e-5), ("prob", 5e-4, 5e-4)):
-            a = tr[f"{k}{st}"].cpu().numpy()
-            dg, dl = np.abs(a - g[f"{k}{st}"]), np.abs(a - live[f"{k}{st}"].numpy())
-            print(f"stage {st} {k:5s}: vs golden max {dg.max():.3e} mean {dg.mean():.3e} | vs live oracle max {dl.max():.3e} "
-                  f"mean {dl.mean():.3e}")
-            assert a.shape == g[f"{k}{st}"].shape
-            assert dg.max() <= tol_gold and dl.max() <= tol_live, f"stage {st} {k}"
+    # Two fp32-equivalent forms of the backbone's 16 -> 32 k5-s2 layer (MDF_CONV_K5_WINOGRAD, read per call): the direct kernel keeps the
+    # r02 bar of 6e-3 mm on the hypotheses against the golden; the Winograd form over the parity images (the default, -22 us per view)
+    # moves the MAXIMUM over a stage's 9216 hypotheses to 5.5e-3 .. 6.3e-3 (mean 3.8e-4 in both, final depth error unchanged) and is
+    # held to 8e-3.  Against the live oracle on this host both are held to 2e-3.  (per-form bars instead of one loosened bar.)
+    import os
+    try:
+        for form, env, tol_hyp in (("direct k5-s2", "0", 6e-3), ("Winograd over parity images (default)", None, 8e-3)):
+            if env is None:
+                os.environ.pop("MDF_CONV_K5_WINOGRAD", None)
+            else:
+                os.environ["MDF_CONV_K5_WINOGRAD"] = env
+            tr.clear()
+            with torch.no_grad():
+                model(imgs.to(DEV), extr.to(DEV), intr.to(DEV), dr.to(DEV))
+            print(f"\n[{form}]")
+            for st in range(3):
+                for k, tol_gold, tol_live in (("hypos", tol_hyp, 2e-3), ("cost", 2e-5, 2e-5), ("prob", 5e-4, 5e-4)):
+                    a = tr[f"{k}{st}"].cpu().numpy()
+                    dg, dl = np.abs(a - g[f"{k}{st}"]), np.abs(a - live[f"{k}{st}"].numpy())
+                    print(f"stage {st} {k:5s}: vs golden max {dg.max():.3e} mean {dg.mean():.3e} | vs live oracle max {dl.max():.3e} "
+                          f"mean {dl.mean():.3e}")
+                    assert a.shape == g[f"{k}{st}"].shape
+                    assert dg.max() <= tol_gold and dl.max() <= tol_live, f"{form}: stage {st} {k}: {dg.max():.3e} (bar {tol_gold}) / {dl.max():.3e} (bar {tol_live})"
+    finally:
+        os.environ.pop("MDF_CONV_K5_WINOGRAD", None)
+        for hk in hooks:
+            hk.remove()
 
 
 @pytest.mark.parametrize("w,h,v,b,rng,base,seed", [
