@@ -14,7 +14,9 @@ Rank 0 prints ONE JSON line; it also carries
   kernels       the same for every hand-written kernel family + the stock (MIOpen) remainder
   cpu_baseline  the oracle (CPU restatement of the reference, kind "port") timed on this box's host cores on a
                 bounded sample of the same workload (rank 0, N=1 only)
-  training      BASELINE configs[2].  N=1: one GPU's training step (768x576x5, batch 1) with its per-family table; N>1: EVERY rank
+  training      BASELINE configs[2].  N=1: one GPU's training step (768x576x5, batch 1): `ms_per_step` is the step replayed from one
+                hipGraph recording (what train.py runs with MDF_TRAIN_HIPGRAPH=1), `eager` the same step issued launch by launch
+                (host-bound on slow host shares), with the per-family kernel table; N>1: EVERY rank
                 runs that step data-parallel with the flat-bucket gradient exchange over RCCL -- aggregate samples/s, the
                 collective's ms per step, and the direct (all-to-all + all-gather) exchange as a second figure
   cfg4          BASELINE configs[3]: 1920x1056 with 7 and 11 views, views/s (rank 0, N=1)
@@ -378,6 +380,24 @@ def training_block(dev, steps, blocks, stock_steps):
         finally:
             layers._TRAIN_STOCK = False
     return rec
+
+
+def primary_training_figure(rec):
+    """`training.ms_per_step` / `samples_per_s` = the step as train.py runs it with MDF_TRAIN_HIPGRAPH=1 (one hipGraph replay per step) when
+    that variant ran; the launch-by-launch (eager) figures move under `training.eager`.  Both execute the same kernels; the eager step is
+    issued at the host's limit (312 launches + the autograd plumbing in ~8.5 ms) and reads 8.5 / 9.1 / 10.3 ms on three boxes of one
+    pool depending on the host share, the replayed step 8.44-8.47 ms on all of them -- the replay is the figure that describes the GPU work."""
+    g = rec.get("graph_replay") or {}
+    rec["eager"] = {k: rec[k] for k in ("ms_per_step", "samples_per_s", "ms_per_step_blocks") if k in rec}
+    rec["eager"]["note"] = "the same step issued launch by launch from Python (host-bound on boxes with a slow host share)"
+    if "ms_per_step" in g:
+        rec["ms_per_step"], rec["samples_per_s"], rec["ms_per_step_blocks"] = g["ms_per_step"], g["samples_per_s"], g["ms_per_step_blocks"]
+        rec["mode"] = "one hipGraph replay per step (mdfnet_hip/graphstep.py; train.py: MDF_TRAIN_HIPGRAPH=1); launch-by-launch figures under `eager`"
+        rec["whole_step_frac_of_fp32_mfma_peak"] = round(rec["mfma_algorithmic_gflop_per_step"] / g["ms_per_step"] / PEAK_FP32_MFMA_TFLOPS, 4)
+    else:
+        rec["mode"] = "launch by launch (the recorded-step variant did not run: see graph_replay)"
+    if "stock_pytorch_rocm_baseline" in rec:
+        rec["stock_pytorch_rocm_baseline"]["speedup"] = round(rec["stock_pytorch_rocm_baseline"]["ms_per_step"] / rec["ms_per_step"], 1)
 
 
 def training_graph_child(steps, blocks):
@@ -856,6 +876,7 @@ def main():
         training = training_block(dev, args.train_steps, max(1, args.blocks), args.train_stock_steps)
         if not args.no_train_graph:
             training["graph_replay"] = training_graph(args.train_steps, max(1, args.blocks))
+        primary_training_figure(training)
     if world > 1 and not args.no_training:
         barrier()                      # rank 0's profile pass is over: every rank enters the training leg together
         training = training_ddp_block(dev, world, rank, args.train_steps, max(1, args.blocks))
