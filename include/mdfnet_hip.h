@@ -157,6 +157,13 @@ int mdf_refine_tail_fwd(const float* x, const float* w1pack, const float* w2, co
 int mdf_conv2d_pair_fwd(const float* x, const float* w1pack, const float* alpha1, const float* beta1, const float* w2pack,
                         const float* alpha2, const float* beta2, float* y, int N, int H, int W, void* stream);
 
+/* ---- a residual block of the refinement net as one launch (net/unit/base.py:39-47 `Res`, net/unit/refine.py:29,40, eval):
+ *      y = x + scale * conv_b(relu(conv_a(x)))   both Conv2d(8,8,k3,p1,no bias); x, y NHWC [N,H,W,8], y != x;
+ *      wa_pack / wb_pack = mdf_conv_pack_weights of the two layers.  Bit-identical to the two mdf_conv2d_fwd launches
+ *      (relu; then res + scale * conv); the intermediate map never reaches memory.                                      */
+int mdf_conv2d_res_pair_fwd(const float* x, const float* wa_pack, const float* wb_pack, float scale, float* y, int N, int H,
+                            int W, void* stream);
+
 /* ---- a9  depth_regression (net/unit/regress.py:5-7): depth = sum_d prob*hypos ----------------- */
 int mdf_depth_regress_fwd(const float* prob, const float* hypos, int hypos_per_pixel, float* depth, int B, int D,
                           int h, int w, void* stream);

@@ -131,6 +131,14 @@ def conv2d_pair(block0, block1, x):
     return ops.conv2d_pair_planar(x, w1, a1, b1, w2, a2, b2)
 
 
+def res_block(conv_a, conv_b, x, scale=0.1):
+    """Res (net/unit/base.py:39-47): x + scale * conv_b(relu(conv_a(x))), both Conv2d(8,8,k3,p1) without bias, as one launch."""
+    assert conv_a.bias is None and conv_b.bias is None and conv_a.in_channels == conv_b.out_channels == 8
+    wa, _, _ = cache_of(conv_a).get([conv_a.weight, conv_a.bias], lambda: (ops.pack_conv2d_weight(conv_a.weight), None, None))
+    wb, _, _ = cache_of(conv_b).get([conv_b.weight, conv_b.bias], lambda: (ops.pack_conv2d_weight(conv_b.weight), None, None))
+    return ops.conv2d_res_pair(x, wa, wb, scale)
+
+
 def refine_tail(conv_a, conv_b, x, lo, span):
     """RefineNet2.conv2 (Conv2d(8,32) -> PixelShuffle(2) -> Conv2d(8,1), no bias) + the mapping lo + y*span as one launch."""
     assert conv_a.bias is None and conv_b.bias is None

@@ -564,6 +564,18 @@ def conv2d_pair_planar(x, w1pack, a1, b1, w2pack, a2, b2):
     return y
 
 
+def conv2d_res_pair(x, wa_pack, wb_pack, scale=0.1):
+    """x + scale * conv3x3(relu(conv3x3(x))) for an 8-channel residual block as ONE launch (res_pair.hip); x [N,H,W,8] NHWC.
+    Bit-identical to two conv2d_nhwc launches (relu=True; then res=x, res_scale=scale)."""
+    _need_gpu(x, wa_pack, wb_pack)
+    n, h, w, c = x.shape
+    assert c == 8 and x.is_contiguous() and x.dtype == torch.float32
+    y = torch.empty_like(x)
+    _abi("mdf_conv2d_res_pair_fwd", (x.data_ptr(), wa_pack.data_ptr(), wb_pack.data_ptr(), ctypes.c_float(scale), y.data_ptr(), n, h, w, _stream(y)),
+         tag=f"8->8->8 k3 res {h}x{w}x{n}", work={"flops": 2.0 * 9 * 2 * 8 * 8 * n * h * w, "bytes": 4.0 * (x.numel() + y.numel()), "bound": "mfma"})
+    return y
+
+
 def shuffle2_rows(weight):
     """Reorder the output channels of a Conv2d that feeds nn.PixelShuffle(2): torch channel oc*4 + sub -> row sub*Cq + oc
     (Cq = Cout/4), the order mdf_conv2d_fwd(pixel_shuffle2=1) expects."""

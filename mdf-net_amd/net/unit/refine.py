@@ -11,6 +11,7 @@ from mdfnet_hip import controlplane, layers, ops
 from .base import Res
 
 _TAIL = os.environ.get("MDF_REFINE_TAIL", "1") != "0"      # dev A/B: the last three stages as three launches
+_RES_PAIR = os.environ.get("MDF_REFINE_RES_PAIR", "1") != "0"   # dev A/B: a Res block as two launches
 
 
 class RefineNet2(nn.Module):
@@ -38,8 +39,11 @@ class RefineNet2(nn.Module):
                 x0 = layers.conv2d_layer(self.conv0, None, x)
                 y = x0
                 for blk in self.ress:                                                               # x + 0.1*conv(relu(conv(x)))
-                    t = layers.conv2d_layer(blk.conv[0], None, y, relu=True)
-                    y = layers.conv2d_layer(blk.conv[2], None, t, res=y, res_scale=0.1)
+                    if _RES_PAIR and self.conv1.in_channels == 8:
+                        y = layers.res_block(blk.conv[0], blk.conv[2], y, 0.1)                      # one launch (res_pair.hip), bit-identical
+                    else:
+                        t = layers.conv2d_layer(blk.conv[0], None, y, relu=True)
+                        y = layers.conv2d_layer(blk.conv[2], None, t, res=y, res_scale=0.1)
                 y = layers.conv2d_layer(self.conv1, None, y, res=x0)                               # x0 + conv1(y)
                 if _TAIL:                                                                          # conv2 + the range mapping in one launch
                     return layers.refine_tail(self.conv2[0], self.conv2[2], y, lo.reshape(b), span.reshape(b))

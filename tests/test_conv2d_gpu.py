@@ -169,3 +169,27 @@ def test_conv2d_pair_equals_the_two_layers(shape):
     m1 = F.relu(F.conv2d(x, w1, None, 1, 1) * a1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1))
     exp = F.relu(F.conv2d(m1, w2, None, 1, 1) * a2.view(1, -1, 1, 1) + b2.view(1, -1, 1, 1))
     np.testing.assert_allclose(ops.from_nhwc(one).cpu().numpy(), exp.numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [(1, 8, 16), (2, 13, 37), (1, 40, 136), (3, 9, 131), (2, 64, 62), (1, 65, 63), (1, 200, 190), (1, 592, 800)])
+def test_res_block_pair_equals_the_two_layers(shape):
+    """mdf_conv2d_res_pair_fwd (res_pair.hip: a Res block of the refinement net, x + 0.1 * conv(relu(conv(x))), in one launch with
+    rolling LDS windows) against the two single-layer launches it replaces -- same packed weights, tap order and epilogue arithmetic,
+    so BIT-IDENTICAL; strips narrower / wider than 62 pixels, row counts around the 8-row steps and the segment boundaries -- and
+    against torch on the CPU (net/unit/base.py:39-47)."""
+    n, h, w = shape
+    rng = np.random.RandomState(n * 100 + h + w + 7)
+    x = T(rng.randn(n, 8, h, w).astype(np.float32))
+    wa = T((rng.randn(8, 8, 3, 3) / np.sqrt(72)).astype(np.float32))
+    wb = T((rng.randn(8, 8, 3, 3) / np.sqrt(72)).astype(np.float32))
+    xd = ops.to_nhwc(x.to(DEV))
+    pa, pb = ops.pack_conv2d_weight(wa.to(DEV)), ops.pack_conv2d_weight(wb.to(DEV))
+    t = ops.conv2d_nhwc(xd, pa, 8, 8, 3, 1, None, None, True)
+    two = ops.conv2d_nhwc(t, pb, 8, 8, 3, 1, None, None, False, xd, 0.1)
+    one = ops.conv2d_res_pair(xd, pa, pb, 0.1)
+    assert one.shape == two.shape == (n, h, w, 8)
+    assert torch.equal(one, two), float((one - two).abs().max())
+    exp = x + 0.1 * F.conv2d(F.relu(F.conv2d(x, wa, None, 1, 1)), wb, None, 1, 1)
+    np.testing.assert_allclose(ops.from_nhwc(one).cpu().numpy(), exp.numpy(), rtol=1e-4, atol=2e-5)
+    # x is not modified, and the call refuses to run in place
+    assert torch.equal(ops.from_nhwc(xd).cpu(), x)
