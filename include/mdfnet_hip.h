@@ -157,6 +157,13 @@ int mdf_refine_tail_fwd(const float* x, const float* w1pack, const float* w2, co
 int mdf_conv2d_pair_fwd(const float* x, const float* w1pack, const float* alpha1, const float* beta1, const float* w2pack,
                         const float* alpha2, const float* beta2, float* y, int N, int H, int W, void* stream);
 
+/* ---- head of the refinement net as one launch (net/unit/refine.py:29,36, eval): y = conv0((depth - lo[b]) / span[b]),
+ *      conv0 = Conv2d(1,8,k3,p1,no bias) with `weight` [8,1,3,3] as the module holds it; depth [B,H,W], y NHWC [B,H,W,8];
+ *      lo / span [B] or both NULL (no mapping).  torch's roundings (sub, true divide); bit-identical to
+ *      mdf_range_affine_fwd(mode 0) + mdf_conv2d_fwd.                                                                     */
+int mdf_refine_head_fwd(const float* depth, const float* lo, const float* span, const float* weight, float* y, int B, int H, int W,
+                        void* stream);
+
 /* ---- a residual block of the refinement net as one launch (net/unit/base.py:39-47 `Res`, net/unit/refine.py:29,40, eval):
  *      y = x + scale * conv_b(relu(conv_a(x)))   both Conv2d(8,8,k3,p1,no bias); x, y NHWC [N,H,W,8], y != x;
  *      wa_pack / wb_pack = mdf_conv_pack_weights of the two layers.  Bit-identical to the two mdf_conv2d_fwd launches

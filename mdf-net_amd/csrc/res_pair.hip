@@ -172,7 +172,57 @@ __global__ __launch_bounds__(256) void res_pair_kernel(const ResPairParams p) {
   }
 }
 
+// ---- head of the refinement net: (depth - lo) / span -> Conv2d(1, 8, k3, p1, no bias) as one launch (net/unit/refine.py:29,36) -------
+// On the matrix cores the 1 -> 8 layer uses one live k in four and 8 rows in 16 (17.5 us at 592x800 for 0.07 GFLOP) behind a range
+// mapping launch of its own (6.4 us).  Here a thread owns an output pixel: it normalises its 3x3 neighbourhood with torch's roundings
+// (sub, then a true divide; 0 outside the image = the conv's zero padding) and runs the 9-tap fma chain of each of the 8 output channels in
+// the MFMA's order (kh, kw ascending, acc = fma(w, x, acc) from 0), weights as scalar operands: bit-identical to the two launches.
+typedef const __attribute__((address_space(4))) float* cweights_p;
+
+__global__ __launch_bounds__(256) void refine_head_kernel(const float* __restrict__ depth, const float* __restrict__ lo, const float* __restrict__ span,
+                                                          const float* w, float* __restrict__ y, int B, int H, int W) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * H * W) return;
+  const int x = (int)(i % W), yy = (int)((i / W) % H), b = (int)(i / ((long long)W * H));
+  const float l = lo ? lo[b] : 0.f, sp = lo ? span[b] : 1.f;
+  const float* d = depth + (size_t)b * H * W;
+  float v[9];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int gy = yy + kh - 1, gx = x + kw - 1;
+      const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const float t = d[in ? (size_t)gy * W + gx : (size_t)yy * W + x];
+      const float nv = lo ? __fdiv_rn(__fsub_rn(t, l), sp) : t;
+      v[kh * 3 + kw] = in ? nv : 0.f;
+    }
+  const cweights_p cw = (cweights_p)w;            // [8][1][3][3]: uniform addresses -> scalar loads
+  float o[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc = __fmaf_rn(cw[c * 9 + t], v[t], acc);
+    o[c] = acc * 1.0f + 0.0f;                      // (the conv kernel's epilogue with alpha = 1, beta = 0)
+  }
+  float4* dst = reinterpret_cast<float4*>(y + (size_t)i * 8);
+  dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+  dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+}
+
 }  // namespace
+
+extern "C" int mdf_refine_head_fwd(const float* depth, const float* lo, const float* span, const float* weight, float* y, int B, int H, int W,
+                                   void* stream) {
+  MDF_REQUIRE(depth && weight && y, "null pointer argument");
+  MDF_REQUIRE((lo == nullptr) == (span == nullptr), "lo and span must both be given or both be NULL");
+  MDF_REQUIRE(B > 0 && H > 0 && W > 0, "bad shape");
+  const long long n = (long long)B * H * W;
+  MDF_REQUIRE(n * 8 < (1ll << 31), "map too large for 32-bit offsets");
+  hipLaunchKernelGGL(refine_head_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, depth, lo, span, weight, y, B, H, W);
+  return mdf::check_launch("refine_head_kernel");
+}
 
 // weights: the packings mdf_conv_pack_weights produces for (Cin_mem 8, Cout 8, 9 taps); the kernel reads their w-phase segments
 // (behind the plain fragments, as conv_lds.hip's LDS_CASE_RW and conv_pair.hip do)

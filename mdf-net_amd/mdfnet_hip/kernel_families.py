@@ -40,7 +40,7 @@ KERNEL_FAMILY = {
     "softmax_regress_bwd_kernel": PROB, "prob_conv_dgrad_kernel": PROB, "upsample2_bwd_kernel": PROB,
     # regress.hip / fpn_compose.hip
     "depth_regress_kernel": HEADS, "confidence_kernel": HEADS, "confidence_up2_kernel": HEADS, "range_affine_kernel": HEADS,
-    "hypos_fit_kernel": HEADS, "hypos_from_fit_kernel": HEADS, "fpn_compose_fwd_kernel": HEADS, "fpn_compose_bwd_kernel": HEADS,
+    "hypos_fit_kernel": HEADS, "hypos_from_fit_kernel": HEADS, "refine_head_kernel": HEADS, "fpn_compose_fwd_kernel": HEADS, "fpn_compose_bwd_kernel": HEADS,
     # consistency.hip
     "consistency_fuse_kernel": FILTER,
     # loss.hip

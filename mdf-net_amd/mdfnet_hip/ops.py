@@ -564,6 +564,19 @@ def conv2d_pair_planar(x, w1pack, a1, b1, w2pack, a2, b2):
     return y
 
 
+def refine_head(depth, lo, span, weight):
+    """conv0((depth - lo) / span): the range mapping and the refinement net's Conv2d(1, 8, k3) in one launch; depth [B,h,w] -> [B,h,w,8]."""
+    _need_gpu(depth, weight)
+    b, h, w = depth.shape
+    assert tuple(weight.shape) == (8, 1, 3, 3)
+    d, wt = _f32c(depth), _f32c(weight.detach())
+    y = torch.empty((b, h, w, 8), device=depth.device, dtype=torch.float32)
+    _abi("mdf_refine_head_fwd", (d.data_ptr(), None if lo is None else _f32c(lo).data_ptr(), None if span is None else _f32c(span).data_ptr(),
+                                 wt.data_ptr(), y.data_ptr(), b, h, w, _stream(y)), tag=f"range + 1->8 k3 {h}x{w}x{b}",
+         work={"bytes": 4.0 * (d.numel() + y.numel()), "bound": "hbm"})
+    return y
+
+
 def conv2d_res_pair(x, wa_pack, wb_pack, scale=0.1):
     """x + scale * conv3x3(relu(conv3x3(x))) for an 8-channel residual block as ONE launch (res_pair.hip); x [N,H,W,8] NHWC.
     Bit-identical to two conv2d_nhwc launches (relu=True; then res=x, res_scale=scale)."""

@@ -11,6 +11,7 @@ from mdfnet_hip import controlplane, layers, ops
 from .base import Res
 
 _TAIL = os.environ.get("MDF_REFINE_TAIL", "1") != "0"      # dev A/B: the last three stages as three launches
+_HEAD = os.environ.get("MDF_REFINE_HEAD", "1") != "0"           # dev A/B: range mapping and conv0 as two launches
 _RES_PAIR = os.environ.get("MDF_REFINE_RES_PAIR", "1") != "0"   # dev A/B: a Res block as two launches
 
 
@@ -35,8 +36,11 @@ class RefineNet2(nn.Module):
         if layers.hip_eval(self, depth):
             with torch.no_grad():
                 # (depth - lo) / span and lo + y * span: one launch each, torch's roundings (mdf_range_affine_fwd)
-                x = ops.range_affine(depth.detach(), lo.reshape(b), span.reshape(b), 0).unsqueeze(-1)   # [B,h,w,1]
-                x0 = layers.conv2d_layer(self.conv0, None, x)
+                if _HEAD and self.conv0.out_channels == 8:
+                    x0 = ops.refine_head(depth.detach(), lo.reshape(b), span.reshape(b), self.conv0.weight)   # one launch, bit-identical
+                else:
+                    x = ops.range_affine(depth.detach(), lo.reshape(b), span.reshape(b), 0).unsqueeze(-1)   # [B,h,w,1]
+                    x0 = layers.conv2d_layer(self.conv0, None, x)
                 y = x0
                 for blk in self.ress:                                                               # x + 0.1*conv(relu(conv(x)))
                     if _RES_PAIR and self.conv1.in_channels == 8:

@@ -193,3 +193,24 @@ def test_res_block_pair_equals_the_two_layers(shape):
     np.testing.assert_allclose(ops.from_nhwc(one).cpu().numpy(), exp.numpy(), rtol=1e-4, atol=2e-5)
     # x is not modified, and the call refuses to run in place
     assert torch.equal(ops.from_nhwc(xd).cpu(), x)
+
+
+@pytest.mark.parametrize("shape", [(1, 8, 16), (2, 13, 37), (1, 65, 63), (2, 128, 160), (1, 592, 800)])
+def test_refine_head_equals_range_mapping_plus_conv0(shape):
+    """mdf_refine_head_fwd ((depth - lo) / span and RefineNet2.conv0 = Conv2d(1, 8, k3) in one launch on the vector ALUs, refine.py:29,36)
+    against the two launches it replaces (mdf_range_affine_fwd + the MFMA conv): same roundings, same fma order -- BIT-IDENTICAL --
+    and against torch on the CPU."""
+    b, h, w = shape
+    rng = np.random.RandomState(b + h + w)
+    depth = T((425 + 510 * rng.rand(b, h, w)).astype(np.float32))
+    lo = T(np.full(b, 425.0, np.float32) + np.arange(b, dtype=np.float32))
+    span = T(np.full(b, 510.0, np.float32) - np.arange(b, dtype=np.float32))
+    wt = T((rng.randn(8, 1, 3, 3) / 3.0).astype(np.float32))
+    dd, lod, spd = depth.to(DEV), lo.to(DEV), span.to(DEV)
+    x = ops.range_affine(dd, lod, spd, 0).unsqueeze(-1)
+    two = ops.conv2d_nhwc(x, ops.pack_conv2d_weight(wt.to(DEV)), 1, 8, 3, 1, None, None, False)
+    one = ops.refine_head(dd, lod, spd, wt.to(DEV))
+    assert one.shape == two.shape == (b, h, w, 8)
+    assert torch.equal(one, two), float((one - two).abs().max())
+    exp = F.conv2d(((depth - lo.view(b, 1, 1)) / span.view(b, 1, 1)).unsqueeze(1), wt, None, 1, 1)
+    np.testing.assert_allclose(ops.from_nhwc(one).cpu().numpy(), exp.numpy(), rtol=1e-4, atol=2e-6)
