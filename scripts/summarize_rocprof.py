@@ -4,7 +4,7 @@ import csv, glob, os, shutil, sys
 
 src, dst, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
 cmd = sys.argv[4] if len(sys.argv) > 4 else ""
-stats = glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True)[0]
+stats = max(glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)   # (gpurun MERGES into gpurun_out/: older runs stay)
 rows = list(csv.DictReader(open(stats)))
 os.makedirs(os.path.dirname(dst), exist_ok=True)
 shutil.copy(stats, dst + "_kernel_stats.csv")

@@ -12,7 +12,7 @@ from mdfnet_hip.kernel_families import family, fetch_size_factor      # noqa: E4
 
 
 def load(d, counter):
-    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    f = max(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)   # (gpurun MERGES into gpurun_out/: older runs stay)
     acc = collections.defaultdict(float)
     n = collections.defaultdict(int)
     for r in csv.DictReader(open(f)):
