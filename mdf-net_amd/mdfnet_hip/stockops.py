@@ -1,11 +1,12 @@
 """Stock PyTorch-op restatement of the hot-path slots in TRAINING mode -- NOT the product's GPU training path.
 
 On an MI355X `model.train()` runs the hand-written training kernels (mdfnet_hip/train_ops.py).  This module is what a
-slot runs for CPU tensors in training mode, and exists for two things only: the gloo rehearsals of the data-parallel
-driver on machines without a GPU (tests/test_train_cpu.py, tests/test_train_data_cpu.py), and -- pinned there to the
-reference's own training golden (loss + gradients, rtol 1e-4) -- as the same-host autograd checker of tests/test_train_gpu.py.
-`MDF_TRAIN_STOCK=1` (bench.py's stated PyTorch-ROCm baseline, scripts/bench_train.py) routes GPU tensors here for an A/B.
-It is an explicit mode, never a silent fallback: inference has no stock-op route (net/core.py raises without a GPU).
+slot runs for CPU tensors in training mode, and exists for the gloo rehearsals of the data-parallel driver on machines
+without a GPU (tests/test_train_cpu.py -- where it is itself pinned to the reference's training golden, loss + gradients at
+rtol 1e-4 --, tests/test_train_data_cpu.py) and, with `MDF_TRAIN_STOCK=1`, as bench.py's stated PyTorch-ROCm baseline
+(scripts/bench_train.py).  It is NOT a checker of the GPU path: tests/test_train_gpu.py compares the kernels with oracle/
+(oracle/train_check.py, fp32 and float64).  It is an explicit mode, never a silent fallback: inference has no stock-op route
+(net/core.py raises without a GPU).
 Arithmetic follows the reference: net/unit/base.py:85-126, homoaggregate.py:25-69, depthhypos.py:27-215, regress.py:5-25."""
 import torch
 import torch.nn.functional as F
