@@ -157,6 +157,15 @@ int mdf_refine_tail_fwd(const float* x, const float* w1pack, const float* w2, co
 int mdf_conv2d_pair_fwd(const float* x, const float* w1pack, const float* alpha1, const float* beta1, const float* w2pack,
                         const float* alpha2, const float* beta2, float* y, int N, int H, int W, void* stream);
 
+/* ---- several 1x1 heads over one input as one launch (the feature pyramid's composed heads, net/unit/backbone.py:58-66, eval):
+ *      y[h] = [up2(res_ups[h]) +] W_h x + bias_h  for h < n_heads (2 or 3); x NHWC [B,H,W,Cin], y[h] NHWC [B,H,W,couts[h]],
+ *      res_ups[h] [B,H/2,W/2,couts[h]] or NULL (bilinear x2, align_corners=False, added BEFORE nothing else: torch's order
+ *      up + conv), biases[h] [couts[h]] or NULL, wpacks[h] = mdf_conv_pack_weights of head h (one tap).  The arrays are HOST arrays
+ *      of device pointers.  Built: Cin 64 -> (64, 32, 16) and Cin 32 -> (32, 16); every output bit-identical to mdf_conv2d_fwd.  */
+int mdf_conv1x1_heads_fwd(const float* x, int n_heads, const float* const* wpacks, const float* const* biases,
+                          const float* const* res_ups, float* const* ys, const int* couts, int B, int H, int W, int Cin,
+                          void* stream);
+
 /* ---- head of the refinement net as one launch (net/unit/refine.py:29,36, eval): y = conv0((depth - lo[b]) / span[b]),
  *      conv0 = Conv2d(1,8,k3,p1,no bias) with `weight` [8,1,3,3] as the module holds it; depth [B,H,W], y NHWC [B,H,W,8];
  *      lo / span [B] or both NULL (no mapping).  torch's roundings (sub, true divide); bit-identical to

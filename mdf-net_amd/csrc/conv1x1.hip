@@ -129,6 +129,139 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const P1 p) {
   }
 }
 
+// ---- several 1x1 heads on ONE input (the feature pyramid's composed heads, net/unit/backbone.py:_composed_heads) ------------------
+// out4 / the level-3 and level-2 contributions of t4 are three 1x1 convs over the same 64-channel map, and the two heads of t3 two over
+// the same 32-channel map: as separate launches the input is streamed once per head.  Here a wave loads its run of input tiles once
+// and multiplies it with the concatenated weight matrix (COUT0 + COUT1 + COUT2 rows); every head keeps its own output tensor, bias and
+// upsample-add source, and its n-tiles go through the single-head kernel's epilogue, so each output is bit-identical to the
+// single-head launch.
+struct P1M {
+  const float* x;          // [npx][CIN]
+  const float* wpack[3];   // per head: plain packing, one tap: [chunk][nt][lane][4]
+  const float* beta[3];    // [COUT_h] or null
+  const float* res_up[3];  // [B][Ho/2][Wo/2][COUT_h] or null
+  float* y[3];             // [npx][COUT_h]
+  int Ho, Wo;
+  long long npx;
+  int n_runs;
+};
+
+template <int CIN, int C0, int C1, int C2, int U>      // U: tiles per run (the weights take NCH * NT * 4 registers)
+__global__ __launch_bounds__(256) void conv1x1_heads_kernel(const P1M p) {
+  constexpr int NCH = CIN / 16;
+  constexpr int N0 = C0 / 16, N1 = C1 / 16, N2 = C2 / 16, NT = N0 + N1 + N2;
+  const int lane = threadIdx.x & 63, q = lane >> 4, n16 = lane & 15;
+  const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+  auto head_of = [](int nt) { return nt < N0 ? 0 : (nt < N0 + N1 ? 1 : 2); };
+  auto first_of = [](int h) { return h == 0 ? 0 : (h == 1 ? N0 : N0 + N1); };
+  auto cout_of = [](int h) { return h == 0 ? C0 : (h == 1 ? C1 : C2); };
+
+  // weights: in registers (NCH * NT * 4 of them) -- or, WLDS (the 64-channel input: 112 registers, one wave per SIMD), in LDS as the
+  // same [chunk][nt][lane][4] fragments, read back with one ds_read_b128 per (chunk, n-tile) and tile
+  constexpr bool WLDS = (NCH * NT * 4 > 64);
+  __shared__ __attribute__((aligned(16))) float wsm[WLDS ? NCH * NT * 64 * 4 : 4];
+  float wr[WLDS ? 1 : NCH][WLDS ? 1 : NT][4];
+  float be[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int h = head_of(nt), lt = nt - first_of(h), nth = cout_of(h) / 16;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      if constexpr (WLDS) {
+        if (threadIdx.x < 64)
+          *reinterpret_cast<float4*>(wsm + ((ch * NT + nt) * 64 + lane) * 4) = *reinterpret_cast<const float4*>(p.wpack[h] + ((size_t)(ch * nth + lt) * 64 + lane) * 4);
+      } else {
+        const float4 v = *reinterpret_cast<const float4*>(p.wpack[h] + ((size_t)(ch * nth + lt) * 64 + lane) * 4);
+        wr[ch][nt][0] = v.x; wr[ch][nt][1] = v.y; wr[ch][nt][2] = v.z; wr[ch][nt][3] = v.w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) be[nt][k] = p.beta[h] ? p.beta[h][lt * 16 + 4 * q + k] : 0.f;
+  }
+  if constexpr (WLDS) __syncthreads();
+
+  for (int run = wave_g; run < p.n_runs; run += n_waves) {
+    const long long px0 = (long long)run * (U * 16) + n16;
+    float4 xb[U][NCH];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long px = px0 + u * 16;
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch)
+        xb[u][ch] = (px < p.npx) ? *reinterpret_cast<const float4*>(p.x + px * CIN + ch * 16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long px = px0 + u * 16;
+      f32x4 acc[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        const float b4[4] = {xb[u][ch].x, xb[u][ch].y, xb[u][ch].z, xb[u][ch].w};
+        if constexpr (WLDS) {
+          asm volatile("" ::: "memory");      // (the fragments are re-read per tile: hoisted out of the loop they are 112 registers again)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const float4 wv = *reinterpret_cast<const float4*>(wsm + ((ch * NT + nt) * 64 + lane) * 4);
+            const float w4[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s], b4[s], acc[nt], 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[ch][nt][s], b4[s], acc[nt], 0, 0, 0);
+        }
+      }
+      if (px >= p.npx) continue;
+      const long long rr = px / p.Wo;
+      const int ow = (int)(px - rr * p.Wo), oh = (int)(rr % p.Ho);
+      const long long img = rr / p.Ho;
+      // bilinear x2 taps of this pixel (F.interpolate(scale_factor=2, bilinear, align_corners=False), backbone.py:60,62)
+      const int Hh = p.Ho >> 1, Wh = p.Wo >> 1;
+      float sy = ((float)oh + 0.5f) * 0.5f - 0.5f; sy = sy < 0.f ? 0.f : sy;
+      float sx = ((float)ow + 0.5f) * 0.5f - 0.5f; sx = sx < 0.f ? 0.f : sx;
+      const int y0 = (int)sy, x0 = (int)sx;
+      const int y1 = y0 + (y0 < Hh - 1), x1 = x0 + (x0 < Wh - 1);
+      const float ly1 = sy - (float)y0, ly0 = 1.f - ly1, lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+      const float w00 = ly0 * lx0, w01 = ly0 * lx1, w10 = ly1 * lx0, w11 = ly1 * lx1;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int h = head_of(nt), co = cout_of(h), c0 = (nt - first_of(h)) * 16 + 4 * q;
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = acc[nt][k] * 1.0f + be[nt][k];          // (the single-head epilogue with alpha = 1)
+        if (p.res_up[h]) {
+          const float* base = p.res_up[h] + (size_t)img * Hh * Wh * co + c0;
+          const float4 v00 = *reinterpret_cast<const float4*>(base + ((size_t)y0 * Wh + x0) * co);
+          const float4 v01 = *reinterpret_cast<const float4*>(base + ((size_t)y0 * Wh + x1) * co);
+          const float4 v10 = *reinterpret_cast<const float4*>(base + ((size_t)y1 * Wh + x0) * co);
+          const float4 v11 = *reinterpret_cast<const float4*>(base + ((size_t)y1 * Wh + x1) * co);
+          // torch order: interpolate(...) + lat(x)  ->  up + o
+          o[0] = __fmaf_rn(w11, v11.x, __fmaf_rn(w10, v10.x, __fmaf_rn(w00, v00.x, w01 * v01.x))) + o[0];
+          o[1] = __fmaf_rn(w11, v11.y, __fmaf_rn(w10, v10.y, __fmaf_rn(w00, v00.y, w01 * v01.y))) + o[1];
+          o[2] = __fmaf_rn(w11, v11.z, __fmaf_rn(w10, v10.z, __fmaf_rn(w00, v00.z, w01 * v01.z))) + o[2];
+          o[3] = __fmaf_rn(w11, v11.w, __fmaf_rn(w10, v10.w, __fmaf_rn(w00, v00.w, w01 * v01.w))) + o[3];
+        }
+        *reinterpret_cast<float4*>(p.y[h] + (size_t)px * co + c0) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+}
+
+template <int CIN, int C0, int C1, int C2, int U>
+int launch_heads(P1M& p, hipStream_t st) {
+  const long long runs = (p.npx + U * 16 - 1) / (U * 16);
+  if (runs > 0x7fffffff) return mdf::fail(MDF_EARG, "conv1x1 heads: too many pixels");
+  p.n_runs = (int)runs;
+  long long blocks = (runs + 3) / 4;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL((conv1x1_heads_kernel<CIN, C0, C1, C2, U>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+  return mdf::check_launch("conv1x1_heads_kernel");
+}
+
 template <int CIN, int COUT>
 int launch_1x1(P1& p, hipStream_t st) {
   constexpr int NCH = CIN / 16;
@@ -161,4 +294,29 @@ int mdf_conv1x1_dispatch(const float* x, const float* wpack, const float* alpha,
   //  non-temporal loads / stores measured slower too: 32->32 @296x400x5 50 -> 60 us inside a forward)
   C1_CASE(16, 16) C1_CASE(16, 32) C1_CASE(16, 64) C1_CASE(32, 16) C1_CASE(32, 32) C1_CASE(32, 64)
   return MDF_EUNSUPPORTED;
+}
+
+// Up to three bias-only 1x1 heads over one NHWC input in one launch; head h: y[h] [B,H,W,couts[h]] = [up2(res_ups[h]) +] W_h x + bias_h.
+extern "C" int mdf_conv1x1_heads_fwd(const float* x, int n_heads, const float* const* wpacks, const float* const* biases,
+                                     const float* const* res_ups, float* const* ys, const int* couts, int B, int H, int W, int Cin,
+                                     void* stream) {
+  MDF_REQUIRE(x && wpacks && biases && res_ups && ys && couts, "null pointer argument");
+  MDF_REQUIRE(n_heads == 2 || n_heads == 3, "n_heads=%d not in {2,3}", n_heads);
+  MDF_REQUIRE(B > 0 && H > 0 && W > 0, "bad shape");
+  P1M p{};
+  p.x = x; p.Ho = H; p.Wo = W; p.npx = (long long)B * H * W;
+  bool any_up = false;
+  for (int h = 0; h < n_heads; ++h) {
+    MDF_REQUIRE(wpacks[h] && ys[h], "head %d: null weights or output", h);
+    p.wpack[h] = wpacks[h]; p.beta[h] = biases[h]; p.res_up[h] = res_ups[h]; p.y[h] = ys[h];
+    any_up = any_up || res_ups[h];
+    MDF_REQUIRE((long long)p.npx * couts[h] < (1ll << 31) && (long long)p.npx * Cin < (1ll << 31), "map too large for 32-bit offsets");
+  }
+  MDF_REQUIRE(!any_up || (H % 2 == 0 && W % 2 == 0), "upsample-add needs even H and W");
+  hipStream_t st = (hipStream_t)stream;
+  // one tile per run for both (r04 sweep: 64 -> 64/32/16 with its weights in LDS 41.3 us at U = 1, 48.0 at 2, 42.5 with 112 weight
+  // registers and one wave per SIMD; 32 -> 32/16 62.9 / 66.5 / 65.8 us at U = 1 / 2 / 4)
+  if (Cin == 64 && n_heads == 3 && couts[0] == 64 && couts[1] == 32 && couts[2] == 16) return launch_heads<64, 64, 32, 16, 1>(p, st);
+  if (Cin == 32 && n_heads == 2 && couts[0] == 32 && couts[1] == 16) return launch_heads<32, 32, 16, 0, 1>(p, st);
+  return mdf::fail(MDF_EUNSUPPORTED, "conv1x1 heads: Cin=%d with %d heads is not built (64 -> 64/32/16, 32 -> 32/16)", Cin, n_heads);
 }

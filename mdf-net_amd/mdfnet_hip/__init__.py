@@ -39,6 +39,8 @@ SIGNATURES = {
     "mdf_conv3d_pack_weights": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp]),
     "mdf_conv2d_fwd": (c_int, [c_fp] * 5 + [ctypes.c_float, c_fp, c_fp] + [c_int] * 10 + [c_fp]),
     "mdf_conv2d_pair_fwd": (c_int, [c_fp] * 8 + [c_int] * 3 + [c_fp]),
+    "mdf_conv1x1_heads_fwd": (c_int, [c_fp, c_int, ctypes.POINTER(c_fp), ctypes.POINTER(c_fp), ctypes.POINTER(c_fp), ctypes.POINTER(c_fp),
+                                      ctypes.POINTER(c_int)] + [c_int] * 4 + [c_fp]),
     "mdf_refine_head_fwd": (c_int, [c_fp] * 5 + [c_int] * 3 + [c_fp]),
     "mdf_conv2d_res_pair_fwd": (c_int, [c_fp] * 3 + [ctypes.c_float, c_fp] + [c_int] * 3 + [c_fp]),
     "mdf_refine_tail_fwd": (c_int, [c_fp] * 6 + [c_int] * 3 + [c_fp]),

@@ -564,6 +564,30 @@ def conv2d_pair_planar(x, w1pack, a1, b1, w2pack, a2, b2):
     return y
 
 
+def conv1x1_heads(x, heads, res_ups):
+    """Several bias-only 1x1 heads over ONE NHWC input in one launch (conv1x1.hip: conv1x1_heads_kernel).  heads: list of
+    (wpack, bias or None, cin, cout); res_ups: per head a [B,H/2,W/2,cout] tensor (bilinear x2 upsample-add) or None.
+    -> list of [B,H,W,cout].  Every output is bit-identical to conv2d_nhwc(x, wpack, cin, cout, 1, 1, None, bias, False, None, 1.0, res_up)."""
+    _need_gpu(x)
+    b, h, w, cin = x.shape
+    assert x.is_contiguous() and all(hd[2] == cin for hd in heads)
+    n = len(heads)
+    ys = [torch.empty((b, h, w, hd[3]), device=x.device, dtype=torch.float32) for hd in heads]
+    ptr = lambda t: None if t is None else t.data_ptr()
+    wp = (ctypes.c_void_p * n)(*[hd[0].data_ptr() for hd in heads])
+    bs = (ctypes.c_void_p * n)(*[ptr(hd[1]) for hd in heads])
+    ru = (ctypes.c_void_p * n)(*[ptr(r) for r in res_ups])
+    yo = (ctypes.c_void_p * n)(*[y.data_ptr() for y in ys])
+    co = (ctypes.c_int * n)(*[hd[3] for hd in heads])
+    for r, hd in zip(res_ups, heads):
+        assert r is None or (tuple(r.shape) == (b, h // 2, w // 2, hd[3]) and r.is_contiguous())
+    cout = sum(hd[3] for hd in heads)
+    _abi("mdf_conv1x1_heads_fwd", (x.data_ptr(), n, wp, bs, ru, yo, co, b, h, w, cin, _stream(x)),
+         tag=f"{cin}->{'/'.join(str(hd[3]) for hd in heads)} k1s1 {h}x{w}x{b}",
+         work={"flops": 2.0 * cin * cout * b * h * w, "bytes": 4.0 * (x.numel() + sum(y.numel() for y in ys)), "bound": "mfma"})
+    return ys
+
+
 def refine_head(depth, lo, span, weight):
     """conv0((depth - lo) / span): the range mapping and the refinement net's Conv2d(1, 8, k3) in one launch; depth [B,h,w] -> [B,h,w,8]."""
     _need_gpu(depth, weight)

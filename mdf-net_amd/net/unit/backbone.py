@@ -13,6 +13,7 @@ from .base import ConvBNReLU
 
 
 import os as _os
+_HEADS = bool(int(_os.environ.get("MDF_FPN_HEADS_FUSED", "1")))    # dev A/B: 0 = every composed head as a launch of its own
 _PAIR = bool(int(_os.environ.get("MDF_CONV_PAIR", "1")))      # dev A/B: 0 = the two full-resolution layers as separate launches
 
 
@@ -79,9 +80,14 @@ class FPN_4Scales(nn.Module):
             t3 = seq(self.conv23, t2)
             t4 = seq(self.conv34, t3)
             hd = self._composed_heads()
-            y4 = head(hd["y4"], t4)
-            y3 = head(hd["y3"], t3, res_up=head(hd["a4"], t4))            # out3(up(t4) + lat3(t3))
-            c3 = head(hd["c3"], t3, res_up=head(hd["c4"], t4))            # out2(up(t4) + lat3(t3))        @1/4
+            if _HEADS and (hd["y4"][2], hd["y4"][3], hd["a4"][3], hd["c4"][3], hd["y3"][2]) == (64, 64, 32, 16, 32):
+                # the three heads of t4 and the two of t3 as one launch each: the input is streamed once (conv1x1_heads_kernel)
+                y4, a4, c4 = ops.conv1x1_heads(t4, [hd["y4"], hd["a4"], hd["c4"]], [None, None, None])
+                y3, c3 = ops.conv1x1_heads(t3, [hd["y3"], hd["c3"]], [a4, c4])    # out3(up(t4) + lat3(t3)); out2(up(t4) + lat3(t3)) @1/4
+            else:
+                y4 = head(hd["y4"], t4)
+                y3 = head(hd["y3"], t3, res_up=head(hd["a4"], t4))            # out3(up(t4) + lat3(t3))
+                c3 = head(hd["c3"], t3, res_up=head(hd["c4"], t4))            # out2(up(t4) + lat3(t3))        @1/4
             y2 = head(hd["y2"], t2, res_up=c3)                            # out2(up(up3) + lat2(t2))        @1/2
         return ops.from_nhwc(y4), ops.from_nhwc(y3), ops.from_nhwc(y2)
 

@@ -214,3 +214,25 @@ def test_refine_head_equals_range_mapping_plus_conv0(shape):
     assert torch.equal(one, two), float((one - two).abs().max())
     exp = F.conv2d(((depth - lo.view(b, 1, 1)) / span.view(b, 1, 1)).unsqueeze(1), wt, None, 1, 1)
     np.testing.assert_allclose(ops.from_nhwc(one).cpu().numpy(), exp.numpy(), rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("b,h,w", [(1, 4, 6), (2, 10, 14), (5, 74, 100), (1, 148, 200)])
+def test_fused_1x1_heads_equal_the_single_head_launches(b, h, w):
+    """mdf_conv1x1_heads_fwd (conv1x1.hip: conv1x1_heads_kernel) -- the three composed heads of t4 (64 -> 64 / 32 / 16) and the two of t3
+    (32 -> 32 / 16, each with its bilinear x2 upsample-add) as one launch per input -- against one mdf_conv2d_fwd launch per head:
+    every output BIT-IDENTICAL (net/unit/backbone.py:58-66 in the composed form)."""
+    rng = np.random.RandomState(b * 1000 + h + w)
+    def head(cin, cout, bias):
+        wt = T((rng.randn(cout, cin, 1, 1) / np.sqrt(cin)).astype(np.float32)).to(DEV)
+        return (ops.pack_conv2d_weight(wt), (T(rng.randn(cout).astype(np.float32)).to(DEV) if bias else None), cin, cout)
+    t4 = T(rng.randn(b, h, w, 64).astype(np.float32)).to(DEV)
+    t3 = T(rng.randn(b, 2 * h, 2 * w, 32).astype(np.float32)).to(DEV)
+    h4 = [head(64, 64, False), head(64, 32, False), head(64, 16, False)]
+    h3 = [head(32, 32, True), head(32, 16, True)]
+    single = lambda x, hd, up=None: ops.conv2d_nhwc(x, hd[0], hd[2], hd[3], 1, 1, None, hd[1], False, None, 1.0, up)
+    y4, a4, c4 = ops.conv1x1_heads(t4, h4, [None, None, None])
+    for got, hd in zip((y4, a4, c4), h4):
+        assert torch.equal(got, single(t4, hd)), hd[3]
+    y3, c3 = ops.conv1x1_heads(t3, h3, [a4, c4])
+    assert torch.equal(y3, single(t3, h3[0], a4)) and torch.equal(c3, single(t3, h3[1], c4))
+    assert y3.shape == (b, 2 * h, 2 * w, 32) and c3.shape == (b, 2 * h, 2 * w, 16)
