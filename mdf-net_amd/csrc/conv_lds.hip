@@ -945,6 +945,9 @@ extern "C" int mdf_release_stream(void* stream) {
     return !stat ? launch_lds<ci, ci, 8, 3, 3, 1, 1, 2, 2>(p, (hipStream_t)stream) : (stat->mode == 1 ? launch_lds<ci, ci, 8, 3, 3, 1, 1, 2, 2, 1>(p, (hipStream_t)stream) : launch_lds<ci, ci, 8, 3, 3, 1, 1, 2, 2, 2>(p, (hipStream_t)stream)); \
   }
 
+int mdf_wino3d_dispatch(const float* x, const float* wpack_wino, const float* alpha, const float* beta, const float* res, float res_scale,
+                        float* y, int B, int D, int H, int W, int Cin, int Cout, int relu, void* stream);   // wino3d.hip
+
 int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
                           float res_scale, const float* res_up, float* y, int B, int D, int H, int W, int Cin, int Cin_mem, int Cout, int KD,
                           int KHW, int stride, int relu, void* stream, int planar_in, int shuffle2, const mdf::ConvStat* stat) {
@@ -986,6 +989,14 @@ int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha
   // 3-D stride-1 layers with 8 output channels: depth-pair Winograd
   { const bool use_wd = use_wg && (wd_mask & 1); LDS_CASE_WD(8) }
   { const bool use_wd = use_wg && (wd_mask & 2); LDS_CASE_WD(16) }
+  // 3-D stride-1 layers with 16 output channels, eval: input-stationary Winograd (wino3d.hip); same fragments as the form below
+  {
+    const bool use_w3 = [] { const char* e = getenv("MDF_CONV_WINO3D"); return e ? atoi(e) != 0 : true; }();   // dev A/B and the equality test (read per call)
+    if (use_wg && use_w3 && !stat && KD == 3 && KHW == 3 && stride == 1 && Cin == Cin_mem && !res_up && !shuffle2 && Cout % 16 == 0) {
+      const int rc = mdf_wino3d_dispatch(x, wpack + (size_t)27 * Cin * Cout, alpha, beta, res, res_scale, y, B, D, H, W, Cin, Cout, relu, stream);
+      if (rc != MDF_EUNSUPPORTED) return rc;
+    }
+  }
   // 3-D stride-1 layers with 16 output channels: Winograd F(2x2,3x3) in (h,w)
   LDS_CASE_WG(16, 16) LDS_CASE_WG(32, 16) LDS_CASE_WG(32, 32) LDS_CASE_WG(16, 8) LDS_CASE_WG(16, 32)
   LDS_CASE_WG2(16, 16) LDS_CASE_WG2(32, 32) LDS_CASE_WG2(64, 64) LDS_CASE_WG2(16, 32) LDS_CASE_WG2(32, 64)
