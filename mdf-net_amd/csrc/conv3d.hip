@@ -903,7 +903,7 @@ static int conv3d_entry(const float* x, const float* wpack, const float* alpha, 
   else if (m == kS2) { p.Do = (Di - 1) / 2 + 1; p.Ho = (Hi - 1) / 2 + 1; p.Wo = (Wi - 1) / 2 + 1; }
   else { p.Do = 2 * Di; p.Ho = 2 * Hi; p.Wo = 2 * Wi; }
   p.m_total = (m == kTr) ? (long long)B * Di * Hi * Wi : (long long)B * p.Do * p.Ho * p.Wo;
-  static const long long lds_min = [] {  // test hook: MDF_CONV_LDS_MIN_VOXELS=0 forces the LDS kernel at any size
+  const long long lds_min = [] {  // test hook (read per call): MDF_CONV_LDS_MIN_VOXELS=0 forces the LDS kernels at any size
     const char* e = getenv("MDF_CONV_LDS_MIN_VOXELS");
     return e ? atoll(e) : 150000LL;
   }();

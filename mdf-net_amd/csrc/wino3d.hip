@@ -58,7 +58,13 @@ struct W3 {
   static constexpr int NPOS = NG * NPP;
   static constexpr int NFILL = (NPOS + 255) / 256;
   static constexpr int EPI_OFF = RING * PLANE;      // alpha[64], beta[64]
-  static constexpr size_t LDS_BYTES = (size_t)(RING * PLANE + 128) * sizeof(float);
+  // the weight fragments of kd slices 0 .. WL-1 stay in LDS for the whole kernel where they fit beside the planes (16 input channels:
+  // 48 KB): as buffer loads the fragments are 88 % of the vector-L1 accesses of the kernel (52 M lines per launch of the 32 -> 16
+  // layer, TCP_TOTAL_CACHE_ACCESSES) and keep that path ~half busy, which costs 9-12 % of the run time (ablation, profiles/r05_wino3d.md)
+  static constexpr int FRAG = 64 * 4;               // floats per fragment
+  static constexpr int WL = ((size_t)(RING * PLANE + 128 + 3 * NCH * 16 * NT * FRAG) * sizeof(float) <= 160 * 1024) ? 3 : 0;
+  static constexpr int W_OFF = EPI_OFF + 128;
+  static constexpr size_t LDS_BYTES = (size_t)(RING * PLANE + 128 + WL * NCH * 16 * NT * FRAG) * sizeof(float);
   static_assert(S > NPP, "a pad vector per group takes the fill's surplus lanes");
 };
 
@@ -66,7 +72,7 @@ struct W3 {
 #define MDF_W3_DIAG 0        // dev ablations (wrong results): 1 no plane traffic, 2 no output stores, 4 no epilogue, 8 no transforms in the steps, 16 no fragment loads in the steps
 #endif
 #ifndef MDF_W3_NOMASK
-#define MDF_W3_NOMASK 1      // dev: 1 = every kd slice of every step is multiplied (no branches in the ab-steps)
+#define MDF_W3_NOMASK 0      // dev: 1 = every kd slice of every step is multiplied (no masked step bodies)
 #endif
 #ifndef MDF_W3_PF_AT_START
 #define MDF_W3_PF_AT_START 0  // dev: 1 = the next plane is requested at the step's start (first version)
@@ -98,6 +104,12 @@ __global__ __launch_bounds__(256, 1) void wino3d_kernel(const Wino3dParams p) {
   if (tid < 128) {
     const int c = tid & 63;
     lds[C::EPI_OFF + tid] = (tid < 64) ? ((c < COUT && p.alpha) ? p.alpha[c] : 1.f) : ((c < COUT && p.beta) ? p.beta[c] : 0.f);
+  }
+
+  if constexpr (C::WL > 0) {      // resident weight fragments: [kd < WL][ab-step][nt][lane][4], as in memory
+    constexpr int NV = C::WL * NSTEP * NT * 64;   // float4s
+    for (int v = tid; v < NV; v += 256)
+      *reinterpret_cast<float4*>(lds + C::W_OFF + v * 4) = *reinterpret_cast<const float4*>(p.wpack + (size_t)v * 4);
   }
 
   // ---- fill constants of the thread: element k is vector v (row, col of the patch) of cin group g; 4 groups fastest so that
@@ -192,12 +204,21 @@ __global__ __launch_bounds__(256, 1) void wino3d_kernel(const Wino3dParams p) {
           const f32x2_t e0 = Dn[a * 4][c], e1 = Dn[a * 4 + 1][c], e2 = Dn[a * 4 + 2][c], e3 = Dn[a * 4 + 3][c];
           V[a * 4][c] = e0 - e2; V[a * 4 + 1][c] = e1 + e2; V[a * 4 + 2][c] = e2 - e1; V[a * 4 + 3][c] = e1 - e3;
         }
+      // the whole transform is ONE cluster here: hipcc otherwise sinks each packed add next to the MFMA that reads its result, and a
+      // vector instruction alone between two MFMAs costs three times what it costs inside a cluster (profiles/r05_mfma_issue.md)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) asm volatile("" : "+v"(V[e][c]));
     };
 
     float af[NA][3][4];
     auto load_a = [&](int i, int buf) {             // fragments (kd 0..2, chunk, ab) of ab-step i = chunk*16 + ab
 #pragma unroll
-      for (int kd = 0; kd < 3; ++kd) buf_load_to<4>(wres, wvoff, ((kd * NSTEP + i) * NT + wn) * (64 * 4 * 4), af[buf][kd]);
+      for (int kd = 0; kd < 3; ++kd) {
+        if (kd < C::WL) lds_frag<4>(lds + C::W_OFF + ((kd * NSTEP + i) * NT + wn) * C::FRAG + lane * 4, af[buf][kd]);
+        else buf_load_to<4>(wres, wvoff, ((kd * NSTEP + i) * NT + wn) * (64 * 4 * 4), af[buf][kd]);
+      }
     };
 
     // output transform + epilogue of set SET for output plane o (conv_lds.hip: wino_epilogue, NT = 1 per wave)
@@ -266,6 +287,7 @@ __global__ __launch_bounds__(256, 1) void wino3d_kernel(const Wino3dParams p) {
     // wave-uniform); fresh1: zi is plane 0 of the volume, so kd 1 (not kd 0 of plane -1) starts output plane 0's set.
     auto step = [&](auto rc, int zi, int z_next2, bool has_next, bool k0, bool k1, bool k2, bool fresh1) {
       constexpr int R = decltype(rc)::value;
+      const bool all3 = MDF_W3_NOMASK || (k0 && k1 && k2 && !fresh1);      // the segment owns all three output planes this plane feeds: one not-taken branch per ab-step
       if (MDF_W3_PF_AT_START) issue_plane(has_next ? zi + 1 : -1);
       constexpr int SLOT_N = (R + 1) % 3;
       static_for<0, NSTEP>([&](auto ic) {
@@ -290,29 +312,45 @@ __global__ __launch_bounds__(256, 1) void wino3d_kernel(const Wino3dParams p) {
         // (rows beyond the volume are zero halos in LDS: a wave with no live row multiplies them instead of idling at the barrier)
         // kd-major: a dependent chain of four MFMAs per accumulator issues at the full rate (profiles/r05_mfma_issue.md)
         constexpr int S0 = ((R + 1) % 3) * 16 + ab, S1 = R * 16 + ab, S2 = ((R + 2) % 3) * 16 + ab;
-        if (MDF_W3_NOMASK || k0) {
+        if (__builtin_expect(all3, 1)) {
           if constexpr (ch == 0) AccTile<S0>::mfma_fresh(af[i % NA][0][0], V[ab][0][0]);      // kd 0 starts output plane zi + 1
           else AccTile<S0>::mfma(af[i % NA][0][0], V[ab][0][0]);
           AccTile<S0>::mfma(af[i % NA][0][1], V[ab][0][1]);
           AccTile<S0>::mfma(af[i % NA][0][2], V[ab][1][0]);
           AccTile<S0>::mfma(af[i % NA][0][3], V[ab][1][1]);
-        }
-        if (MDF_W3_NOMASK || k1) {
-          if constexpr (ch == 0) {
-            if (fresh1) AccTile<S1>::mfma_fresh(af[i % NA][1][0], V[ab][0][0]);
-            else AccTile<S1>::mfma(af[i % NA][1][0], V[ab][0][0]);
-          } else {
-            AccTile<S1>::mfma(af[i % NA][1][0], V[ab][0][0]);
-          }
+          AccTile<S1>::mfma(af[i % NA][1][0], V[ab][0][0]);
           AccTile<S1>::mfma(af[i % NA][1][1], V[ab][0][1]);
           AccTile<S1>::mfma(af[i % NA][1][2], V[ab][1][0]);
           AccTile<S1>::mfma(af[i % NA][1][3], V[ab][1][1]);
-        }
-        if (MDF_W3_NOMASK || k2) {
           AccTile<S2>::mfma(af[i % NA][2][0], V[ab][0][0]);
           AccTile<S2>::mfma(af[i % NA][2][1], V[ab][0][1]);
           AccTile<S2>::mfma(af[i % NA][2][2], V[ab][1][0]);
           AccTile<S2>::mfma(af[i % NA][2][3], V[ab][1][1]);
+        } else {       // a segment's first two and last two planes
+          if (k0) {
+            if constexpr (ch == 0) AccTile<S0>::mfma_fresh(af[i % NA][0][0], V[ab][0][0]);
+            else AccTile<S0>::mfma(af[i % NA][0][0], V[ab][0][0]);
+            AccTile<S0>::mfma(af[i % NA][0][1], V[ab][0][1]);
+            AccTile<S0>::mfma(af[i % NA][0][2], V[ab][1][0]);
+            AccTile<S0>::mfma(af[i % NA][0][3], V[ab][1][1]);
+          }
+          if (k1) {
+            if constexpr (ch == 0) {
+              if (fresh1) AccTile<S1>::mfma_fresh(af[i % NA][1][0], V[ab][0][0]);
+              else AccTile<S1>::mfma(af[i % NA][1][0], V[ab][0][0]);
+            } else {
+              AccTile<S1>::mfma(af[i % NA][1][0], V[ab][0][0]);
+            }
+            AccTile<S1>::mfma(af[i % NA][1][1], V[ab][0][1]);
+            AccTile<S1>::mfma(af[i % NA][1][2], V[ab][1][0]);
+            AccTile<S1>::mfma(af[i % NA][1][3], V[ab][1][1]);
+          }
+          if (k2) {
+            AccTile<S2>::mfma(af[i % NA][2][0], V[ab][0][0]);
+            AccTile<S2>::mfma(af[i % NA][2][1], V[ab][0][1]);
+            AccTile<S2>::mfma(af[i % NA][2][2], V[ab][1][0]);
+            AccTile<S2>::mfma(af[i % NA][2][3], V[ab][1][1]);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (ab == 15 && !last_chunk) { if (!(MDF_W3_DIAG & 8)) transform(); }        // chunk boundary: the next patch is complete -> one cluster of 64 packed adds
@@ -405,5 +443,7 @@ int mdf_wino3d_dispatch(const float* x, const float* wpack_wino, const float* al
   if ((long long)H * W * Cin * 4 >= (1ll << 31)) return MDF_EUNSUPPORTED;   // plane offsets are 31-bit
   if (Cin == 32 && Cout == 16) return launch_wino3d<32, 16>(p, (hipStream_t)stream);
   if (Cin == 16 && Cout == 16) return launch_wino3d<16, 16>(p, (hipStream_t)stream);
+  // (32 -> 32 @24x74x100 was built and measured: 81 us against 69 us in conv_lds.hip's form -- 76 four-row tiles x 24 planes leave a block
+  //  ~7 planes per segment, two of them halo work, and a quarter of the 128-column tiles is empty; bit-identical, not instantiated)
   return MDF_EUNSUPPORTED;
 }

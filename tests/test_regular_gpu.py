@@ -68,6 +68,29 @@ def test_conv3d_layer_lds_kernels(cin, cout, shape):
     np.testing.assert_allclose(ops.from_ndhwc(y2).cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("cin,cout", [(32, 16), (16, 16)])
+@pytest.mark.parametrize("shape", [(1, 6, 130, 201), (2, 5, 125, 131), (1, 1, 400, 400), (1, 2, 3, 25001), (1, 90, 5, 401), (1, 7, 9, 33),
+                                   (3, 4, 17, 40), (1, 13, 8, 32)])
+def test_input_stationary_winograd_kernel_equals_the_output_stationary_one(cin, cout, shape, monkeypatch):
+    """wino3d.hip (each input plane transformed once and multiplied into three rotating accumulator sets, stream-K over tile x depth)
+    accumulates every output in the order of conv_lds.hip's Winograd form (kd, cin chunk, k): the results are bit-identical, with and
+    without the epilogue (BN, ReLU, residual).  Shapes: ragged tiles, batch 2 and 3 (tile changes inside a block's range), a single
+    plane, two planes, more planes than a block's share, a volume smaller than one tile's 32 columns."""
+    b, d, h, w = shape
+    g = torch.Generator().manual_seed(cin * 7 + cout + d * h + w)
+    x = ops.to_ndhwc(torch.randn(b, cin, d, h, w, generator=g).to(DEV))
+    wp = ops.pack_conv3d_weight((torch.randn(cout, cin, 3, 3, 3, generator=g) / np.sqrt(27 * cin)).to(DEV), False)
+    alpha, beta = (torch.rand(cout, generator=g) + 0.5).to(DEV), (torch.rand(cout, generator=g) * 0.4 - 0.2).to(DEV)
+    res = torch.randn(b, d, h, w, cout, generator=g).to(DEV)
+    monkeypatch.setenv("MDF_CONV_LDS_MIN_VOXELS", "0")     # small volumes take the LDS kernels too
+    out = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("MDF_CONV_WINO3D", v)
+        out[v] = (ops.conv3d_ndhwc(x, wp, cin, cout, 1, False, alpha, beta, True, res), ops.conv3d_ndhwc(x, wp, cin, cout, 1, False))
+    assert torch.equal(out["0"][0], out["1"][0]) and torch.equal(out["0"][1], out["1"][1])
+    assert not torch.isnan(out["1"][0]).any()
+
+
 @pytest.mark.parametrize("cin,cout", [(8, 16), (16, 32)])
 @pytest.mark.parametrize("shape", [(1, 25, 203, 261), (2, 11, 190, 301), (1, 6, 401, 799), (1, 2, 700, 900), (1, 3, 640, 1000)])
 def test_conv3d_stride2_layer_large_volumes(cin, cout, shape):
