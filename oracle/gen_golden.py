@@ -175,22 +175,80 @@ def fp32_spread(sd32, gt, depths64, grads64, draws=6, metric="l2"):
     return dmax, gmax
 
 
-def gen_train_f64(sd):
+@contextlib.contextmanager
+def reference_in_float64():
+    """The reference hard-codes fp32 in five places (`origin_imgs.float()` core.py:39, `dtype=torch.float32` base.py:102-103,
+    `depth_range[...].float()` depthhypos.py:29,223 / refine.py:31, `dtype=torch.float` regress.py:15), so `config.model.double()`
+    alone fails at the first conv.  While this context is active those spellings mean float64: the reference's OWN code then runs
+    in double precision, unmodified on disk."""
+    f32, fl, tf = torch.float32, torch.float, torch.Tensor.float
+    torch.float32 = torch.float64
+    torch.float = torch.float64
+    torch.Tensor.float = lambda self, *a, **k: self.double()
+    try:
+        yield
+    finally:
+        torch.float32, torch.float, torch.Tensor.float = f32, fl, tf
+
+
+def ref_train_step(model, ref_loss, sd32, gt, dtype, imgs_scale=None):
+    """One forward + Loss + backward of the REFERENCE model (train.py:36-45) on the training golden's scene in `dtype`
+    -> (loss, [depth], {name: grad}) as numpy."""
+    imgs, extr, intr, dr = synth.make_scene(96, 64, 3, batch=2, rot_deg=3.0, seed=31)
+    if imgs_scale is not None:
+        imgs = imgs * imgs_scale
+    model.float()
+    model.load_state_dict(sd32)
+    model.train()
+    model.zero_grad()
+    ctx = reference_in_float64() if dtype == torch.float64 else contextlib.nullcontext()
+    if dtype == torch.float64:
+        model.double()
+    with ctx:
+        out = model(imgs.to(dtype), extr.to(dtype), intr.to(dtype), dr.to(dtype))
+        loss = ref_loss.Loss()(out, {k: torch.as_tensor(v).to(dtype) for k, v in gt.items()}, dr.to(dtype))
+        loss.backward()
+    res = (float(loss), [npy(d) for d in out["depth"]], {k: npy(p.grad) for k, p in model.named_parameters()})
+    model.float()
+    return res
+
+
+def gen_train_f64(model, ref_loss, sd):
+    """tests/golden/train_tiny_f64.npz: the training golden's step through the REFERENCE in float64 (the yardstick
+    no longer comes from the oracle) and the reference-class fp32 spread around it: the reference in fp32 on the unperturbed inputs
+    and on six copies whose images and parameters are moved by one fp32 ulp (`one_ulp`, torch seeds 0..5), each compared with the
+    float64 result of the unperturbed inputs.  The oracle's own float64 run is stored as `oracle64:*` distances (they agree to
+    ~1e-12: the restatement IS the reference's arithmetic)."""
     g = np.load(os.path.join(OUT, "train_tiny.npz"))
-    loss, depths, grads = train_f64(sd, {k: g["gt" + k] for k in ("3", "2", "1", "0")})
-    tg = {"loss": np.float64(loss)}
+    gt = {k: g["gt" + k] for k in ("3", "2", "1", "0")}
+    loss, depths, grads = ref_train_step(model, ref_loss, sd, gt, torch.float64)
+    o_loss, o_depths, o_grads = train_f64(sd, gt)
+    tg = {"loss": np.float64(loss), "oracle64:loss_absdiff": np.float64(abs(loss - o_loss))}
     for i, d in enumerate(depths):
         tg[f"depth{i}"] = d
-        print(f"depth{i}: reference fp32 golden vs float64: mean |d| {np.abs(g[f'depth{i}'] - d).mean():.3e}")
+        tg[f"oracle64:depth{i}"] = np.float64(np.abs(o_depths[i] - d).max())
+        print(f"depth{i}: reference fp32 golden vs reference float64: mean |d| {np.abs(g[f'depth{i}'] - d).mean():.3e}; oracle float64 vs reference float64: max |d| {tg[f'oracle64:depth{i}']:.1e}")
     for k in TRAIN_GRAD_KEYS:
         tg["grad:" + k] = grads[k]
-        print(f"grad:{k}: reference fp32 golden vs float64: max rel {np.abs(g['grad:' + k] - grads[k]).max() / np.abs(grads[k]).max():.2e}")
-    dmax, gmax = fp32_spread(sd, {k: g["gt" + k] for k in ("3", "2", "1", "0")}, depths, {k: grads[k] for k in TRAIN_GRAD_KEYS}, metric="maxrel")
+        tg["oracle64:grad:" + k] = np.float64(np.abs(o_grads[k] - grads[k]).max() / np.abs(grads[k]).max())
+        print(f"grad:{k}: reference fp32 golden vs float64: max rel {np.abs(g['grad:' + k] - grads[k]).max() / np.abs(grads[k]).max():.2e}; oracle64 vs reference64 {tg['oracle64:grad:' + k]:.1e}")
+    dmax, gmax = [0.0] * 4, {k: 0.0 for k in TRAIN_GRAD_KEYS}
+    for t in range(-1, 6):
+        scale, src = None, sd
+        if t >= 0:
+            torch.manual_seed(t)
+            scale = one_ulp((2, 3, 3, 64, 96))
+            src = {k: (v * one_ulp(v.shape) if v.dtype == torch.float32 and "running" not in k else v) for k, v in sd.items()}
+        _, d32, g32 = ref_train_step(model, ref_loss, src, gt, torch.float32, scale)
+        for i in range(4):
+            dmax[i] = max(dmax[i], float(np.abs(d32[i].astype(np.float64) - depths[i]).mean()))
+        for k in gmax:
+            gmax[k] = max(gmax[k], float(np.abs(g32[k].astype(np.float64) - grads[k]).max() / np.abs(grads[k]).max()))
     for i, v in enumerate(dmax):
         tg[f"spread:depth{i}"] = np.float64(v)
     for k, v in gmax.items():
         tg["spread:grad:" + k] = np.float64(v)
-        print(f"spread:grad:{k}: fp32 oracle, unperturbed + 6 one-ulp draws: max rel distance from float64 up to {v:.2e}")
+        print(f"spread:grad:{k}: reference fp32, unperturbed + 6 one-ulp draws: max rel distance from float64 up to {v:.2e}")
     np.savez_compressed(os.path.join(OUT, "train_tiny_f64.npz"), **tg)
 
 
@@ -287,12 +345,6 @@ def main():
         return gen_io()
     if "--only-filter" in sys.argv:
         return gen_filter()
-    if "--only-train-f64" in sys.argv:      # needs train_tiny.npz (its ground-truth maps); no reference import: the oracle in float64
-        import contextlib as _c
-        with _c.redirect_stdout(io.StringIO()):
-            import config as own_config
-            shapes = own_config.build_model().state_dict()
-        return gen_train_f64(synth.seeded_state_dict(shapes, seed=1))
     cfg, base, agg, regress, dh, scale, ref_loss = load_reference()
     model = cfg.model
     sd = synth.seeded_state_dict(model.state_dict(), seed=1)
@@ -300,6 +352,8 @@ def main():
     model.eval()
     if "--only-train" in sys.argv:
         return gen_train(model, sd, ref_loss)
+    if "--only-train-f64" in sys.argv:      # needs train_tiny.npz (its ground-truth maps)
+        return gen_train_f64(model, ref_loss, sd)
     meta = {k: list(v.shape) for k, v in model.state_dict().items()}
     np.savez(os.path.join(OUT, "state_dict_meta.npz"),
              keys=np.array(list(meta.keys())), shapes=np.array([str(s) for s in meta.values()]),
@@ -411,7 +465,7 @@ def main():
     e2e("e2e_5view.npz", 320, 256, 5, 1, 5.0, 21, False)
 
     gen_train(model, sd, ref_loss)
-    gen_train_f64(sd)
+    gen_train_f64(model, ref_loss, sd)
     gen_io()
     gen_filter()
     for f in sorted(os.listdir(OUT)):

@@ -244,16 +244,23 @@ def variance_aggregate(features, ref_proj, src_projs, depth_hypos, warp=homo_war
 
 
 # --------------------------------------------------------------------------- a6-a8 regularisers
+RELU3_HOOK = None    # test hook (oracle/train_check.py:relu_hook): called with every ReLU input of the regularisers in layer order INSTEAD of F.relu
+
+
+def _relu3(x):
+    return F.relu(x) if RELU3_HOOK is None else RELU3_HOOK(x)
+
+
 def _cbr3(x, p, pre, stride=1, training=False):
     """ConvBNReLU3D, net/unit/base.py:50-68 (k=3, pad=1, no conv bias)."""
     x = F.conv3d(x, p[pre + "conv.weight"], None, stride, 1)
-    return F.relu(_bn(x, p, pre + "bn.", training))
+    return _relu3(_bn(x, p, pre + "bn.", training))
 
 
 def _tbr3(x, p, pre_conv, pre_bn, training=False):
     """ConvTranspose3d(k3,s2,p1,op1,no bias) + BN + ReLU (regular.py:32-34,38-40,95-108)."""
     x = F.conv_transpose3d(x, p[pre_conv + "weight"], None, 2, 1, 1)
-    return F.relu(_bn(x, p, pre_bn, training))
+    return _relu3(_bn(x, p, pre_bn, training))
 
 
 def regular_3scales_logits(x, p, training=False):

@@ -46,16 +46,27 @@ def expected_buffers(sd, trace, momentum=0.1):
     return out
 
 
+@contextlib.contextmanager
+def relu_hook(fn):
+    """While active, every ReLU of the regularisers (oracle.mvs_oracle._relu3) is `fn(pre_activation)`: record the pre-activations, or
+    replace the decision `pre > 0` by a given mask (the run then follows another implementation's ReLU decisions)."""
+    prev, O.RELU3_HOOK = O.RELU3_HOOK, fn
+    try:
+        yield
+    finally:
+        O.RELU3_HOOK = prev
+
+
 def grads(params):
     return {k: v.grad for k, v in params.items() if v.is_floating_point() and v.requires_grad}
 
 
-def regulariser(sd, cost, hypos, ddepth, dtype=torch.float32):
+def regulariser(sd, cost, hypos, ddepth, dtype=torch.float32, relu=None):
     """Regular[s] + soft-argmin (regular.py:47-69 / :114-133, regress.py:5-7), training mode, backward from d depth.
-    -> dict(prob, depth, dcost, grads, buffers)."""
+    relu: optional replacement of the ReLUs (relu_hook).  -> dict(prob, depth, dcost, grads, buffers)."""
     p = leaf_params(sd, dtype)
     c = cost.detach().to(dtype).clone().requires_grad_(True)
-    with O.precision(dtype), bn_trace() as tr:
+    with O.precision(dtype), bn_trace() as tr, relu_hook(relu):
         prob = O.regular(c, p, training=True)
         depth = O.depth_regression(prob, hypos.to(dtype))
     depth.backward(ddepth.to(dtype))

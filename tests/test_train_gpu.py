@@ -425,18 +425,82 @@ def test_regulariser_training_forward_backward(stage, weights, seeded_sd):
           f"median HIP / fp32-unperturbed {float(np.median([got[k] / max(first[k], 1e-30) for k in got])):.2f}")
     # Bars: (1) typical accuracy -- the median tensor is no farther from float64 than 1.5 x the unperturbed fp32 oracle (measured
     # 0.06-0.26: the centred softmax backward of prob_bwd.hip makes the HIP gradients 4-16 x MORE accurate than fp32 autograd);
-    # (2) every tensor within 1.5 x the fp32 spread.  Should the HIP path hit a combination of ReLU flips none of the nine fp32 runs
-    # hit, (2) is relaxed to: at most a quarter of the tensors beyond, none beyond 10 x (a wrong kernel is off by orders of magnitude).
+    # (2) EVERY tensor within 1.5 x the fp32 spread (measured <= 1.02; no relaxation clause: what moves a gradient between the
+    # quantised error levels is one ReLU decision, shown directly by test_relu_decisions_explain_the_gradient_spread).
     bad = [(k, a, c_) for q, a, _, c_, k in rows if q > 1.5]
     print(f"   tensors beyond 1.5 x the fp32 spread: {len(bad)} of {len(rows)}")
-    assert len(bad) <= len(rows) // 4, bad
-    assert rows[0][0] <= 10.0, rows[:3]
+    assert not bad, bad
     assert float(np.median([got[k] / max(first[k], 1e-30) for k in got])) <= 1.5
     assert _l2(cd.grad, cpu["dcost"]) < 1e-2
     for k, pa in reg.named_parameters():
         assert _l2(pa.grad, cpu["grads"][k]) < 2e-2, (k, _l2(pa.grad, cpu["grads"][k]))
     for k, ba in reg.named_buffers():                       # running statistics: nn.BatchNorm's update from the oracle's batch statistics
         assert _rel(ba.float(), cpu["buffers"][k].float()) < 1e-4, k
+
+
+@pytest.mark.parametrize("stage", [0, 2])
+def test_relu_decisions_explain_the_gradient_spread(stage, seeded_sd):
+    """the error of the regulariser's gradients against float64 is quantised (dcost of Regular[0] with the golden
+    weights: 2.3e-5, 5.2e-4 or 2.3e-3 over one-ulp perturbations), explained so far only by perturbation statistics.  Direct proof:
+    (1) every ReLU decision of the HIP forward is compared with the float64 oracle's (the tape holds each layer's raw conv output and
+        its folded BatchNorm (a, b): the decision is y a + b > 0); the decisions differ on a handful of units, and every one of them has
+        a float64 pre-activation within MARGIN = 2e-5 layer-rms of zero, i.e. within fp32 rounding after up to 11 layers;
+    (2) the float64 oracle is run again FOLLOWING the HIP decisions (relu(x) := x * [HIP decision]): against that run the HIP
+        gradients are at the fp32 rounding level -- at least 5x closer than to the free float64 run whenever decisions differ, and
+        within FLOOR = 5e-5 of it in any case (measured <= 8e-6).  So the whole excess of the free comparison is the flipped units, not the kernels."""
+    from oracle import train_check as TC
+    import copy
+    MARGIN, FLOOR = 2e-5, 5e-5
+    torch.manual_seed(11 + stage)
+    m = build_model()
+    m.load_state_dict(seeded_sd)
+    sd = m.Regular[stage].state_dict()
+    reg = copy.deepcopy(m.Regular[stage]).to(DEV).train()
+    g, d, h, w = ((32, 48, 12, 20), (16, 24, 24, 40), (8, 8, 48, 56))[stage]
+    torch.manual_seed(stage + 3)
+    cost = torch.rand(2, g, d, h, w)
+    hyp = (425 + 510 * torch.rand(2, 1, h, w)) + torch.linspace(-20, 20, d).reshape(1, d, 1, 1)
+    dd = torch.randn(2, h, w)
+    pre64 = []
+    free = TC.regulariser(sd, cost, hyp, dd, torch.float64, relu=lambda x: (pre64.append(x.detach()), torch.relu(x))[1])
+    cd = cost.to(DEV).requires_grad_(True)
+    prob, depth = reg(cd, hyp.to(DEV))
+    depth.backward(dd.to(DEV))
+    # the decisions were taken in the forward pass: re-run it for the tape (same kernels, same inputs: deterministic)
+    cd2 = cost.to(DEV).requires_grad_(True)
+    _, depth2 = reg(cd2, hyp.to(DEV))
+    layers_ = depth2.grad_fn.tape.layers
+    assert len(layers_) == len(pre64)
+    hip_dec, flips, worst = [], 0, 0.0
+    for (conv, bn, tr, stride, x, y, aux, res, z), p64 in zip(layers_, pre64):
+        c = conv.out_channels
+        pre = y * aux[:c] + aux[c:2 * c]                                  # NDHWC, the kernel's own folded scale / shift
+        dec = ops.from_ndhwc((pre > 0).float()).cpu().bool()
+        assert dec.shape == p64.shape
+        dif = dec != (p64 > 0)
+        flips += int(dif.sum())
+        if dif.any():
+            worst = max(worst, float((p64[dif].abs() / p64.pow(2).mean().sqrt()).max()))
+        hip_dec.append(dec)
+    it = iter(hip_dec)
+    forced = TC.regulariser(sd, cost, hyp, dd, torch.float64, relu=lambda x: x * next(it).to(x.dtype))
+    got = {"dcost": cd.grad, **{k: p.grad for k, p in reg.named_parameters()}}
+    rows = []
+    for k, v in got.items():
+        e_free = _l2(v, free["dcost"] if k == "dcost" else free["grads"][k])
+        e_forced = _l2(v, forced["dcost"] if k == "dcost" else forced["grads"][k])
+        rows.append((e_free / max(e_forced, 1e-30), e_free, e_forced, k))
+    rows.sort(reverse=True)
+    units = sum(int(p.numel()) for p in pre64)
+    print(f"\nstage {stage}: {flips} of {units} ReLU decisions differ from float64; farthest flipped pre-activation {worst:.1e} layer-rms from zero; "
+          f"dcost error vs float64 free {_l2(cd.grad, free['dcost']):.1e}, following the HIP decisions {_l2(cd.grad, forced['dcost']):.1e}; "
+          f"largest free / forced ratios {[(f'{q:.0f}x', f'{a:.1e}', f'{b_:.1e}', k) for q, a, b_, k in rows[:3]]}")
+    assert worst <= MARGIN, (flips, worst)
+    assert flips <= units // 100000 + 8, flips
+    for q, e_free, e_forced, k in rows:
+        assert e_forced <= FLOOR, (k, e_free, e_forced)
+        if flips and e_free > 5 * FLOOR:
+            assert e_forced * 5 <= e_free, (k, e_free, e_forced)
 
 
 def test_frozen_or_hooked_weight_does_not_take_the_deferred_sum_route(seeded_sd):
@@ -519,10 +583,11 @@ def test_training_step_on_gpu_vs_reference_golden(golden, seeded_sd):
         train_ops._abi = orig
     assert {"mdf_warp_aggregate_vec_train", "mdf_conv3d_wgrad_partial", "mdf_wgrad_sum_batch", "mdf_bn_relu_bwd", "mdf_prob_conv_dgrad_stat"} <= set(used)
     bucket.allreduce_gradients()
-    # Yardstick: the same step through the oracle in float64 (tests/golden/train_tiny_f64.npz, oracle/gen_golden.py:gen_train_f64).
-    # The reference's own fp32 result is e_ref away from it; the HIP path may be at most 1.5 x that far.  The
-    # distance HIP <-> reference golden (the r03 bar: 1e-3 mm on stages 0-2) is printed for information: both sit ~1.4e-3 mm from
-    # the exact result on stage 0, so their mutual distance is a sample of fp32 noise, not a margin.
+    # Yardstick: the same step through the REFERENCE in float64 (tests/golden/train_tiny_f64.npz, oracle/gen_golden.py:gen_train_f64 runs
+    # /root/reference's own model under reference_in_float64(); the oracle's float64 run agrees with it to <= 2e-15).  The reference's
+    # own fp32 result is e_ref away from it; the HIP path may be at most 1.5 x that far, AND at most 2 x e_ref from
+    # the reference's fp32 golden itself (a binding bar against the reference's output; two fp32 results that
+    # are each ~e_ref from the exact one are ~sqrt(2) e_ref apart if their errors are independent: measured 0.4-0.75 e_ref).
     g64 = golden("train_tiny_f64.npz")
     fails = []
     for i, d in enumerate(out["depth"]):
@@ -532,6 +597,7 @@ def test_training_step_on_gpu_vs_reference_golden(golden, seeded_sd):
         print(f"\ndepth{i}: mean |d| vs float64: HIP {e_hip:.3e}, reference fp32 {e_ref:.3e} (ratio {e_hip / e_ref:.2f}); "
               f"HIP vs reference fp32 golden: mean {err.mean():.3e} max {err.max():.3e}")
         fails += [("depth", i, e_hip, e_ref)] if e_hip > 1.5 * e_ref else []
+        fails += [("depth vs the reference fp32 golden", i, err.mean(), e_ref)] if err.mean() > 2.0 * e_ref else []
         assert err.max() < 0.5, (i, err.max())
     np.testing.assert_allclose(float(loss.detach()), float(g["loss"]), rtol=2e-5)
     params = dict(m.named_parameters())
