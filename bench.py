@@ -364,7 +364,8 @@ def training_block(dev, steps, blocks, stock_steps):
                                                  for k, v in traffic.items()}}
     if stock_steps > 0:
         # the same step through PyTorch-ROCm's own autograd (MIOpen convs, ATen grid_sample / BatchNorm): a stated baseline
-        layers._TRAIN_STOCK = True
+        import rehearsal
+        rehearsal.enable(on_gpu=True)                    # explicit: torch autograd over the stock ops instead of the HIP training kernels
         try:
             sopt = torch.optim.Adam(model.parameters(), lr=1e-3)
             step(sopt)                                   # warm-up (MIOpen find)
@@ -375,10 +376,10 @@ def training_block(dev, steps, blocks, stock_steps):
             torch.cuda.synchronize()
             st = (time.perf_counter() - t0) / stock_steps
             rec["stock_pytorch_rocm_baseline"] = {"ms_per_step": round(1e3 * st, 1), "samples_per_s": round(1.0 / st, 3), "steps": stock_steps,
-                                                  "note": "same model, inputs and step through torch autograd on this GPU (MDF_TRAIN_STOCK route)",
+                                                  "note": "same model, inputs and step through torch autograd on this GPU (rehearsal backend, mdf-net_amd/rehearsal)",
                                                   "speedup": round(st / med, 1)}
         finally:
-            layers._TRAIN_STOCK = False
+            rehearsal.disable()
     return rec
 
 

@@ -56,15 +56,29 @@ def cache_of_key(mod, name):
     return c
 
 
+_NO_CPU = ("the slots run on hand-written MI355X kernels only (got a CPU tensor in {} mode); there is no CPU route in the product.  "
+           "Rehearsals of the drivers on machines without a GPU select the stock-op backend explicitly: `import rehearsal; rehearsal.enable()` "
+           "(mdf-net_amd/rehearsal/)")
+
+
 def hip_train(mod, *tensors):
-    """True when the slot runs its TRAINING mode on the hand-written kernels: module in training mode (or an enclosing
-    CoreNet in training mode) with its tensors on a GPU.  CPU tensors in training mode take the stock-op route
-    (mdfnet_hip/stockops.py), which exists for the reference-pinned CPU tests and the gloo rehearsals only."""
+    """True when the slot runs its TRAINING mode on the hand-written kernels: module in training mode (or an enclosing CoreNet in
+    training mode) with its tensors on a GPU.  CPU tensors in training mode RAISE unless the rehearsal backend has been selected
+    (mdf-net_amd/rehearsal: gloo rehearsals, the autograd baseline of bench.py) -- it is not part of the product's dispatch."""
     ts = [t for t in tensors if isinstance(t, torch.Tensor)]
     training = mod.training if mod is not None else bool(getattr(_mode, "training", False))
-    if _TRAIN_STOCK:        # dev A/B switch (scripts/bench_train.py): PyTorch-ROCm autograd instead of the HIP training kernels
+    if _TRAIN_STOCK and _REHEARSAL is not None:        # rehearsal.enable(on_gpu=True): PyTorch-ROCm autograd instead of the HIP training kernels
         return False
+    if training and len(ts) > 0 and not all(t.is_cuda for t in ts) and _REHEARSAL is None:
+        raise RuntimeError(_NO_CPU.format("training"))
     return training and len(ts) > 0 and all(t.is_cuda for t in ts)
+
+
+def stock():
+    """The rehearsal backend's slot functions (mdf-net_amd/rehearsal/stockops.py); raises unless it was selected."""
+    if _REHEARSAL is None:
+        raise RuntimeError(_NO_CPU.format("training"))
+    return _REHEARSAL
 
 
 def hip_eval(mod, x):
@@ -76,7 +90,8 @@ import contextlib
 import os
 import threading
 
-_TRAIN_STOCK = bool(int(os.environ.get("MDF_TRAIN_STOCK", "0")))
+_TRAIN_STOCK = False     # set by rehearsal.enable(on_gpu=True)
+_REHEARSAL = None        # the stock-op backend module once rehearsal.enable() was called
 
 _mode = threading.local()
 
@@ -95,17 +110,20 @@ def model_mode(training):
 
 def use_hip(mod, *tensors):
     """Slot dispatch for INFERENCE.  A module in eval mode with no autograd graph wanted runs the hand-written eval kernels and
-    REFUSES CPU tensors -- there is no CPU fallback.  Returns False in training mode (module.training, an enclosing CoreNet in
-    training mode, or inputs that require grad): the callers have asked `hip_train` first (GPU tensors -> the hand-written
-    training kernels of train_ops.py), so what is left is CPU tensors / MDF_TRAIN_STOCK, i.e. mdfnet_hip/stockops.py.
+    REFUSES CPU tensors -- there is no CPU fallback.  In training mode (module.training, an enclosing CoreNet in training mode, or
+    inputs that require grad) the callers have asked `hip_train` first (GPU tensors -> the hand-written training kernels of
+    train_ops.py); what is left is the rehearsal backend if it was selected explicitly (returns False), an error otherwise.
     `mod` is None for plain functions."""
     ts = [t for t in tensors if isinstance(t, torch.Tensor)]
     training = mod.training if mod is not None else bool(getattr(_mode, "training", False))
     if training or (torch.is_grad_enabled() and any(t.requires_grad for t in ts)):
+        if _REHEARSAL is None:
+            raise RuntimeError(_NO_CPU.format("training") if not all(t.is_cuda for t in ts) else
+                               "this slot has no hand-written training kernel for the given call (autograd wanted outside CoreNet's training "
+                               "step); the stock-op route is the rehearsal backend: `import rehearsal; rehearsal.enable(on_gpu=True)`")
         return False
     if not all(t.is_cuda for t in ts):
-        raise RuntimeError("inference slots run on hand-written MI355X kernels only (got a CPU tensor); there is no CPU "
-                           "fallback (training mode on CPU tensors is the stock-op rehearsal path of mdfnet_hip/stockops.py)")
+        raise RuntimeError(_NO_CPU.format("eval"))
     return True
 
 

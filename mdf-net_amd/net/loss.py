@@ -14,7 +14,7 @@ class Loss(torch.nn.Module):
             # on the GPU: one reduction launch per scale + one finalize (and one backward launch per scale) instead of ~55
             # tiny elementwise / reduction launches (mdfnet_hip/train_ops.py:LossTrainFn, csrc/loss.hip)
             from mdfnet_hip import layers, train_ops
-            if not layers._TRAIN_STOCK:
+            if not layers._TRAIN_STOCK:      # (rehearsal.enable(on_gpu=True): the autograd baseline)
                 return train_ops.loss_train(depth_range[:, 0], pairs)
         total = 0.0
         floor = depth_range[:, 0].view(-1, 1, 1)

@@ -4,7 +4,7 @@ MFMA conv kernel; homo_warping is the HIP warp."""
 import torch
 import torch.nn as nn
 
-from mdfnet_hip import hostmirror, layers, ops, stockops
+from mdfnet_hip import hostmirror, layers, ops
 
 
 class ConvBNReLU(nn.Module):
@@ -52,6 +52,6 @@ def homo_warping(src_fea, src_proj, ref_proj, depth_hypos):
     """base.py:85-126.  src_fea [B,C,h,w]; projections [B,4,4]; hypos [B,D,1,1] | [B,D,h,w] -> [B,C,D,h,w]
     (bit-identical to the reference's CPU result).  With autograd / on the CPU: the stock-op training path."""
     if not layers.use_hip(None, src_fea, depth_hypos):
-        return stockops.homo_warping(src_fea, src_proj, ref_proj, depth_hypos)
+        return layers.stock().homo_warping(src_fea, src_proj, ref_proj, depth_hypos)
     proj = ops.relative_projections(hostmirror.get(ref_proj), [hostmirror.get(src_proj)])[0]
     return ops.homo_warp(src_fea, proj.to(src_fea.device, non_blocking=True), depth_hypos)

@@ -2,7 +2,7 @@
 import torch
 import torch.nn as nn
 
-from mdfnet_hip import controlplane, hostmirror, layers, ops, stockops
+from mdfnet_hip import controlplane, hostmirror, layers, ops
 
 _MODES = {"gauss1": 1, "laplace": 2}
 
@@ -40,7 +40,7 @@ class HyposByFit(nn.Module):
         if not on_gpu and not layers.use_hip(self, depth.detach(), prob_volume.detach()):
             if self.curve_calss not in _MODES:
                 raise NotImplementedError(f"HyposByFit curve '{self.curve_calss}' is not built (gauss1, laplace are)")
-            return stockops.hypos_by_fit(self.curve_calss, self.prob_thresh, self.ndepths, depth.detach(), depth_range,
+            return layers.stock().hypos_by_fit(self.curve_calss, self.prob_thresh, self.ndepths, depth.detach(), depth_range,
                                          prob_volume.detach(), depth_hypos.detach(), upsample)
         mode = _MODES.get(self.curve_calss)
         if mode is None:

@@ -2,7 +2,7 @@
 import torch
 import torch.nn as nn
 
-from mdfnet_hip import controlplane, hostmirror, layers, ops, stockops
+from mdfnet_hip import controlplane, hostmirror, layers, ops
 from .base import ConvBNReLU3D
 
 
@@ -36,8 +36,8 @@ class VectorAggregate(nn.Module):
             proj = _projections(ref_proj, src_projs, features[0].device)
             return train_ops.aggregate_train(self, list(features), proj, depth_hypos)
         if not layers.use_hip(self, *features, depth_hypos):
-            # training path (autograd, batch-stat BN in depth_weight): stock PyTorch ops, see mdfnet_hip/stockops.py
-            return stockops.vector_aggregate(self.depth_weight, self.ngroups, features, ref_proj, src_projs, depth_hypos)
+            # training path (autograd, batch-stat BN in depth_weight): the rehearsal backend only (mdf-net_amd/rehearsal/stockops.py)
+            return layers.stock().vector_aggregate(self.depth_weight, self.ngroups, features, ref_proj, src_projs, depth_hypos)
         with torch.no_grad():
             proj = _projections(ref_proj, src_projs, features[0].device)
             return ops.warp_aggregate_vec(list(features), proj, depth_hypos, self._params(), self.ngroups)
@@ -46,7 +46,7 @@ class VectorAggregate(nn.Module):
 def homo_aggregate_by_variance(features, ref_proj, src_projs, depth_hypos):
     """homoaggregate.py:49-69: variance over {ref, softmax_C(warped src)} -> [B,C,D,h,w]."""
     if not layers.use_hip(None, *features, depth_hypos):
-        return stockops.variance_aggregate(features, ref_proj, src_projs, depth_hypos)
+        return layers.stock().variance_aggregate(features, ref_proj, src_projs, depth_hypos)
     with torch.no_grad():
         proj = _projections(ref_proj, src_projs, features[0].device)
         return ops.warp_aggregate_var(list(features), proj, depth_hypos)

@@ -1,11 +1,11 @@
 """Regress slot: soft-argmin depth and photometric confidence (reference: net/unit/regress.py)."""
-from mdfnet_hip import layers, ops, stockops
+from mdfnet_hip import layers, ops
 
 
 def depth_regression(prob_volume, depth_hypos):
     """regress.py:5-7: sum_d prob * hypos.  prob [B,D,h,w]; hypos [B,D,1,1] | [B,D,h,w] -> [B,h,w]."""
     if not layers.use_hip(None, prob_volume, depth_hypos):
-        return stockops.depth_regression(prob_volume, depth_hypos)   # training path (autograd)
+        return layers.stock().depth_regression(prob_volume, depth_hypos)   # rehearsal backend only
     return ops.depth_regress(prob_volume, depth_hypos)
 
 

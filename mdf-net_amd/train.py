@@ -2,8 +2,9 @@
 decay lr*(1-(e-1)/E)^0.9, per-epoch checkpoint {'epoch','model'} without a `module.` prefix, epoch_loss.txt.
 Data parallel = one process per GPU (`torchrun --nproc-per-node N train.py ...`): flat-bucket gradient all-reduce
 over RCCL (mdfnet_hip/ddp.py) instead of nn.DataParallel.  On a GPU the model's training mode runs the hand-written
-training kernels (mdfnet_hip/train_ops.py: forward + backward of every slot, the loss, one-launch Adam); CPU tensors take
-the stock-op restatement (mdfnet_hip/stockops.py), which exists for the gloo rehearsals and as the tests' same-host checker."""
+training kernels (mdfnet_hip/train_ops.py: forward + backward of every slot, the loss, one-launch Adam).  On a CPU device the
+driver is a REHEARSAL (gloo runs of the data-parallel wiring on machines without a GPU): it selects the stock-op backend of
+mdf-net_amd/rehearsal explicitly and says so; the product's slots themselves refuse CPU tensors."""
 import argparse
 import logging
 import os
@@ -91,6 +92,10 @@ def main():
         start_epoch = ckpt["epoch"] + 1
         model.load_state_dict(ckpt["model"])
     model.to(device)
+    if torch.device(device).type != "cuda":
+        import rehearsal
+        rehearsal.enable()
+        logging.getLogger(__name__).warning("train.py on %s: REHEARSAL run on the stock-op backend (mdf-net_amd/rehearsal), not the product's kernels", device)
     dump_dir = os.environ.get("MDF_DUMP_RANK_STATE")       # test hook (tests/test_train_ddp_gpu.py): every rank's final parameters
     if dump_dir:
         from mdfnet_hip import ops as _ops

@@ -13,6 +13,8 @@ W, H, V = (int(x) for x in os.environ.get("MDF_TRAIN_SHAPE", "768,576,5").split(
 model = bench.build(dev).train()
 bucket = ddp.FlatBucket(model)
 if os.environ.get("MDF_TRAIN_STOCK") == "1":
+    import rehearsal
+    rehearsal.enable(on_gpu=True)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
 else:
     from mdfnet_hip.optim import FlatAdam

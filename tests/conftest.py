@@ -15,6 +15,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture
+def rehearsal_backend():
+    """CPU tests of the training drivers select the stock-op rehearsal backend explicitly (mdf-net_amd/rehearsal); the product's own
+    dispatch refuses CPU tensors."""
+    import rehearsal
+    with rehearsal.mode():
+        yield
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np

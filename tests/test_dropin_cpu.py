@@ -25,7 +25,7 @@ def test_state_dict_matches_reference_contract(golden, seeded_sd):
     assert sd["Backbone.conv01.0.bn.num_batches_tracked"].dtype == torch.int64
 
 
-def test_slot_signatures_and_mode_dispatch():
+def test_slot_signatures_and_mode_dispatch(rehearsal_backend):
     from modelutil import build_model
     from net.unit import regress, scale
     m = build_model()
@@ -38,11 +38,11 @@ def test_slot_signatures_and_mode_dispatch():
     assert rp.shape == (1, 4, 4) and len(sps) == 2 and torch.equal(k, k0)   # inputs untouched (scale.py:14)
     hyp = m.Depth_hypos[0](None, torch.tensor([[425.0, 935.0]], dtype=torch.float64), None, None, upsample=True)
     assert hyp.shape == (1, 48, 1, 1) and float(hyp[0, 0]) == 425.0 and float(hyp[0, -1]) == 935.0
-    m.train()   # training mode = stock-op path (autograd), works on the CPU too
+    m.train()   # training mode on CPU tensors = the rehearsal backend (selected by the fixture)
     cost = m.Homoaggre[0]([torch.randn(1, 64, 4, 4, requires_grad=True) for _ in range(2)], rp, sps[:1], hyp)
     assert cost.shape == (1, 32, 48, 4, 4) and cost.requires_grad
     m.eval()    # inference = hand-written kernels only: CPU tensors are refused
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
+    with pytest.raises(RuntimeError, match="no CPU route"):
         m.Homoaggre[0]([torch.zeros(1, 64, 4, 4)] * 2, rp, sps[:1], hyp)
 
 

@@ -3,7 +3,9 @@ suite would notice)."""
 
 
 def test_product_modules_import_and_expose_their_entry_points():
-    from mdfnet_hip import ddp, dropin, hostmirror, layers, ops, shard, stockops, synth  # noqa: F401
+    from mdfnet_hip import ddp, dropin, hostmirror, layers, ops, shard, synth  # noqa: F401
+    import rehearsal  # noqa: F401
+    from rehearsal import stockops  # noqa: F401
     import net.core, net.loss  # noqa: F401,E401
     from net.unit import backbone, base, depthhypos, homoaggregate, refine, regress, regular, scale  # noqa: F401
     for name in ("conv2d_layer", "use_hip", "hip_eval", "cache_of", "model_mode"):

@@ -1,5 +1,6 @@
-"""CPU: the product's TRAINING path (stock-op mode of the slots, mdfnet_hip/stockops.py) against the reference's
-training golden, and the one-process-per-GPU data parallelism (flat gradient bucket, one all-reduce) over gloo."""
+"""CPU: the REHEARSAL backend (mdf-net_amd/rehearsal: the slots' training mode on stock ops, selected explicitly) against the
+reference's training golden, the one-process-per-GPU data parallelism (flat gradient bucket, one all-reduce) over gloo on it, and the
+product's own dispatch refusing CPU tensors in eval AND training mode."""
 import json
 import os
 import subprocess
@@ -16,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 T = torch.from_numpy
 
 
-def test_training_forward_backward_vs_reference_golden(golden, seeded_sd):
+def test_training_forward_backward_vs_reference_golden(golden, seeded_sd, rehearsal_backend):
     from net.loss import Loss
     g = golden("train_tiny.npz")
     m = build_model()
@@ -39,12 +40,18 @@ def test_training_forward_backward_vs_reference_golden(golden, seeded_sd):
             np.testing.assert_allclose(params[k[5:]].grad.numpy(), ref, rtol=1e-4, atol=1e-5 * float(np.abs(ref).max()))
 
 
-def test_eval_mode_refuses_cpu(seeded_sd):
+def test_eval_and_training_mode_refuse_cpu_tensors(seeded_sd):
+    """no second backend behind the slots -- without `rehearsal.enable()` CPU tensors raise in both modes."""
+    import rehearsal
+    assert not rehearsal.enabled()
     m = build_model()
     m.load_state_dict(seeded_sd)
-    m.eval()
     imgs, extr, intr, dr = synth.make_scene(96, 64, 3, batch=1, seed=1)
+    m.eval()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(imgs, extr, intr, dr)
+    m.train()
+    with pytest.raises(RuntimeError, match="rehearsal.enable"):
         m(imgs, extr, intr, dr)
 
 
@@ -53,6 +60,7 @@ import os, sys, json
 sys.path[:0] = [%(pkg)r, %(tests)r]
 import numpy as np, torch, torch.distributed as dist
 from mdfnet_hip import ddp, shard, synth
+import rehearsal; rehearsal.enable()      # CPU ranks: the stock-op backend, selected explicitly
 from modelutil import build_model
 from net.loss import Loss
 torch.set_num_threads(2)
@@ -78,7 +86,7 @@ dist.barrier()
 '''
 
 
-def test_two_rank_gloo_flat_bucket_matches_mean_of_replica_gradients(tmp_path, seeded_sd):
+def test_two_rank_gloo_flat_bucket_matches_mean_of_replica_gradients(tmp_path, seeded_sd, rehearsal_backend):
     """DDP semantics = DataParallel's: each replica normalises with its own batch statistics; the synchronised gradient is
     the mean of the per-replica gradients.  Checked against two single-process backward passes."""
     from net.loss import Loss

@@ -70,7 +70,7 @@ def test_blendedmvs_loader_items(tmp_path):
     assert np.array_equal(it["extrinsics"][3], it["extrinsics"][1])         # padded views repeat source 0
 
 
-def test_one_training_epoch_on_the_synthetic_dtu_train_set(tmp_path, monkeypatch):
+def test_one_training_epoch_on_the_synthetic_dtu_train_set(tmp_path, monkeypatch, rehearsal_backend):
     """load -> DataLoader collate -> CoreNet.train() -> Loss -> FlatBucket -> Adam step -> checkpoint, as train.py wires them."""
     import importlib.util
     import torch.optim as optim
