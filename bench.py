@@ -24,6 +24,7 @@ Rank 0 prints ONE JSON line; it also carries
 The headline `value` / `config` are the eval figures for every N; the blocks above are extra keys of the same line.
 """
 import argparse
+import math
 import json
 import os
 import sys
@@ -397,8 +398,12 @@ def primary_training_figure(rec):
         rec["whole_step_frac_of_fp32_mfma_peak"] = round(rec["mfma_algorithmic_gflop_per_step"] / g["ms_per_step"] / PEAK_FP32_MFMA_TFLOPS, 4)
     else:
         rec["mode"] = "launch by launch (the recorded-step variant did not run: see graph_replay)"
-    if "stock_pytorch_rocm_baseline" in rec:
-        rec["stock_pytorch_rocm_baseline"]["speedup"] = round(rec["stock_pytorch_rocm_baseline"]["ms_per_step"] / rec["ms_per_step"], 1)
+    if "stock_pytorch_rocm_baseline" in rec:      # like with like: the baseline is issued launch by launch, so is `eager`
+        sb = rec["stock_pytorch_rocm_baseline"]
+        sb["speedup"] = round(sb["ms_per_step"] / rec["eager"]["ms_per_step"], 1)
+        sb["speedup_note"] = "stock autograd (launch by launch) / HIP training kernels issued launch by launch (training.eager)"
+        if "ms_per_step" in g:
+            sb["speedup_vs_recorded_step"] = round(sb["ms_per_step"] / g["ms_per_step"], 1)
 
 
 def training_graph_child(steps, blocks):
@@ -596,6 +601,9 @@ def cfg5_scan_block(dev, in_flight, nviews=49, nsrc_model=4):
             "filter": {"us_per_view_wall": round(1e6 * t_filter / nviews, 1), "kernel_us_per_view": round(k_us, 1),
                        "kernel_gbs": round(k_bytes / (k_us * 1e-6) / 1e9, 1) if k_us else None,
                        "kernel_frac_of_hbm_peak": round(k_bytes / (k_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4) if k_us else None,
+                       # its real roof (profiles/r05_filter_pmc.md): 267 vector instructions per (pixel, source view) -- seven IEEE divides and a
+                       # sqrt that bit-exactness needs -- against the 1024 SIMD-32 units' issue rate at 2.4 GHz (78.6 T lane-ops/s)
+                       "kernel_frac_of_vector_issue_peak": round(267.0 * WIDTH * HEIGHT * 10 / (k_us * 1e-6) / (1024 * 32 * 2.4e9), 4) if k_us else None,
                        "algorithmic_bytes_per_view": round(k_bytes), "nsrc": 10, "final_mask_keeps": round(kept, 4),
                        "note": "depth maps are the model's own (random weights: no two views agree, so the masks are nearly empty and "
                                "the gathers incoherent); wall includes the host-side matrix set-up and mask conversions per view"},
@@ -749,9 +757,10 @@ def main():
                     help="items in flight on that many HIP streams (the eval driver's pipelining); 1 = strictly one at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--blocks", type=int, default=3,
+    ap.add_argument("--blocks", type=int, default=0,
                     help="the K-step timed block is repeated this many times (each one barrier + synchronize bracketed); the "
-                         "MEDIAN block is reported, all of them under `blocks_ms_per_step`")
+                         "MEDIAN block is reported, all of them and their spread under `blocks_ms_per_step`.  0 (default) = as many "
+                         "as it takes for >= 1 s of timed work in total, at least 3, at most 41 (the driver's --steps 20 is 0.08 s a block)")
     ap.add_argument("--rank-timeout", type=float, default=1500.0,
                     help="self-launched multi-rank runs (plain `python bench.py --gpus N`): seconds after which all ranks are stopped")
     ap.add_argument("--no-training", action="store_true", help="skip the BASELINE configs[2] training-step block (N=1: one GPU's step; "
@@ -772,7 +781,7 @@ def main():
     if args.train_graph_child:
         if not torch.cuda.device_count():
             raise SystemExit("bench.py needs an MI355X (no GPU visible)")
-        training_graph_child(args.train_steps, max(1, args.blocks))
+        training_graph_child(args.train_steps, min(3, max(1, args.blocks if args.blocks > 0 else 3)))
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -829,7 +838,10 @@ def main():
             one_step()
         pipe.drain()
         block_dts = []
-        for _ in range(max(1, args.blocks)):
+        n_blocks = args.blocks if args.blocks > 0 else 3
+        bi = 0
+        while bi < n_blocks:
+            bi += 1
             # one block = EXACTLY K steps bracketed by barrier + synchronize on both sides, max over ranks
             torch.cuda.synchronize()
             barrier()
@@ -847,13 +859,16 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 bdt = float(t.item())
             block_dts.append(bdt)
+            if args.blocks <= 0 and bi == 1:                 # auto: >= 1 s of timed work (every rank computes the same count from the max-over-ranks time)
+                n_blocks = min(41, max(3, int(math.ceil(1.0 / max(bdt, 1e-4)))) | 1)
         dt = sorted(block_dts)[len(block_dts) // 2]          # the median block
+        args.blocks = len(block_dts) if args.blocks <= 0 else args.blocks      # the other legs (serial view, training) take 3
         out = last["out"]
         # the same K steps strictly one at a time (latency view of the same work), rank 0 only, outside the timed region
         dt_serial = None
         if rank == 0 and args.in_flight > 1:
             ser = []
-            for _ in range(max(1, args.blocks)):
+            for _ in range(min(3, max(1, args.blocks))):
                 torch.cuda.synchronize()
                 ts = time.perf_counter()
                 for _ in range(args.steps):
@@ -874,13 +889,13 @@ def main():
         extra["cfg5_scan"] = cfg5_scan_block(dev, args.in_flight)
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_training:
-        training = training_block(dev, args.train_steps, max(1, args.blocks), args.train_stock_steps)
+        training = training_block(dev, args.train_steps, min(3, max(1, args.blocks)), args.train_stock_steps)
         if not args.no_train_graph:
-            training["graph_replay"] = training_graph(args.train_steps, max(1, args.blocks))
+            training["graph_replay"] = training_graph(args.train_steps, min(3, max(1, args.blocks)))
         primary_training_figure(training)
     if world > 1 and not args.no_training:
         barrier()                      # rank 0's profile pass is over: every rank enters the training leg together
-        training = training_ddp_block(dev, world, rank, args.train_steps, max(1, args.blocks))
+        training = training_ddp_block(dev, world, rank, args.train_steps, min(3, max(1, args.blocks)))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
     if rank == 0:
@@ -889,7 +904,8 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
                "items_in_flight": args.in_flight,
                "blocks_ms_per_step": {"all": [round(1e3 * b / args.steps, 3) for b in block_dts], "reported": "median",
-                                      "min": round(1e3 * min(block_dts) / args.steps, 3), "max": round(1e3 * max(block_dts) / args.steps, 3)},
+                                      "min": round(1e3 * min(block_dts) / args.steps, 3), "max": round(1e3 * max(block_dts) / args.steps, 3),
+                                      "spread_pct": round(100.0 * (max(block_dts) - min(block_dts)) / dt, 2), "timed_s": round(sum(block_dts), 3)},
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"DTU eval {WIDTH}x{HEIGHT} (1600x1200 cropped as load/dtueval.py:34), {VIEWS} views, "
                                       "3 cost-volume stages + x2 refine = 4 output scales, hypotheses (48,24,8), batch 1 per rank, "

@@ -282,7 +282,8 @@ def range_affine(x, lo, span, mode):
     x = _f32c(x)
     y = torch.empty_like(x)
     b = x.shape[0]
-    _abi("mdf_range_affine_fwd", (x.data_ptr(), _f32c(lo).data_ptr(), _f32c(span).data_ptr(), mode, y.data_ptr(), b, x.numel() // b, _stream(y),))
+    lo_c, span_c = _f32c(lo), _f32c(span)      # (locals: a converted copy must outlive the launch's enqueue)
+    _abi("mdf_range_affine_fwd", (x.data_ptr(), lo_c.data_ptr(), span_c.data_ptr(), mode, y.data_ptr(), b, x.numel() // b, _stream(y),))
     return y
 
 
@@ -502,8 +503,9 @@ def refine_tail(x, w1pack, w2, lo=None, span=None):
     b, h, w, c = x.shape
     assert c == 8 and x.is_contiguous() and tuple(w2.shape) == (1, 8, 3, 3)
     y = torch.empty((b, 2 * h, 2 * w), device=x.device, dtype=torch.float32)
-    _abi("mdf_refine_tail_fwd", (x.data_ptr(), w1pack.data_ptr(), _f32c(w2.detach()).data_ptr(), None if lo is None else _f32c(lo).data_ptr(),
-                                 None if span is None else _f32c(span).data_ptr(), y.data_ptr(), b, h, w, _stream(y),),
+    w2_c, lo_c, span_c = _f32c(w2.detach()), (None if lo is None else _f32c(lo)), (None if span is None else _f32c(span))
+    _abi("mdf_refine_tail_fwd", (x.data_ptr(), w1pack.data_ptr(), w2_c.data_ptr(), None if lo_c is None else lo_c.data_ptr(),
+                                 None if span_c is None else span_c.data_ptr(), y.data_ptr(), b, h, w, _stream(y),),
          tag=f"8->32->1 {h}x{w}x{b}", work={"flops": 2.0 * 72 * (32 + 4) * b * h * w, "bytes": 4.0 * (x.numel() + y.numel()), "bound": "mfma"})
     return y
 
@@ -595,7 +597,8 @@ def refine_head(depth, lo, span, weight):
     assert tuple(weight.shape) == (8, 1, 3, 3)
     d, wt = _f32c(depth), _f32c(weight.detach())
     y = torch.empty((b, h, w, 8), device=depth.device, dtype=torch.float32)
-    _abi("mdf_refine_head_fwd", (d.data_ptr(), None if lo is None else _f32c(lo).data_ptr(), None if span is None else _f32c(span).data_ptr(),
+    lo_c, span_c = (None if lo is None else _f32c(lo)), (None if span is None else _f32c(span))
+    _abi("mdf_refine_head_fwd", (d.data_ptr(), None if lo_c is None else lo_c.data_ptr(), None if span_c is None else span_c.data_ptr(),
                                  wt.data_ptr(), y.data_ptr(), b, h, w, _stream(y)), tag=f"range + 1->8 k3 {h}x{w}x{b}",
          work={"bytes": 4.0 * (d.numel() + y.numel()), "bound": "hbm"})
     return y

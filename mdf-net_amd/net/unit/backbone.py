@@ -80,7 +80,8 @@ class FPN_4Scales(nn.Module):
             t3 = seq(self.conv23, t2)
             t4 = seq(self.conv34, t3)
             hd = self._composed_heads()
-            if _HEADS and (hd["y4"][2], hd["y4"][3], hd["a4"][3], hd["c4"][3], hd["y3"][2]) == (64, 64, 32, 16, 32):
+            if _HEADS and (hd["y4"][2], hd["y4"][3], hd["a4"][3], hd["c4"][3], hd["y3"][2], hd["y3"][3], hd["c3"][2], hd["c3"][3]) == (64, 64, 32, 16, 32, 32, 32, 16) \
+                    and tuple(t3.shape[1:3]) == (2 * t4.shape[1], 2 * t4.shape[2]):       # the full tuple the kernel is built for: any other pyramid takes the per-head branch
                 # the three heads of t4 and the two of t3 as one launch each: the input is streamed once (conv1x1_heads_kernel)
                 y4, a4, c4 = ops.conv1x1_heads(t4, [hd["y4"], hd["a4"], hd["c4"]], [None, None, None])
                 y3, c3 = ops.conv1x1_heads(t3, [hd["y3"], hd["c3"]], [a4, c4])    # out3(up(t4) + lat3(t3)); out2(up(t4) + lat3(t3)) @1/4

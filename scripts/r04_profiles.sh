@@ -1,8 +1,8 @@
 # round-4 measurement artefacts (run on the GPU box through gpurun; outputs under gpurun_out/, summaries copied to profiles/ afterwards
 # by scripts/r04_collect.sh here).  Every rocprofv3 command profiles `python3 <script>` directly (no env / shell hop behind `--`).
-cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
 set -e
+cd "${GRAFT_REPO_ROOT:?}"
+export TMPDIR=/tmp
 EVAL="bench.py --in-flight 1 --steps 20 --warmup 3 --blocks 1 --no-cpu-baseline --no-profile --no-training --no-extra-configs"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r4_prof_eval -- python3 $EVAL > gpurun_out/r4_prof_eval.log 2>&1
 export MDF_TRAIN_NOPROFILE=1 MDF_TRAIN_STEPS=20

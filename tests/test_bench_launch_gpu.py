@@ -39,9 +39,9 @@ def test_bench_extra_config_blocks_at_reduced_size():
     import torch
     sys.path[:0] = [ROOT]
     os.environ["MDF_BENCH_SIZE"] = "320x256x5"
+    import importlib
+    import bench
     try:
-        import importlib
-        import bench
         importlib.reload(bench)
         dev = torch.device("cuda", 0)
         r = bench.cfg5_scan_block(dev, 2, nviews=12)
@@ -54,3 +54,4 @@ def test_bench_extra_config_blocks_at_reduced_size():
         assert c4["7_views"]["views_per_s"] > 0 and c4["11_views"]["views_per_s"] > 0
     finally:
         os.environ.pop("MDF_BENCH_SIZE", None)
+        importlib.reload(bench)        # back to the full-size constants for any later importer in this process
