@@ -947,6 +947,8 @@ extern "C" int mdf_release_stream(void* stream) {
 
 int mdf_wino3d_dispatch(const float* x, const float* wpack_wino, const float* alpha, const float* beta, const float* res, float res_scale,
                         float* y, int B, int D, int H, int W, int Cin, int Cout, int relu, void* stream);   // wino3d.hip
+int mdf_wino2d_dispatch(const float* x, const float* wpack_wino, const float* alpha, const float* beta, const float* res, float res_scale,
+                        float* y, int B, int H, int W, int Cin, int Cout, int relu, void* stream);          // wino2d.hip
 
 int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
                           float res_scale, const float* res_up, float* y, int B, int D, int H, int W, int Cin, int Cin_mem, int Cout, int KD,
@@ -994,6 +996,14 @@ int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha
     const bool use_w3 = [] { const char* e = getenv("MDF_CONV_WINO3D"); return e ? atoi(e) != 0 : true; }();   // dev A/B and the equality test (read per call)
     if (use_wg && use_w3 && !stat && KD == 3 && KHW == 3 && stride == 1 && Cin == Cin_mem && !res_up && !shuffle2 && Cout % 16 == 0) {
       const int rc = mdf_wino3d_dispatch(x, wpack + (size_t)27 * Cin * Cout, alpha, beta, res, res_scale, y, B, D, H, W, Cin, Cout, relu, stream);
+      if (rc != MDF_EUNSUPPORTED) return rc;
+    }
+  }
+  // 2-D 3x3 stride-1 layers of the feature pyramid, eval: wino2d.hip (same fragments as LDS_CASE_WG2 below)
+  {
+    const bool use_w2 = [] { const char* e = getenv("MDF_CONV_WINO2D"); return e ? atoi(e) != 0 : true; }();   // dev A/B and the equality test (read per call)
+    if (use_wg && use_w2 && !stat && KD == 1 && KHW == 3 && stride == 1 && Cin == Cin_mem && !res_up && !shuffle2 && !planar_in && D == 1) {
+      const int rc = mdf_wino2d_dispatch(x, wpack + (size_t)9 * Cin * (((Cout + 15) / 16) * 16), alpha, beta, res, res_scale, y, B, H, W, Cin, Cout, relu, stream);
       if (rc != MDF_EUNSUPPORTED) return rc;
     }
   }

@@ -171,6 +171,28 @@ def test_conv2d_pair_equals_the_two_layers(shape):
     np.testing.assert_allclose(ops.from_nhwc(one).cpu().numpy(), exp.numpy(), rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("cin", [16, 32, 64])
+@pytest.mark.parametrize("shape", [(1, 130, 201), (2, 125, 131), (1, 8, 32), (1, 3, 5), (3, 17, 40), (1, 61, 700)])
+def test_wino2d_kernel_equals_the_conv_lds_winograd_form(cin, shape, monkeypatch):
+    """wino2d.hip (pinned accumulators, lane-constant fill offsets, one transform cluster per chunk, tiles a whole step ahead) keeps
+    conv_lds.hip's accumulation order per output: bit-identical with and without the epilogue (BN, ReLU, scaled residual), over ragged
+    tiles, batch 2 / 3 (image changes inside a block's run of tiles), images smaller than one tile.  16 channels: MDF_WINO2D_16=1 (that
+    layer stays on conv_lds.hip's form by default, it is memory-bound)."""
+    b, h, w = shape
+    g = torch.Generator().manual_seed(cin * 3 + h * w)
+    x = ops.to_nhwc(torch.randn(b, cin, h, w, generator=g).to(DEV))
+    wp = ops.pack_conv2d_weight((torch.randn(cin, cin, 3, 3, generator=g) / np.sqrt(9 * cin)).to(DEV))
+    alpha, beta = (torch.rand(cin, generator=g) + 0.5).to(DEV), (torch.rand(cin, generator=g) * 0.4 - 0.2).to(DEV)
+    res = torch.randn(b, h, w, cin, generator=g).to(DEV)
+    monkeypatch.setenv("MDF_WINO2D_16", "1")
+    out = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("MDF_CONV_WINO2D", v)
+        out[v] = (ops.conv2d_nhwc(x, wp, cin, cin, 3, 1, alpha, beta, True, res, 0.1), ops.conv2d_nhwc(x, wp, cin, cin, 3, 1))
+    assert torch.equal(out["0"][0], out["1"][0]) and torch.equal(out["0"][1], out["1"][1])
+    assert not torch.isnan(out["1"][0]).any()
+
+
 @pytest.mark.parametrize("shape", [(1, 8, 16), (2, 13, 37), (1, 40, 136), (3, 9, 131), (2, 64, 62), (1, 65, 63), (1, 200, 190), (1, 592, 800)])
 def test_res_block_pair_equals_the_two_layers(shape):
     """mdf_conv2d_res_pair_fwd (res_pair.hip: a Res block of the refinement net, x + 0.1 * conv(relu(conv(x))), in one launch with
