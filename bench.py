@@ -224,7 +224,25 @@ def profile_pass(model, inputs, steps=3):
         with torch.no_grad():
             model(*inputs)
     recs, info = bracketed_launches(fwd, steps)
+    info["per_kernel"] = per_kernel_table(recs, steps)
     return family_table(recs, steps, lambda n, t: None if n == "mdf_conv3d_pack_weights" else family(n, t)), info
+
+
+def per_kernel_table(recs, steps):
+    """Per __global__ function (the kernel each ABI entry enqueued last, mdf_last_launch): launches, bracketed time and the
+    ALGORITHMIC bytes / flops of the calls it served, per step -- what scripts/summarize_traffic.py sets beside the PMC bytes of the
+    same kernel (wasted traffic attributable per kernel)."""
+    tab = {}
+    for n, tag, ms, work in recs:
+        k = work.get("kernel") or n
+        t = tab.setdefault(k, {"launches": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0})
+        t["launches"] += 1
+        t["ms"] += ms
+        t["bytes"] += float(work.get("bytes", 0.0))
+        t["flops"] += float(work.get("flops", 0.0))
+    return {k: {"launches_per_step": round(v["launches"] / steps, 1), "ms_per_step": round(v["ms"] / steps, 4),
+                "algorithmic_mb_per_step": round(v["bytes"] / steps / 1e6, 2), "algorithmic_gflop_per_step": round(v["flops"] / steps / 1e9, 2)}
+            for k, v in sorted(tab.items(), key=lambda kv: -kv[1]["ms"])}
 
 
 def _newest_profile(suffix):
@@ -927,7 +945,7 @@ def main():
                 ms = sum(k["ms_per_step"] for k in mf)
                 gf = sum(k["algorithmic_gflop_per_step"] for k in mf)
                 ach = gf / ms
-                rec["roofline"] = {"kernel": "fp32-MFMA implicit-GEMM conv family (conv_lds_kernel + conv3d_kernel + convtr_all_kernel + conv_pair_kernel + res_pair_kernel + conv1x1_kernel + conv1x1_heads_kernel + refine_tail_kernel + prob_fused_kernel)", "bound": "mfma",
+                rec["roofline"] = {"kernel": "fp32-MFMA implicit-GEMM conv family (conv_lds_kernel + wino3d_kernel + wino2d_kernel + conv3d_kernel + convtr_all_kernel + conv_pair_kernel + res_pair_kernel + conv1x1_kernel + conv1x1_heads_kernel + refine_tail_kernel + prob_fused_kernel)", "bound": "mfma",
                                    "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                                    "traffic": (round(traffic["mfma_conv"]["hbm_bytes_per_forward"]) if "mfma_conv" in traffic else None),

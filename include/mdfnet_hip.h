@@ -43,6 +43,9 @@ extern "C" {
 
 int mdf_abi_version(void);
 const char* mdf_last_error(void);
+/* Name of the __global__ function the calling thread's most recent entry enqueued last ("" before the first launch): lets a
+ * profiler attribute an entry's algorithmic bytes / flops to the kernel that served it (bench.py: roofline.per_kernel).      */
+const char* mdf_last_launch(void);
 /* The conv kernels keep one device-side work-item counter pair per HIP stream that has launched them (128 slots per
  * process; launches on one stream are ordered, launches on different streams may overlap).  A long-lived process that
  * destroys streams hands their slots back with this call (before hipStreamDestroy, with no conv launch of this library

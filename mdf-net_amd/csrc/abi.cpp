@@ -9,7 +9,10 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof g_err, fmt, ap);
   va_end(ap);
 }
+static thread_local const char* g_last_launch = "";
+void note_launch(const char* kernel) { g_last_launch = kernel; }
 }  // namespace mdf
 
 extern "C" int mdf_abi_version(void) { return MDF_ABI_VERSION; }
 extern "C" const char* mdf_last_error(void) { return mdf::g_err; }
+extern "C" const char* mdf_last_launch(void) { return mdf::g_last_launch; }

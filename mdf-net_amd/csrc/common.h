@@ -8,6 +8,7 @@
 namespace mdf {
 
 void set_error(const char* fmt, ...);
+void note_launch(const char* kernel);     // abi.cpp: the kernel the calling thread enqueued last (mdf_last_launch)
 
 inline int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 inline int fail(int code, const char* fmt, ...) {
@@ -21,6 +22,7 @@ inline int fail(int code, const char* fmt, ...) {
 }
 
 inline int check_launch(const char* what) {
+  note_launch(what);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MDF_EHIP, "%s: %s", what, hipGetErrorString(e));
   return MDF_OK;

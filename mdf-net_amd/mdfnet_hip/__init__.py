@@ -27,6 +27,7 @@ c_i64 = ctypes.c_int64
 SIGNATURES = {
     "mdf_abi_version": (c_int, []),
     "mdf_last_error": (ctypes.c_char_p, []),
+    "mdf_last_launch": (ctypes.c_char_p, []),
     "mdf_release_stream": (c_int, [c_fp]),
     "mdf_homo_warp_fwd": (c_int, [c_fp, c_int, c_fp, c_fp, c_int, c_fp, c_int] + [c_int] * 5 + [c_fp]),
     "mdf_warp_corner_indices": (c_int, [c_fp, c_fp, c_int, c_fp] + [c_int] * 4 + [c_fp]),

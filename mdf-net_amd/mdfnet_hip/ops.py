@@ -57,7 +57,7 @@ def _abi(name, args, tag="", work=None):
     e0.record()
     check(fn(*args), name)
     e1.record()
-    _prof.append((name, tag, e0, e1, work or {}))
+    _prof.append((name, tag, e0, e1, dict(work or {}, kernel=lib().mdf_last_launch().decode())))
 
 
 class _single_thread:
