@@ -284,6 +284,12 @@ int mdf_conv3d_wgrad_partial(const float* small_, const float* big, float* dw, f
 int mdf_conv2d_wgrad_partial(const float* small_, const float* big, float* dw, float* workspace, int B, int Hs, int Ws, int A, int Bc,
                              int ksize, int stride, int* nslab_out, void* stream);
 int mdf_wgrad_sum_batch(const float* const* slabs, float* const* outs, const int* nslabs, const int* ns, int njobs, void* stream);
+/* Deferred weight-gradient launches.  Between mdf_wgrad_batch_begin() and mdf_wgrad_batch_flush(stream) the calling thread's
+ * mdf_conv3d_wgrad_partial / mdf_conv2d_wgrad_partial calls that take the LDS-staged kernel are RECORDED (operands, workspace and dw
+ * must stay valid until the flush; *nslab_out is final at once); the flush launches them grouped by kernel instantiation, the layers
+ * of a group as ONE launch (job table in the kernel arguments).  Results are those of the separate launches bit for bit.       */
+int mdf_wgrad_batch_begin(void);
+int mdf_wgrad_batch_flush(void* stream);
 /* (input gradients of these layers are mdf_conv3d_fwd with re-packed weights: a stride-1 conv with flipped taps and
  *  swapped channels, the transposed conv for a stride-2 conv and vice versa.) */
 

@@ -10,6 +10,7 @@
 //
 //     dw[a][b][z][kh][kw] (+)= sum_o small[o][a] * big[s*o + tap - pad][b]       z = blockIdx.z (kd in 3-D, kh in 2-D)
 #include <cstdlib>
+#include <vector>
 #include "common.h"
 
 namespace {
@@ -48,15 +49,19 @@ struct WgradLdsParams {
 // is 54-108 MFMAs per wave between two barriers and a commit, and its 6 chunks split unevenly over 4 waves.  TH rows share their
 // staged `big` rows (3-D, stride 1: TH + 2 rows of a depth plane serve the 3 kernel rows of TH output rows instead of 3 TH) and
 // amortise the per-tile fixed cost TH times.
+// VB: the block's coordinates in its launch's (gx, gy, gz) grid -- the hardware's for a one-layer launch, computed from the job table
+// for a batched launch (wgrad_lds_batch_kernel)
+struct VBlock { int bx, by, bz, gx, gy, gz; };
+
 template <int KH, int KW, bool MODE3D, int R, int TH>
-__global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) {
+__device__ __forceinline__ void wgrad_lds_body(const WgradLdsParams& p, const VBlock vb) {
   constexpr int NT = (R == 0) ? KW : (R == 1 ? 2 : 1);     // MFMA chains (accumulators) per kernel row
   constexpr int NBR = MODE3D ? TH + KH - 1 : TH;           // staged rows of `big` (3-D with TH > 1: stride 1 only, host-checked)
   constexpr int TSTEP = (R == 0) ? 1 : R + 1;              // first tap of chain ts: ts * TSTEP
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if (p.zero_out) {
-    const int nblk = gridDim.x * gridDim.y * gridDim.z;
-    const int bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int nblk = vb.gx * vb.gy * vb.gz;
+    const int bid = (vb.bz * vb.gy + vb.by) * vb.gx + vb.bx;
     for (int i = bid * 256 + threadIdx.x; i < p.zero_n; i += nblk * 256) p.zero_out[i] = 0.f;
   }
   const int s = p.stride;
@@ -68,7 +73,7 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, c16 = lane & 15;
   const int pairs_per_block = 4 / p.split;
-  const int pair = blockIdx.y * pairs_per_block + wave / p.split;
+  const int pair = vb.by * pairs_per_block + wave / p.split;
   const int part = wave % p.split;
   const int na = pair / p.NB, nb = pair % p.NB;
   const int a = na * 16 + c16, bcol = nb * 16 + c16;
@@ -76,7 +81,7 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) 
   // operand lanes: (shift, channel) when packed; clamped lanes feed tile rows / columns that are never stored
   const int sa = (R > 0 && p.pa > 1) ? min(c16 / p.A, p.pa - 1) : 0, sb = (R > 0 && p.pb > 1) ? min(c16 / p.Bc, p.pb - 1) : 0;
   const int ac = (R > 0 && p.pa > 1) ? c16 % p.A : min(a, p.A - 1), bc = (R > 0 && p.pb > 1) ? c16 % p.Bc : min(bcol, p.Bc - 1);
-  const int z = blockIdx.z;
+  const int z = vb.bz;
 
   f32x4 acc[KH * NT];
 #pragma unroll
@@ -156,12 +161,12 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) 
   const float* la = sm_small + (q + hal - sa) * p.AS + ac;
   const float* lb = sm_big + (q * s + sb) * p.BS + bc;
 
-  long long tile = blockIdx.x;
+  long long tile = vb.bx;
   if (tile < p.n_tiles) stage(tile);
   while (tile < p.n_tiles) {
     commit();
     __syncthreads();
-    const long long next = tile + gridDim.x;
+    const long long next = tile + vb.gx;
     if (next < p.n_tiles) stage(next);         // in flight during the MFMAs below
     for (int cq = 0; cq < nchunk; ++cq) {
       const int c = part + cq * p.split;
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) 
     __syncthreads();
   }
   if (part == 0 && b_ok) {
-    float* out = p.slab + (long long)blockIdx.x * p.A * p.Bc * p.ntaps_total;
+    float* out = p.slab + (long long)vb.bx * p.A * p.Bc * p.ntaps_total;
     if constexpr (R == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -242,6 +247,34 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) 
   }
 }
 
+template <int KH, int KW, bool MODE3D, int R, int TH>
+__global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) {
+  wgrad_lds_body<KH, KW, MODE3D, R, TH>(p, VBlock{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y, (int)gridDim.z});
+}
+
+// The weight gradients of SEVERAL layers in one launch (the ~20 small layers of a cfg3 step paid 12-15 us of
+// fixed cost each as launches of their own).  The job table travels by value (kernel arguments, <= 4 KB): block b belongs to the
+// job j with first[j] <= b < first[j+1] and takes the place (bx, by, bz) of that job's own grid.
+constexpr int kWgradBatchMax = 22;
+struct WgradBatch {
+  int njobs;
+  int first[kWgradBatchMax + 1];
+  int gx[kWgradBatchMax], gy[kWgradBatchMax];
+  WgradLdsParams job[kWgradBatchMax];
+};
+static_assert(sizeof(WgradBatch) <= 4096, "the job table is a kernel argument");
+
+template <int KH, int KW, bool MODE3D, int R, int TH>
+__global__ __launch_bounds__(256) void wgrad_lds_batch_kernel(const WgradBatch tb) {
+  const int b = blockIdx.x;
+  int j = 0;
+  while (j + 1 < tb.njobs && b >= tb.first[j + 1]) ++j;           // (wave-uniform: scalar unit)
+  const int local = b - tb.first[j];
+  const int gx = tb.gx[j], gy = tb.gy[j];
+  const int gz = (tb.first[j + 1] - tb.first[j]) / (gx * gy);
+  wgrad_lds_body<KH, KW, MODE3D, R, TH>(tb.job[j], VBlock{local % gx, (local / gx) % gy, local / (gx * gy), gx, gy, gz});
+}
+
 // voxel stride (floats) such that q and q+1 (voxels `step` apart) land 16 banks apart: stride*step = 16 (mod 32)
 int padded_stride(int C, int step) {
   if (C <= 8) return C;                         // 8 (or 4) valid lanes per voxel: q groups cannot collide within 32 banks
@@ -250,7 +283,74 @@ int padded_stride(int C, int step) {
   return C + 4;
 }
 
+// ---- deferred launches (mdf_wgrad_batch_begin / _flush): the calling thread's dispatches are recorded instead of launched
+struct PendingJob { int key; WgradLdsParams p; int gx, gy, gz; size_t lds; };
+thread_local bool g_batching = false;
+thread_local std::vector<PendingJob>* g_pending = nullptr;
+
+template <int KH, int KW, bool MODE3D, int R, int TH>
+int launch_batch(const WgradBatch& tb, int blocks, size_t lds, hipStream_t st) {
+  static bool attr_done[64] = {};
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  if (dev_id < 0 || dev_id >= 64 || !attr_done[dev_id]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lds_batch_kernel<KH, KW, MODE3D, R, TH>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return mdf::fail(MDF_EHIP, "hipFuncSetAttribute(dynamic LDS): %s", hipGetErrorString(e));
+    if (dev_id >= 0 && dev_id < 64) attr_done[dev_id] = true;
+  }
+  hipLaunchKernelGGL((wgrad_lds_batch_kernel<KH, KW, MODE3D, R, TH>), dim3(blocks), dim3(256), lds, st, tb);
+  return mdf::check_launch("wgrad_lds_batch_kernel");
+}
+
+// key = ((KH * 8 + KW) * 2 + MODE3D) * 4 + R) * 8 + TH
+constexpr int wg_key(int kh, int kw, bool m3, int r, int th) { return ((((kh * 8 + kw) * 2 + (m3 ? 1 : 0)) * 4 + r) * 8) + th; }
+
+int launch_batch_key(int key, const WgradBatch& tb, int blocks, size_t lds, hipStream_t st) {
+#define WGB(KHv, KWv, M3, Rv, THv) if (key == wg_key(KHv, KWv, M3, Rv, THv)) return launch_batch<KHv, KWv, M3, Rv, THv>(tb, blocks, lds, st);
+#define WGB3(KHv, KWv, M3, Rv) WGB(KHv, KWv, M3, Rv, 1) WGB(KHv, KWv, M3, Rv, 2) WGB(KHv, KWv, M3, Rv, 4)
+  WGB3(3, 3, true, 2) WGB3(3, 3, true, 1) WGB3(3, 3, true, 0) WGB3(1, 3, false, 2) WGB3(1, 3, false, 1) WGB3(1, 3, false, 0) WGB3(1, 5, false, 0) WGB3(1, 1, false, 0)
+#undef WGB3
+#undef WGB
+  return mdf::fail(MDF_EUNSUPPORTED, "wgrad batch: no kernel for key %d", key);
+}
+
 }  // namespace
+
+extern "C" int mdf_wgrad_batch_begin(void) {
+  if (!g_pending) g_pending = new std::vector<PendingJob>();
+  g_pending->clear();
+  g_batching = true;
+  return MDF_OK;
+}
+
+extern "C" int mdf_wgrad_batch_flush(void* stream) {
+  g_batching = false;
+  if (!g_pending || g_pending->empty()) return MDF_OK;
+  std::vector<PendingJob> jobs;
+  jobs.swap(*g_pending);
+  std::vector<char> done(jobs.size(), 0);
+  for (size_t i = 0; i < jobs.size(); ++i) {
+    if (done[i]) continue;
+    WgradBatch tb{};
+    int blocks = 0;
+    size_t lds = 0;
+    for (size_t k = i; k < jobs.size() && tb.njobs < kWgradBatchMax; ++k) {
+      if (done[k] || jobs[k].key != jobs[i].key) continue;
+      const PendingJob& jb = jobs[k];
+      tb.first[tb.njobs] = blocks;
+      tb.gx[tb.njobs] = jb.gx; tb.gy[tb.njobs] = jb.gy;
+      tb.job[tb.njobs] = jb.p;
+      blocks += jb.gx * jb.gy * jb.gz;
+      if (jb.lds > lds) lds = jb.lds;
+      ++tb.njobs;
+      done[k] = 1;
+    }
+    tb.first[tb.njobs] = blocks;
+    if (int rc = launch_batch_key(jobs[i].key, tb, blocks, lds, (hipStream_t)stream)) return rc;
+  }
+  return MDF_OK;
+}
 
 // returns MDF_EUNSUPPORTED when the shape has no LDS instantiation (the caller falls back to the direct kernels)
 int mdf_wgrad_lds_dispatch(const float* small_, const float* big, float* workspace, int* gx_io, int B, int Ds, int Hs, int Ws, int A, int Bc,
@@ -323,6 +423,10 @@ int mdf_wgrad_lds_dispatch(const float* small_, const float* big, float* workspa
   hipStream_t st = (hipStream_t)stream;
 #define WG_LAUNCH_TH(KHv, KWv, M3, Rv, THv)                                                                               \
   {                                                                                                                        \
+    if (g_batching) {       /* recorded: launched by mdf_wgrad_batch_flush together with the other layers of this instantiation */ \
+      g_pending->push_back(PendingJob{wg_key(KHv, KWv, M3, Rv, THv), p, (int)grid.x, (int)grid.y, (int)grid.z, lds});       \
+      return MDF_OK;                                                                                                       \
+    }                                                                                                                      \
     static bool attr_done[64] = {};                                                                                        \
     int dev_id = 0;                                                                                                        \
     (void)hipGetDevice(&dev_id);                                                                                           \

@@ -70,6 +70,8 @@ SIGNATURES = {
     "mdf_conv3d_wgrad_partial": (c_int, [c_fp] * 4 + [c_int] * 7 + [ctypes.POINTER(c_int), c_fp]),
     "mdf_conv2d_wgrad_partial": (c_int, [c_fp] * 4 + [c_int] * 7 + [ctypes.POINTER(c_int), c_fp]),
     "mdf_wgrad_sum_batch": (c_int, [ctypes.POINTER(c_fp), ctypes.POINTER(c_fp), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int, c_fp]),
+    "mdf_wgrad_batch_begin": (c_int, []),
+    "mdf_wgrad_batch_flush": (c_int, [c_fp]),
     "mdf_conv2d_wgrad_workspace": (c_i64, [c_int] * 6),
     "mdf_conv2d_wgrad": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp]),
     "mdf_pack_job_bytes": (c_i64, []),

@@ -32,7 +32,7 @@ KERNEL_FAMILY = {
     "agg_prepare_kernel": CONTROL, "agg_finalize_kernel": CONTROL, "agg_bwd_finalize_kernel": WARP_SCATTER,
     # wgrad.hip / wgrad_lds.hip
     "wgrad_kernel": WGRAD, "wgrad_a1_kernel": WGRAD, "wgrad_a1_valu_kernel": WGRAD, "wgrad2d_kernel": WGRAD,
-    "wgrad_lds_kernel": WGRAD, "slab_sum_kernel": WGRAD, "slab_sum_batch_kernel": WGRAD,
+    "wgrad_lds_kernel": WGRAD, "wgrad_lds_batch_kernel": WGRAD, "slab_sum_kernel": WGRAD, "slab_sum_batch_kernel": WGRAD,
     # bn_train.hip
     "bn_reduce_kernel": BN, "bn_finalize_kernel": BN, "bn_relu_apply_kernel": BN, "bn_finalize_apply_kernel": BN,
     "bn_relu_bwd_kernel": BN,

@@ -14,7 +14,7 @@ import os as _os
 
 import torch
 
-from . import lib
+from . import lib, check
 from . import ops
 from .ops import _abi, _f32c, _need_gpu, _stream, _src_array, _hypos_arg
 
@@ -134,6 +134,7 @@ def bn_relu_backward(dz, y, aux, gamma, n, c, groups=1, pool=None, red=None):
 # (it would ADD an unfinished gradient into an existing .grad).  The pending list holds the gradient's ADDRESS, not the tensor: a
 # second reference would make AccumulateGrad clone it instead of taking it (59 copies per step, and of unfinished data).
 DEFER_WGRAD_SUMS = bool(int(_os.environ.get("MDF_WGRAD_DEFER", "1")))      # dev A/B
+BATCH_WGRAD = DEFER_WGRAD_SUMS and bool(int(_os.environ.get("MDF_WGRAD_BATCH", "1")))   # dev A/B: the LAUNCHES deferred too and batched (mdf_wgrad_batch_flush)
 _PENDING_SUMS = {}          # device index -> [streams the partial tiles were launched on, [(work, dw, nslab, n), ...]]
 
 
@@ -152,13 +153,27 @@ def sum_wgrad_jobs(jobs):
 
 def _flush_wgrad_sums(dev_index):
     ent = _PENDING_SUMS.pop(dev_index, None)
-    if not ent or not ent[1]:
+    if not ent or not (ent[1] or ent[2]):
         return
-    streams, jobs = ent
+    streams, jobs, deferred = ent
     cur = torch.cuda.current_stream(torch.device("cuda", dev_index))
     for st in streams:          # partial tiles may have been launched on other streams: join them
         if st != cur:
             cur.wait_stream(st)
+    if deferred:
+        # the weight gradients whose LAUNCH was deferred too (BATCH_WGRAD): recorded by the library, then launched grouped by
+        # kernel instantiation -- the ~45 small layers of a cfg3 step as a handful of launches (mdf_wgrad_batch_flush)
+        lib().mdf_wgrad_batch_begin()
+        flops = nbytes = 0.0
+        try:
+            for fn in deferred:
+                job, fl, by = fn()
+                jobs.append(job)
+                flops += fl
+                nbytes += by
+        finally:
+            _abi("mdf_wgrad_batch_flush", (deferred[0].stream,), tag=f"{len(deferred)} weight gradients",
+                 work={"flops": flops, "bytes": nbytes, "bound": "mfma"})
     sum_wgrad_jobs(jobs)
 
 
@@ -190,17 +205,37 @@ def _sum_later(work, dw, nslab, n, param):
     # gradient yet and without tensor hooks (a frozen weight's dw is dropped and its block re-used within the same backward pass; a
     # hooked or already-populated .grad gets a clone or a sum of the unfinished tensor) -- ADVICE r03
     defer = _can_defer(param)
-    ent = _PENDING_SUMS.get(dev)
-    if ent is None:
-        ent = _PENDING_SUMS[dev] = [[], []]
-        if defer:
-            torch.autograd.Variable._execution_engine.queue_callback(lambda d=dev: _flush_wgrad_sums(d))
+    ent = _pending_entry(dev, defer)
     cur = torch.cuda.current_stream(dw.device)
     if cur not in ent[0]:
         ent[0].append(cur)
     ent[1].append((work, dw.data_ptr(), nslab, n))
     if not defer:
         _flush_wgrad_sums(dev)
+
+
+def _pending_entry(dev, defer):
+    ent = _PENDING_SUMS.get(dev)
+    if ent is None:
+        ent = _PENDING_SUMS[dev] = [[], [], []]       # streams, sum jobs, deferred launches
+        if defer:
+            torch.autograd.Variable._execution_engine.queue_callback(lambda d=dev: _flush_wgrad_sums(d))
+    return ent
+
+
+class _DeferredWgrad:
+    """A weight-gradient launch put off to the end of the backward pass.  It keeps its OPERANDS and the workspace alive until then, and
+    only the ADDRESS of the gradient tensor: a second reference to dw would make AccumulateGrad clone the (still empty) tensor
+    instead of taking it over -- the rule of the deferred sums above."""
+
+    def __init__(self, entry, args_of, small, big, dw, work, flops):
+        self.entry, self.args_of, self.small, self.big, self.work, self.flops = entry, args_of, small, big, work, flops
+        self.dw_ptr, self.dw_numel, self.stream = dw.data_ptr(), dw.numel(), _stream(dw)
+
+    def __call__(self):
+        nslab = ctypes.c_int(0)
+        check(getattr(lib(), self.entry)(*self.args_of(nslab)), self.entry)
+        return (self.work, self.dw_ptr, nslab.value, self.dw_numel), self.flops, 4.0 * (self.small.numel() + self.big.numel())
 
 
 def conv3d_wgrad(small, big, stride, out_shape, param=None):
@@ -214,6 +249,17 @@ def conv3d_wgrad(small, big, stride, out_shape, param=None):
     work = torch.empty(n, device=small.device, dtype=torch.float32)
     dw = torch.empty(out_shape, device=small.device, dtype=torch.float32)
     assert dw.numel() == a * bc * 27
+    if BATCH_WGRAD and _can_defer(param):
+        st = _stream(dw)
+        ent = _pending_entry(dw.device.index, True)
+        cur = torch.cuda.current_stream(dw.device)
+        if cur not in ent[0]:
+            ent[0].append(cur)
+        dwp = dw.data_ptr()         # (the closure must not capture dw itself)
+        ent[2].append(_DeferredWgrad("mdf_conv3d_wgrad_partial", lambda ns: (small.data_ptr(), big.data_ptr(), dwp, work.data_ptr(), b, ds, hs, ws,
+                                                                             a, bc, stride, ctypes.byref(ns), st),
+                                     small, big, dw, work, 2.0 * 27 * a * bc * b * ds * hs * ws))
+        return dw
     nslab = ctypes.c_int(0)
     _abi("mdf_conv3d_wgrad_partial", (small.data_ptr(), big.data_ptr(), dw.data_ptr(), work.data_ptr(), b, ds, hs, ws, a, bc, stride,
                                       ctypes.byref(nslab), _stream(dw)), tag=f"wgrad {a}x{bc} s{stride} {ds}x{hs}x{ws}",
@@ -518,6 +564,17 @@ def conv2d_wgrad(small, big, ksize, stride, out_shape, param=None, hold=None):
     n = lib().mdf_conv2d_wgrad_workspace(b, hs, ws, a, bc, ksize)
     work = torch.empty(n, device=small.device, dtype=torch.float32)
     dw = torch.empty((a, bc, ksize, ksize), device=small.device, dtype=torch.float32)
+    if BATCH_WGRAD and hold is None and tuple(out_shape) == tuple(dw.shape) and _can_defer(param):
+        st = _stream(dw)
+        ent = _pending_entry(dw.device.index, True)
+        cur = torch.cuda.current_stream(dw.device)
+        if cur not in ent[0]:
+            ent[0].append(cur)
+        dwp = dw.data_ptr()         # (the closure must not capture dw itself)
+        ent[2].append(_DeferredWgrad("mdf_conv2d_wgrad_partial", lambda ns: (small.data_ptr(), big.data_ptr(), dwp, work.data_ptr(), b, hs, ws, a, bc,
+                                                                             ksize, stride, ctypes.byref(ns), st),
+                                     small, big, dw, work, 2.0 * ksize * ksize * a * bc * b * hs * ws))
+        return dw
     nslab = ctypes.c_int(0)
     _abi("mdf_conv2d_wgrad_partial", (small.data_ptr(), big.data_ptr(), dw.data_ptr(), work.data_ptr(), b, hs, ws, a, bc, ksize, stride,
                                       ctypes.byref(nslab), _stream(dw)), tag=f"wgrad2d {a}x{bc} k{ksize}s{stride} {hs}x{ws}x{b}",

@@ -206,6 +206,83 @@ def test_fused_bn_sums_equal_the_separate_passes(stage, seeded_sd, monkeypatch):
         assert _l2(a, b_) < 1e-4, (i, _l2(a, b_))
 
 
+@pytest.mark.parametrize("stage", [0, 2])
+def test_batched_weight_gradient_launches_equal_the_separate_ones(stage, monkeypatch):
+    """the weight-gradient launches of one backward pass, recorded and issued as one job-table launch per kernel
+    form (mdf_wgrad_batch_begin / mdf_wgrad_batch_flush), run the SAME block bodies on the same operands as the separate launches:
+    every gradient agrees to the rounding of the final sums, and the pass makes fewer launches."""
+    torch.manual_seed(5 + stage)
+    reg = build_model().Regular[stage].train().to(DEV)
+    g, d, h, w = ((32, 48, 12, 20), (16, 24, 48, 80), (8, 8, 96, 160))[stage]
+    cost = torch.rand(2, g, d, h, w, device=DEV)
+    hyp = ((425 + 510 * torch.rand(2, 1, h, w)) + torch.linspace(-20, 20, d).reshape(1, d, 1, 1)).to(DEV)
+    dd = torch.randn(2, h, w, device=DEV)
+    res, calls = {}, {}
+    for batched in (True, False):
+        monkeypatch.setattr(train_ops, "BATCH_WGRAD", batched)
+        ops.count_begin()
+        c = cost.clone().requires_grad_(True)
+        prob, depth = reg(c, hyp)
+        depth.backward(dd)
+        calls[batched] = ops.count_end()
+        res[batched] = [c.grad] + [p.grad.clone() for p in reg.parameters()]
+        reg.zero_grad()
+    assert calls[True].get("mdf_wgrad_batch_flush", 0) == 1 and calls[True].get("mdf_conv3d_wgrad_partial", 0) == 0, calls[True]
+    assert calls[False].get("mdf_wgrad_batch_flush", 0) == 0 and calls[False].get("mdf_conv3d_wgrad_partial", 0) >= 10, calls[False]
+    for i, (a, b_) in enumerate(zip(res[True], res[False])):      # (the partial tiles are bit-identical -- next test; their final sums meet
+        assert _l2(a, b_) < 1e-6, (i, _l2(a, b_))                 #  through fp32 atomics in arrival order: ~2e-7 between ANY two runs)
+
+
+def test_job_table_launch_writes_the_same_partial_tiles_as_separate_launches():
+    """The boundary itself: mdf_conv3d_wgrad_partial / mdf_conv2d_wgrad_partial between mdf_wgrad_batch_begin and mdf_wgrad_batch_flush
+    only RECORD their launch; the flush issues one job-table launch per kernel form.  The partial tiles in the workspaces (the
+    final sums meet through fp32 atomics in arrival order, so the tiles are the deterministic quantity) are bit-identical to the
+    ones separate launches write -- mixed shapes, strides, 2-D and 3-D, in one batch."""
+    import ctypes
+    from mdfnet_hip import lib, check
+    L = lib()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(3)
+    jobs = []
+    for (a, bc, s, b, ds, hs, ws) in [(8, 8, 1, 2, 8, 24, 40), (16, 8, 2, 2, 4, 12, 20), (16, 16, 1, 1, 6, 12, 20), (32, 16, 2, 1, 3, 6, 10),
+                                      (8, 16, 1, 1, 5, 7, 9)]:
+        small = torch.randn(b, ds, hs, ws, a, device=DEV)
+        big = torch.randn(b, ds * s, hs * s, ws * s, bc, device=DEV)
+        jobs.append(("mdf_conv3d_wgrad_partial", small, big, a * bc * 27, L.mdf_conv3d_wgrad_workspace(b, ds, hs, ws, a, bc),
+                     lambda sm, bg, dw, wk, ns, a=a, bc=bc, s=s, b=b, ds=ds, hs=hs, ws=ws: (sm, bg, dw, wk, b, ds, hs, ws, a, bc, s, ns, st)))
+    for (a, bc, k, s, b, hs, ws) in [(16, 8, 3, 1, 2, 48, 64), (32, 16, 5, 2, 1, 24, 32), (64, 32, 3, 1, 1, 12, 16)]:
+        small = torch.randn(b, hs, ws, a, device=DEV)
+        big = torch.randn(b, hs * s, ws * s, bc, device=DEV)
+        jobs.append(("mdf_conv2d_wgrad_partial", small, big, a * bc * k * k, L.mdf_conv2d_wgrad_workspace(b, hs, ws, a, bc, k),
+                     lambda sm, bg, dw, wk, ns, a=a, bc=bc, k=k, s=s, b=b, hs=hs, ws=ws: (sm, bg, dw, wk, b, hs, ws, a, bc, k, s, ns, st)))
+
+    def run(batched):
+        outs = []
+        if batched:
+            check(L.mdf_wgrad_batch_begin(), "mdf_wgrad_batch_begin")
+        for entry, small, big, n, nwork, args in jobs:
+            work = torch.full((nwork,), float("nan"), device=DEV)
+            dw = torch.full((n,), float("nan"), device=DEV)
+            ns = ctypes.c_int(0)
+            check(getattr(L, entry)(*args(small.data_ptr(), big.data_ptr(), dw.data_ptr(), work.data_ptr(), ctypes.byref(ns))), entry)
+            outs.append((work, dw, ns.value))
+        if batched:
+            torch.cuda.synchronize()
+            assert sum(bool(torch.isnan(w).all()) for w, _, _ in outs) >= 5     # the LDS-staged forms have not launched yet
+            check(L.mdf_wgrad_batch_flush(st), "mdf_wgrad_batch_flush")
+        torch.cuda.synchronize()
+        return outs
+    sep, bat = run(False), run(True)
+    for (entry, _, _, n, _, _), (w0, d0, n0), (w1, d1, n1) in zip(jobs, sep, bat):
+        assert n0 == n1 and n0 >= 1
+        assert torch.equal(w0[:n0 * n], w1[:n0 * n]) and not bool(torch.isnan(w0[:n0 * n]).any()), entry
+        assert torch.equal(d0.isnan(), d1.isnan()) and torch.equal(d0.nan_to_num(), d1.nan_to_num())   # (zeroed, or left for the sum)
+    # a flush with nothing recorded is a no-op; calls outside begin/flush launch at once again
+    check(L.mdf_wgrad_batch_flush(st), "mdf_wgrad_batch_flush")
+    again = run(False)
+    assert all(torch.equal(a[0][:a[2] * j[3]], b_[0][:b_[2] * j[3]]) for a, b_, j in zip(again, sep, jobs))
+
+
 @pytest.mark.parametrize("c,d", [(8, 8), (16, 24)])
 def test_prob_head_backward(c, d):
     torch.manual_seed(c)
@@ -581,7 +658,8 @@ def test_training_step_on_gpu_vs_reference_golden(golden, seeded_sd):
         loss.backward()
     finally:
         train_ops._abi = orig
-    assert {"mdf_warp_aggregate_vec_train", "mdf_conv3d_wgrad_partial", "mdf_wgrad_sum_batch", "mdf_bn_relu_bwd", "mdf_prob_conv_dgrad_stat"} <= set(used)
+    wgrad = "mdf_wgrad_batch_flush" if train_ops.BATCH_WGRAD else "mdf_conv3d_wgrad_partial"   # (one job-table launch per kernel form)
+    assert {"mdf_warp_aggregate_vec_train", wgrad, "mdf_wgrad_sum_batch", "mdf_bn_relu_bwd", "mdf_prob_conv_dgrad_stat"} <= set(used)
     bucket.allreduce_gradients()
     # Yardstick: the same step through the REFERENCE in float64 (tests/golden/train_tiny_f64.npz, oracle/gen_golden.py:gen_train_f64 runs
     # /root/reference's own model under reference_in_float64(); the oracle's float64 run agrees with it to <= 2e-15).  The reference's
