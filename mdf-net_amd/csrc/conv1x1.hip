@@ -30,6 +30,22 @@ struct P1 {
   int n_runs;           // runs of U tiles
 };
 
+// (image, row, column) of a run's pixels for the upsample-add: two 32-bit divisions per RUN (its first pixel) and a carry per tile, instead
+// of two 64-bit divisions per tile -- ~250 vector instructions beside the 4-12 MFMAs of a tile, which kept these HBM-bound layers at
+// 3.0-3.6 TB/s (r05; the launchers bound the pixel count to 31 bits)
+struct PixBase { int img, oh, ow; };
+__device__ __forceinline__ PixBase pix_base(unsigned first_px, int Ho, int Wo) {
+  const unsigned rr = first_px / (unsigned)Wo, img = rr / (unsigned)Ho;
+  return PixBase{(int)img, (int)(rr - img * (unsigned)Ho), (int)(first_px - rr * (unsigned)Wo)};
+}
+__device__ __forceinline__ void pix_at(const PixBase& b, int delta, int Ho, int Wo, int& img, int& oh, int& ow) {
+  img = b.img; oh = b.oh; ow = b.ow + delta;
+  while (ow >= Wo) {
+    ow -= Wo;
+    if (++oh == Ho) { oh = 0; ++img; }
+  }
+}
+
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void conv1x1_kernel(const P1 p) {
   constexpr int NCH = CIN / 16, NT = COUT / 16;
@@ -65,6 +81,8 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const P1 p) {
       for (int ch = 0; ch < NCH; ++ch)
         xb[u][ch] = (px < p.npx) ? *reinterpret_cast<const float4*>(p.x + px * CIN + ch * 16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    PixBase pb{0, 0, 0};
+    if (p.res_up) pb = pix_base((unsigned)run * (U * 16), p.Ho, p.Wo);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const long long px = px0 + u * 16;
@@ -81,14 +99,8 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const P1 p) {
       }
       if (px >= p.npx) continue;
       // (upsample-add: pixel -> (image, row, column) of the output grid)
-      int oh = 0, ow = 0;
-      long long img = 0;
-      if (p.res_up) {
-        const long long rr = px / p.Wo;
-        ow = (int)(px - rr * p.Wo);
-        oh = (int)(rr % p.Ho);
-        img = rr / p.Ho;
-      }
+      int oh = 0, ow = 0, img = 0;
+      if (p.res_up) pix_at(pb, u * 16 + n16, p.Ho, p.Wo, img, oh, ow);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int c0 = nt * 16 + 4 * q;
@@ -190,6 +202,7 @@ __global__ __launch_bounds__(256) void conv1x1_heads_kernel(const P1M p) {
       for (int ch = 0; ch < NCH; ++ch)
         xb[u][ch] = (px < p.npx) ? *reinterpret_cast<const float4*>(p.x + px * CIN + ch * 16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    const PixBase pb = pix_base((unsigned)run * (U * 16), p.Ho, p.Wo);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const long long px = px0 + u * 16;
@@ -216,9 +229,8 @@ __global__ __launch_bounds__(256) void conv1x1_heads_kernel(const P1M p) {
         }
       }
       if (px >= p.npx) continue;
-      const long long rr = px / p.Wo;
-      const int ow = (int)(px - rr * p.Wo), oh = (int)(rr % p.Ho);
-      const long long img = rr / p.Ho;
+      int img, oh, ow;
+      pix_at(pb, u * 16 + n16, p.Ho, p.Wo, img, oh, ow);
       // bilinear x2 taps of this pixel (F.interpolate(scale_factor=2, bilinear, align_corners=False), backbone.py:60,62)
       const int Hh = p.Ho >> 1, Wh = p.Wo >> 1;
       float sy = ((float)oh + 0.5f) * 0.5f - 0.5f; sy = sy < 0.f ? 0.f : sy;
@@ -290,6 +302,7 @@ int mdf_conv1x1_dispatch(const float* x, const float* wpack, const float* alpha,
   P1 p{};
   p.x = x; p.wpack = wpack; p.alpha = alpha; p.beta = beta; p.res = res; p.res_up = res_up; p.y = y;
   p.res_scale = res_scale; p.relu = relu; p.Ho = H; p.Wo = W; p.npx = (long long)B * H * W;
+  if (p.npx >= (1ll << 31) - 256) return MDF_EUNSUPPORTED;      // (pixel coordinates are 32-bit in the kernel)
   // (64 input channels stay on the LDS kernels: 2 tiles per run is all the registers allow, and that measured 1-2 us slower;
   //  non-temporal loads / stores measured slower too: 32->32 @296x400x5 50 -> 60 us inside a forward)
   C1_CASE(16, 16) C1_CASE(16, 32) C1_CASE(16, 64) C1_CASE(32, 16) C1_CASE(32, 32) C1_CASE(32, 64)

@@ -142,12 +142,11 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
     long long m = m0 + t * 16 + n16;
     live[t] = m < p.m_total;
     if (!live[t]) m = p.m_total - 1;
-    const int mw = (int)(m % Mw);
-    long long r = m / Mw;
-    const int mh = (int)(r % Mh);
-    r /= Mh;
-    const int md = (int)(r % Md);
-    const int b = (int)(r / Md);
+    // (m < 2^31: the entry bounds the volume to 32-bit offsets.  32-bit divisions: the 64-bit ones were ~240 vector instructions per
+    //  m-tile in front of the 100-400 MFMAs of a block -- a quarter of the run time of the small-volume launches, r05)
+    const unsigned mu = (unsigned)m, r1 = mu / (unsigned)Mw, r2 = r1 / (unsigned)Mh;
+    const int mw = (int)(mu - r1 * (unsigned)Mw), mh = (int)(r1 - r2 * (unsigned)Mh);
+    const int b = (int)(r2 / (unsigned)Md), md = (int)(r2 - (unsigned)b * (unsigned)Md);
     int bd, bh, bw;  // base input coordinate
     unsigned vm = 0;
     if (MODE == kS1) { bd = md; bh = mh; bw = mw; }
@@ -399,12 +398,9 @@ __global__ __launch_bounds__(256) void convtr_all_kernel(const ConvParams p) {
     long long m = m0 + t * 16 + n16;
     const bool live = m < p.m_total;
     if (!live) m = p.m_total - 1;
-    const int mw = (int)(m % p.Wi);
-    long long r = m / p.Wi;
-    const int mh = (int)(r % p.Hi);
-    r /= p.Hi;
-    const int md = (int)(r % p.Di);
-    const int b = (int)(r / p.Di);
+    const unsigned mu = (unsigned)m, r1 = mu / (unsigned)p.Wi, r2 = r1 / (unsigned)p.Hi;      // (32-bit: see conv3d_kernel)
+    const int mw = (int)(mu - r1 * (unsigned)p.Wi), mh = (int)(r1 - r2 * (unsigned)p.Hi);
+    const int b = (int)(r2 / (unsigned)p.Di), md = (int)(r2 - (unsigned)b * (unsigned)p.Di);
     vmask[t] = live ? (8u | (md + 1 < p.Di ? 1u : 0u) | (mh + 1 < p.Hi ? 2u : 0u) | (mw + 1 < p.Wi ? 4u : 0u)) : 0u;
     in_off[t] = (int)((((long long)b * p.Di + md) * p.Hi + mh) * p.Wi + mw) * CIN;
     out_vox[t] = (((long long)b * p.Do + 2 * md) * p.Ho + 2 * mh) * p.Wo + 2 * mw;
@@ -659,7 +655,7 @@ __host__ __device__ inline bool wino2d_built(int Cin, int Cout) {   // ((16, 32)
 }
 __host__ __device__ inline bool wd_built(int Cin, int Cout) { return Cout == 8 && (Cin == 8 || Cin == 16); }   // 3-D, depth-pair Winograd
 // 2-D k5 s2 layers that also run as a Winograd 3x3 conv over the four parity images of their input (conv_lds.hip, LdsConvParams::s2d)
-__host__ __device__ inline bool k5w_built(int Cin, int Cout) { return Cin == 16 && Cout == 32; }
+__host__ __device__ inline bool k5w_built(int Cin, int Cout) { return (Cin == 16 && Cout == 32) || (Cin == 8 && Cout == 16); }
 __host__ __device__ inline int padded_cin(int c) { return c <= 4 ? 4 : c; }
 
 // One complete packed weight set, as mdf_conv3d_pack_weights / mdf_conv_pack_weights lay it out: the plain fragments, then

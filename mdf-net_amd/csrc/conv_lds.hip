@@ -948,7 +948,9 @@ extern "C" int mdf_release_stream(void* stream) {
 int mdf_wino3d_dispatch(const float* x, const float* wpack_wino, const float* alpha, const float* beta, const float* res, float res_scale,
                         float* y, int B, int D, int H, int W, int Cin, int Cout, int relu, void* stream);   // wino3d.hip
 int mdf_wino2d_dispatch(const float* x, const float* wpack_wino, const float* alpha, const float* beta, const float* res, float res_scale,
-                        float* y, int B, int H, int W, int Cin, int Cout, int relu, void* stream);          // wino2d.hip
+                        float* y, int B, int H, int W, int Cin, int Cout, int relu, void* stream);
+int mdf_wino2d_s2d_dispatch(const float* x, const float* wpack_k5w, const float* alpha, const float* beta, float* y, int B, int Ho, int Wo,
+                            int Cin_mem, int Cout, int relu, void* stream);          // wino2d.hip
 
 int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha, const float* beta, const float* res,
                           float res_scale, const float* res_up, float* y, int B, int D, int H, int W, int Cin, int Cin_mem, int Cout, int KD,
@@ -981,6 +983,13 @@ int mdf_conv_lds_dispatch(const float* x, const float* wpack, const float* alpha
   {
     const bool k5w = [] { const char* e = getenv("MDF_CONV_K5_WINOGRAD"); return e ? atoi(e) != 0 : true; }();   // dev A/B (read per call)
     if (use_wg && k5w && KD == 1 && KHW == 5 && stride == 2 && !stat && !res_up && !shuffle2 && !planar_in && H % 2 == 0 && W % 2 == 0) {
+      // (wino2d.hip's S2D form first: pinned accumulators, one transform cluster per chunk -- 16 -> 32 and, there, 8 -> 16 too)
+      const bool use_w2 = [] { const char* e = getenv("MDF_CONV_WINO2D"); return e ? atoi(e) != 0 : true; }();
+      if (use_w2 && !res && Cin == Cin_mem && ((Cin == 16 && Cout == 32) || (Cin == 8 && Cout == 16))) {
+        const size_t plain = (size_t)25 * 64 * (Cin == 16 ? 2 * 4 : 1 * 2);      // 25 taps x NCH 1 x NT x 64 lanes x KPL floats
+        const int rc = mdf_wino2d_s2d_dispatch(x, wpack + plain, alpha, beta, y, B, p.Ho, p.Wo, Cin, Cout, relu, stream);
+        if (rc != MDF_EUNSUPPORTED) return rc;
+      }
       if (Cin == 16 && Cin_mem == 16 && Cout == 32) {
         p.s2d = 1; p.wpack = wpack + (size_t)25 * 1 * 2 * 64 * 4;
         return launch_lds<64, 64, 32, 1, 3, 1, 1, 2, 1>(p, (hipStream_t)stream);

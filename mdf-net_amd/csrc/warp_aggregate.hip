@@ -224,8 +224,14 @@ __global__ __launch_bounds__(kThreads) void warp_kernel(const Params p) {
 // and the two 16-byte gathers of a corner are one contiguous 32 bytes per lane.  Lane s takes the channels of lanes 2s and 2s+1
 // of the 4-channel kernel and adds their two partial dot products first -- the first step of that kernel's reduction tree --, so
 // every sum is formed from the same operands: bit-identical cost volume.
+#ifndef MDF_VEC8_MIN_BLOCKS
+#define MDF_VEC8_MIN_BLOCKS 1      // dev: blocks per CU the register allocation must allow
+#endif
+#ifndef MDF_VEC8_TAB
+#define MDF_VEC8_TAB 1024          // dev: tap-table entries (32 B each) per block
+#endif
 template <int C>
-__global__ __launch_bounds__(kThreads) void warp_vec8_kernel(const Params p) {
+__global__ __launch_bounds__(kThreads, MDF_VEC8_MIN_BLOCKS) void warp_vec8_kernel(const Params p) {
   constexpr int LPP = C / 8;           // lanes per pixel
   constexpr int PPB = kThreads / LPP;  // pixels per block
   constexpr int G = C / 2;
@@ -363,7 +369,7 @@ template <int C>
 int launch_vec8(Params& p, hipStream_t st) {
   constexpr int ppb = kThreads / (C / 8);
   p.nblk_x = (p.g.h * p.g.w + ppb - 1) / ppb;
-  int dch = 1024 / (p.n_src * ppb);  // ~32 KiB of tap table per block (twice the pixels of warp_kernel's tile, the same planes)
+  int dch = MDF_VEC8_TAB / (p.n_src * ppb);  // ~32 KiB of tap table per block (twice the pixels of warp_kernel's tile, the same planes)
   if (dch < 1) dch = 1;
   if (dch > p.D) dch = p.D;
   p.dchunk = dch;

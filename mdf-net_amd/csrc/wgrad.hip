@@ -91,11 +91,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   // Software pipeline over the wave's items: the 40 operand loads of item i+1 are in flight while the 36 MFMAs of item i run
   // (the first version loaded, waited and multiplied one kernel row at a time: three exposed memory latencies per item).
   auto issue = [&](long long item, float (&af)[4], float (&bf)[9][4]) -> int {
-    const int ch = (int)(item % p.chunks_per_row);
-    long long r = item / p.chunks_per_row;
-    const int oh = (int)(r % p.Hs); r /= p.Hs;
-    const int od = (int)(r % p.Ds);
-    const int n = (int)(r / p.Ds);
+    const unsigned iu = (unsigned)item, r1 = iu / (unsigned)p.chunks_per_row, r2 = r1 / (unsigned)p.Hs;      // (< 2^31 items: 32-bit divisions)
+    const int ch = (int)(iu - r1 * (unsigned)p.chunks_per_row), oh = (int)(r1 - r2 * (unsigned)p.Hs);
+    const int n = (int)(r2 / (unsigned)p.Ds), od = (int)(r2 - (unsigned)n * (unsigned)p.Ds);
     const int id = od * s + kd - 1;
     if (id < 0 || id >= p.Db) return 0;            // wave-uniform
     const int ow0 = ch * 16;
@@ -369,10 +367,8 @@ __global__ __launch_bounds__(256) void wgrad2d_kernel(const Wgrad2dParams p) {
 #pragma unroll
   for (int t = 0; t < KS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto issue = [&](long long item, float (&af)[4], float (&bf)[KS][4]) -> int {
-    const int ch = (int)(item % p.chunks_per_row);
-    const long long r = item / p.chunks_per_row;
-    const int oh = (int)(r % p.Hs);
-    const int n = (int)(r / p.Hs);
+    const unsigned iu = (unsigned)item, r1 = iu / (unsigned)p.chunks_per_row;      // (< 2^31 items: 32-bit divisions)
+    const int ch = (int)(iu - r1 * (unsigned)p.chunks_per_row), n = (int)(r1 / (unsigned)p.Hs), oh = (int)(r1 - (unsigned)n * (unsigned)p.Hs);
     const int ih = oh * s + kh - PAD;
     if (ih < 0 || ih >= p.Hb) return 0;            // wave-uniform
     const int ow0 = ch * 16;

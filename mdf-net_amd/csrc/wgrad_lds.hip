@@ -103,11 +103,12 @@ __device__ __forceinline__ void wgrad_lds_body(const WgradLdsParams& p, const VB
   for (int k = 0; k < NPR; ++k) { const int i = threadIdx.x + 256 * k; lds_big[k] = (i >> lb2) * p.BS + 4 * (i & (c4b - 1)); }
 
   auto decode = [&](long long tile, int& n, int& od, int& oh, int& ow0) {      // oh = first of the tile's TH rows
-    const int wt = (int)(tile % p.wtiles);
-    long long r = tile / p.wtiles;
-    oh = (int)(r % p.htiles) * TH; r /= p.htiles;
-    od = (int)(r % p.Ds);
-    n = (int)(r / p.Ds);
+    // (32-bit: a launch has < 2^31 tiles -- the host checks; three 64-bit divisions were ~250 vector instructions per decode, r05)
+    const unsigned tu = (unsigned)tile, r1 = tu / (unsigned)p.wtiles, r2 = r1 / (unsigned)p.htiles;
+    const int wt = (int)(tu - r1 * (unsigned)p.wtiles);
+    oh = (int)(r1 - r2 * (unsigned)p.htiles) * TH;
+    n = (int)(r2 / (unsigned)p.Ds);
+    od = (int)(r2 - (unsigned)n * (unsigned)p.Ds);
     ow0 = wt * p.tv;
   };
   auto stage = [&](long long tile) {          // global -> registers (zero for out-of-range voxels / rows)

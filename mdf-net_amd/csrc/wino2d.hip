@@ -9,6 +9,10 @@
 //     and the other free accumulator registers, so the next tile's loads are in flight a whole tile ahead at no vector-register cost;
 //   * tiles are handed out as one contiguous run per block (no atomics), three LDS slots rotate (one barrier per tile).
 // Per accumulator the MFMA order is conv_lds.hip's (cin chunk, k): the two kernels agree bit for bit.
+//
+// S2D: the 5x5 stride-2 layers of the pyramid (8 -> 16, 16 -> 32; backbone.py:20-27) as a 3x3 stride-1 conv over the FOUR PARITY IMAGES of
+// their input (conv_lds.hip, LdsConvParams::s2d; weights: conv3d.hip kSrcK5S2Phases): 16 instead of 25 MFMA groups per input channel.
+// x is then [B, 2H, 2W, CIN/4]; cin group g = parity (py*2+px) * (CIN/16) + 4-channel slice, and only the fill's addresses change.
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
@@ -27,7 +31,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 struct Wino2dParams {
-  const float* x;      // [B,H,W,CIN]
+  const float* x;      // [B,H,W,CIN]; S2D: [B,2H,2W,CIN/4]
   const float* wpack;  // transform-domain fragments [chunk][ab][nt][lane][4] (conv3d.hip: pack_wino_elem, nkd = 1)
   const float* alpha;  // [COUT] or null
   const float* beta;   // [COUT] or null
@@ -42,9 +46,11 @@ template <int CIN, int COUT>
 struct W2 {
   static_assert(CIN % 16 == 0 && COUT % 16 == 0 && COUT <= 64, "2-D Winograd form: Cin, Cout multiples of 16, Cout <= 64");
   static constexpr int NCH = CIN / 16, NT = COUT / 16, NG = CIN / 4;
-  // a wave owns two output rows and NTW <= 2 cout tiles (32 pinned accumulator tiles); with 64 output channels the four waves are
-  // 2 row pairs x 2 cout halves (both halves transform the same patch: 0.5 packed adds per MFMA), the tile is 4 rows high
-  static constexpr int WN = (NT > 2) ? NT / 2 : 1, NTW = NT / WN, WM = 4 / WN;
+  // a wave owns two output rows and NTW <= 2 cout tiles (32 pinned accumulator tiles); with 64 input channels a 10-row patch does not
+  // fit three times (87 KB): the four waves are 2 row pairs x 2 cout halves (both halves transform the same patch: 0.5 packed adds per
+  // MFMA with 64 output channels, 1 with 32), the tile is 4 rows high
+  static constexpr int WN = (CIN >= 64) ? 2 : 1, NTW = NT / WN, WM = 4 / WN;
+  static_assert(NT % WN == 0 && NTW >= 1 && NTW <= 2, "cout tiles per wave");
   static constexpr int TH = 2 * WM, TWO = 32;
   static constexpr int PH = TH + 2, PW = TWO + 2;
   static constexpr int NPP = PH * PW;
@@ -63,6 +69,12 @@ struct W2 {
   static_assert(S > NPP, "a pad vector per group takes the fill's surplus lanes");
 };
 
+#ifndef MDF_W2_DIAG
+#define MDF_W2_DIAG 0        // dev ablations (wrong results): 1 no input traffic, 2 no output stores, 4 no epilogue, 8 no transforms in the steps, 16 no fragment loads in the steps, 32 no patch reads
+#endif
+#ifndef MDF_W2_HOLD_REL
+#define MDF_W2_HOLD_REL 0
+#endif
 #ifndef MDF_W2_NA
 #define MDF_W2_NA 4
 #endif
@@ -70,7 +82,7 @@ struct W2 {
 #define MDF_W2_WRITE_AB 2
 #endif
 
-template <int CIN, int COUT, int NA, int WRITE_AB>
+template <int CIN, int COUT, int NA, int WRITE_AB, bool S2D>
 __global__ __launch_bounds__(256, 1) void wino2d_kernel(const Wino2dParams p) {
   typedef W2<CIN, COUT> C;
   constexpr int NCH = C::NCH, NT = C::NT, S = C::S, PW = C::PW, NPP = C::NPP, NFILL = C::NFILL, NSTEP = C::NSTEP;
@@ -100,7 +112,17 @@ __global__ __launch_bounds__(256, 1) void wino2d_kernel(const Wino2dParams p) {
   // ---- fill constants of the thread (element k = vector v of cin group g, 4 groups fastest: wino3d.hip): its LDS address, its patch
   // row / column (packed) and its offset inside the image relative to the patch origin
   // (64 channels: 13 elements -- the offset is rebuilt from the packed coordinates per tile instead of held: registers)
-  constexpr bool HOLD_REL = (NFILL <= 11);
+  constexpr bool HOLD_REL = (NFILL <= 11) || (NTW == 1) || MDF_W2_HOLD_REL;
+  constexpr int CM = S2D ? CIN / 4 : CIN;            // channels of a pixel in memory
+  [[maybe_unused]] constexpr int GPP = CM / 4;       // S2D: 4-channel slices per parity image
+  auto rel_of = [&](int row, int col, int g) -> int {      // byte offset of element (patch row, patch column, cin group) from the patch origin
+    if constexpr (S2D) {
+      const int par = g / GPP, c4 = g - par * GPP;
+      return (((2 * row + (par >> 1)) * (2 * p.W) + 2 * col + (par & 1)) * CM + c4 * 4) * 4;
+    } else {
+      return ((row * p.W + col) * CIN + g * 4) * 4;
+    }
+  };
   int f_lds[NFILL], f_rc[NFILL], f_rel[HOLD_REL ? NFILL : 1];
 #pragma unroll
   for (int k = 0; k < NFILL; ++k) {
@@ -111,7 +133,7 @@ __global__ __launch_bounds__(256, 1) void wino2d_kernel(const Wino2dParams p) {
     const int row = live ? v / PW : 0x40, col = v % PW;           // (a dead lane's row is outside every tile's valid range)
     f_lds[k] = live ? (g * S + v) * 4 : NPP * 4;
     f_rc[k] = (row << 16) | (col << 8) | g;
-    if constexpr (HOLD_REL) f_rel[k] = ((row * p.W + col) * CIN + g * 4) * 4;             // bytes
+    if constexpr (HOLD_REL) f_rel[k] = live ? rel_of(row, col, g) : (int)0x80000000u;     // (a dead lane reads nothing)
   }
 
   // ---- the block's run of tiles
@@ -120,32 +142,48 @@ __global__ __launch_bounds__(256, 1) void wino2d_kernel(const Wino2dParams p) {
   const int t_end = __builtin_amdgcn_readfirstlane((int)((unsigned long long)(lb + 1) * (unsigned)p.n_tiles / gridDim.x));
   if (t_begin >= t_end) return;
 
-  const size_t img_elems = (size_t)p.H * p.W * CIN;
   float4 pf[NFILL];
-  auto tile_origin = [&](int t, int& b, int& h0, int& w0) {
+  // tile coordinates live in scalar registers and advance tile by tile: two integer divisions per tile (issue + epilogue) were ~100 vector
+  // instructions of the ~250 a tile spends outside its MFMAs and transforms (ablation: profiles/r05_wino2d.md)
+  struct TileAt { int b, th, tw; };
+  auto tile_at = [&](int t) -> TileAt {
     const int tw = t % p.tiles_w, rest = t / p.tiles_w;
-    b = __builtin_amdgcn_readfirstlane(rest / p.tiles_h);
-    h0 = __builtin_amdgcn_readfirstlane((rest % p.tiles_h) * C::TH);
-    w0 = __builtin_amdgcn_readfirstlane(tw * C::TWO);
+    return TileAt{__builtin_amdgcn_readfirstlane(rest / p.tiles_h), __builtin_amdgcn_readfirstlane(rest % p.tiles_h), __builtin_amdgcn_readfirstlane(tw)};
   };
-  auto issue_tile = [&](int t) {                    // global loads of tile t's patch -> pf (zeros outside the image; t < 0: nothing)
-    int b, h0, w0;
-    tile_origin(t < 0 ? 0 : t, b, h0, w0);
+  auto tile_advance = [&](TileAt& c) {
+    if (++c.tw == p.tiles_w) {
+      c.tw = 0;
+      if (++c.th == p.tiles_h) { c.th = 0; ++c.b; }
+    }
+  };
+  auto issue_tile = [&](const TileAt& at, bool valid) {      // global loads of the tile's patch -> pf (zeros outside the image; !valid: nothing)
+    const int b = valid ? at.b : 0, h0 = (valid ? at.th : 0) * C::TH, w0 = (valid ? at.tw : 0) * C::TWO;
     // base = the patch origin (h0 - 1, w0 - 1) of image b: may lie before the image, every VALID element's address does not
-    const long long org = ((long long)b * p.H + (h0 - 1)) * p.W + (w0 - 1);
-    const float* pz = p.x + org * CIN;
+    const long long org = S2D ? ((long long)b * (2 * p.H) + 2 * (h0 - 1)) * (2 * p.W) + 2 * (w0 - 1)      // (pixels of the full-resolution map)
+                              : ((long long)b * p.H + (h0 - 1)) * p.W + (w0 - 1);
+    const float* pz = p.x + org * CM;
     const unsigned long long pa = (unsigned long long)pz;
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pa), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pa >> 32));
-    const unsigned nrec = (t < 0) ? 0u : 0x7fffffffu;
+    const unsigned nrec = (!valid || (MDF_W2_DIAG & 1)) ? 0u : 0x7fffffffu;
     const __amdgpu_buffer_rsrc_t xr = make_rsrc((const void*)(((unsigned long long)hi << 32) | lo), nrec);
     const int r_lo = 1 - h0, r_hi = p.H + 1 - h0, c_lo = 1 - w0, c_hi = p.W + 1 - w0;     // valid patch rows / columns of this tile
+    if constexpr (HOLD_REL) {
+      if (r_lo <= 0 && r_hi >= C::PH && c_lo <= 0 && c_hi >= C::PW) {      // the whole patch lies inside the image (most tiles): no bounds arithmetic
+#pragma unroll
+        for (int k = 0; k < NFILL; ++k) {
+          const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(xr, f_rel[k], 0, 0);
+          pf[k] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < NFILL; ++k) {
       const int row = f_rc[k] >> 16, col = (f_rc[k] >> 8) & 0xff;
       const bool ok = row >= r_lo && row < r_hi && col >= c_lo && col < c_hi;
       int rel;
       if constexpr (HOLD_REL) rel = f_rel[k];
-      else rel = ((row * p.W + col) * CIN + (f_rc[k] & 0xff) * 4) * 4;
+      else rel = rel_of(row, col, f_rc[k] & 0xff);
       const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? rel : (int)0x80000000u, 0, 0);
       pf[k] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
@@ -194,9 +232,8 @@ __global__ __launch_bounds__(256, 1) void wino2d_kernel(const Wino2dParams p) {
   };
 
   // output transform + epilogue of tile t (conv_lds.hip: wino_epilogue); accumulator tile nt*16 + ab
-  auto epilogue = [&](int t) {
-    int b, h0, w0;
-    tile_origin(t, b, h0, w0);
+  auto epilogue = [&](const TileAt& at) {
+    const int b = at.b, h0 = at.th * C::TH, w0 = at.tw * C::TWO;
     if (h0 + 2 * wm >= p.H) return;
     const float* epi_tab = lds + C::EPI_OFF;
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -248,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void wino2d_kernel(const Wino2dParams p) {
             ov[0] = rv.x + ov[0] * p.res_scale; ov[1] = rv.y + ov[1] * p.res_scale;
             ov[2] = rv.z + ov[2] * p.res_scale; ov[3] = rv.w + ov[3] * p.res_scale;
           }
-          *reinterpret_cast<float4*>(p.y + oi) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+          if (!(MDF_W2_DIAG & 2) || ov[0] == 1234.5f) *reinterpret_cast<float4*>(p.y + oi) = make_float4(ov[0], ov[1], ov[2], ov[3]);
         }
       }
     });
@@ -256,21 +293,21 @@ __global__ __launch_bounds__(256, 1) void wino2d_kernel(const Wino2dParams p) {
 
   // One tile in ring slot R.  On entry: its first transformed chunk is in V, the first AH fragments are in flight, pf holds tile
   // t + 1 (requested before the previous tile's epilogue).  On exit the same for tile t + 1 (unconditional definitions: wino3d.hip).
-  auto step = [&](auto rc, int t, int t_next2, bool has_next) {
+  auto step = [&](auto rc, const TileAt& at, const TileAt& at_next2, bool valid_next2, bool has_next) {
     constexpr int R = decltype(rc)::value;
     constexpr int SLOT_N = (R + 1) % 3;
     static_for<0, NSTEP>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       constexpr int ch = i / 16, ab = i % 16;
       constexpr bool last_chunk = (ch == NCH - 1);
-      load_a((i + AH) % NSTEP, (i + AH) % NA);
+      if (!(MDF_W2_DIAG & 16)) load_a((i + AH) % NSTEP, (i + AH) % NA);
       if constexpr (ch == 0 && ab == WRITE_AB) {
         if (has_next) {                 // tile t + 1 -> its slot; everybody is past tile t - 2
           write_tile(SLOT_N);
           __syncthreads();
         }
       }
-      if constexpr (ab > WRITE_AB && ab <= WRITE_AB + 8) {
+      if constexpr (ab > WRITE_AB && ab <= WRITE_AB + 8 && !(MDF_W2_DIAG & 32)) {
         constexpr int e0 = 2 * (ab - WRITE_AB - 1);
         if constexpr (!last_chunk) { read_elem(R, ch + 1, e0); read_elem(R, ch + 1, e0 + 1); }
         else { read_elem(SLOT_N, 0, e0); read_elem(SLOT_N, 0, e0 + 1); }
@@ -286,20 +323,23 @@ __global__ __launch_bounds__(256, 1) void wino2d_kernel(const Wino2dParams p) {
         AccTile<T>::mfma(af[i % NA][nt][3], V[ab][1][1]);
       });
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (ab == 15 && !last_chunk) transform();
+      if constexpr (ab == 15 && !last_chunk) { if (!(MDF_W2_DIAG & 8)) transform(); }
     });
-    issue_tile(t_next2);          // behind the tile's MFMAs, ahead of the epilogue (vmcnt retires in order: wino3d.hip)
-    transform();
-    epilogue(t);
+    issue_tile(at_next2, valid_next2);          // behind the tile's MFMAs, ahead of the epilogue (vmcnt retires in order: wino3d.hip)
+    if (!(MDF_W2_DIAG & 8)) transform();
+    if (!(MDF_W2_DIAG & 4)) epilogue(at);
   };
 
   // ---- prologue
   int t = t_begin;
   const int t_last = t_end - 1;
-  issue_tile(t);
+  TileAt at = tile_at(t), at2 = at;
+  issue_tile(at, true);
   write_tile(0);
   __syncthreads();
-  issue_tile(t < t_last ? t + 1 : -1);
+  tile_advance(at2);
+  issue_tile(at2, t < t_last);
+  tile_advance(at2);              // tile t + 2
 #pragma unroll
   for (int e = 0; e < 16; ++e) read_elem(0, 0, e);
   transform();
@@ -309,9 +349,9 @@ __global__ __launch_bounds__(256, 1) void wino2d_kernel(const Wino2dParams p) {
 #define W2_STEP(RR)                                                                        \
   {                                                                                        \
     const bool has_next = t < t_last;                                                      \
-    step(std::integral_constant<int, RR>{}, t, (t + 2 <= t_last) ? t + 2 : -1, has_next);  \
+    step(std::integral_constant<int, RR>{}, at, at2, t + 2 <= t_last, has_next);           \
     if (!has_next) break;                                                                  \
-    ++t;                                                                                   \
+    ++t; tile_advance(at); tile_advance(at2);                                              \
   }
   for (;;) {
     W2_STEP(0)
@@ -321,7 +361,7 @@ __global__ __launch_bounds__(256, 1) void wino2d_kernel(const Wino2dParams p) {
 #undef W2_STEP
 }
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool S2D = false>
 int launch_wino2d(Wino2dParams& p, hipStream_t st) {
   typedef W2<CIN, COUT> C;
   constexpr int NA = MDF_W2_NA, WRITE_AB = MDF_W2_WRITE_AB;
@@ -330,7 +370,7 @@ int launch_wino2d(Wino2dParams& p, hipStream_t st) {
   const long long tiles = (long long)p.B * p.tiles_h * p.tiles_w;
   if (tiles >= (1ll << 31)) return MDF_EUNSUPPORTED;
   p.n_tiles = (int)tiles;
-  auto kern = &wino2d_kernel<CIN, COUT, NA, WRITE_AB>;
+  auto kern = &wino2d_kernel<CIN, COUT, NA, WRITE_AB, S2D>;
   static bool attr_done_dev[64] = {};
   int dev_id = 0;
   (void)hipGetDevice(&dev_id);
@@ -363,5 +403,18 @@ int mdf_wino2d_dispatch(const float* x, const float* wpack_wino, const float* al
   if (Cin == 16 && Cout == 16 && getenv("MDF_WINO2D_16")) return launch_wino2d<16, 16>(p, (hipStream_t)stream);
   if (Cin == 32 && Cout == 32) return launch_wino2d<32, 32>(p, (hipStream_t)stream);
   if (Cin == 64 && Cout == 64) return launch_wino2d<64, 64>(p, (hipStream_t)stream);
+  return MDF_EUNSUPPORTED;
+}
+
+// The 5x5 stride-2 layers over the parity images of their input: x [B,2*Ho,2*Wo,Cin_mem], y [B,Ho,Wo,Cout]; wpack_k5w = the layer's
+// transform-domain fragments over 4*Cin_mem logical input channels (conv3d.hip: k5w_built).
+int mdf_wino2d_s2d_dispatch(const float* x, const float* wpack_k5w, const float* alpha, const float* beta, float* y, int B, int Ho, int Wo,
+                            int Cin_mem, int Cout, int relu, void* stream) {
+  Wino2dParams p{};
+  p.x = x; p.wpack = wpack_k5w; p.alpha = alpha; p.beta = beta; p.res = nullptr; p.res_scale = 0.f; p.y = y;
+  p.B = B; p.H = Ho; p.W = Wo; p.relu = relu;
+  if ((long long)B * Ho * Wo * 4 * Cin_mem * 4 >= (1ll << 31)) return MDF_EUNSUPPORTED;     // byte offsets inside a patch are 31-bit
+  if (Cin_mem == 16 && Cout == 32) return launch_wino2d<64, 32, true>(p, (hipStream_t)stream);
+  if (Cin_mem == 8 && Cout == 16) return launch_wino2d<32, 16, true>(p, (hipStream_t)stream);
   return MDF_EUNSUPPORTED;
 }

@@ -1,6 +1,7 @@
 """Diagnostic build with in-kernel cycle stamps: where does a conv_lds block spend its time?
    usage (on the GPU box): python scripts/diag_conv_stamps.py     (builds a separate .so; the product library is untouched)"""
 import ctypes, os, subprocess, sys
+os.environ.setdefault('MDF_CONV_WINO3D', '0'); os.environ.setdefault('MDF_CONV_WINO2D', '0')   # (the stamps live in conv_lds_kernel)
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [R + '/mdf-net_amd']
 csrc = R + '/mdf-net_amd/csrc'
@@ -16,7 +17,7 @@ from mdfnet_hip import ops
 lib = mdfnet_hip.lib()
 lib.mdf_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 dev = 'cuda:0'
-for name, ci, co, D, H, W in [("32->16", 32, 16, 48, 148, 200), ("16->16", 16, 16, 48, 148, 200), ("16->8", 16, 8, 24, 296, 400), ("8->8", 8, 8, 8, 592, 800)]:
+for name, ci, co, D, H, W in ([] if os.environ.get("STAMPS_2D_ONLY") else [("32->16", 32, 16, 48, 148, 200), ("16->16", 16, 16, 48, 148, 200)]):
     x = torch.randn(1, D, H, W, ci, device=dev)
     wp = ops.pack_conv3d_weight(torch.randn(co, ci, 3, 3, 3, device=dev) * 0.05)
     for _ in range(2): ops.conv3d_ndhwc(x, wp, ci, co)
@@ -35,7 +36,7 @@ for name, ci, co, D, H, W in [("32->16", 32, 16, 48, 148, 200), ("16->16", 16, 1
           f"cyc/d-step compute {comp/dsteps:7.0f} refill {fill/dsteps:6.0f}, cyc/item sched {sched/items:6.0f} prologue {pro/max(items-blocks,1):6.0f}")
 
 print("2-D layers (per tile: compute = MFMA step incl. epilogue stores, refill = wait for the next tile's loads + LDS stores + barrier)")
-for name, ci, co, k, st, b, h, w in [("refine 8->8", 8, 8, 3, 1, 1, 592, 800), ("refine 8->32", 8, 32, 3, 1, 1, 592, 800), ("bb 8->8", 8, 8, 3, 1, 5, 1184, 1600), ("bb 8->16 k5s2", 8, 16, 5, 2, 5, 1184, 1600), ("bb 16->16", 16, 16, 3, 1, 5, 592, 800),
+for name, ci, co, k, st, b, h, w in [("refine 8->8", 8, 8, 3, 1, 1, 592, 800), ("refine 8->32", 8, 32, 3, 1, 1, 592, 800), ("bb 8->8", 8, 8, 3, 1, 5, 1184, 1600), ("bb 8->16 k5s2", 8, 16, 5, 2, 5, 1184, 1600), ("bb 16->16", 16, 16, 3, 1, 5, 592, 800), ("bb 16->32 k5s2", 16, 32, 5, 2, 5, 592, 800),
                                      ("bb 32->32", 32, 32, 3, 1, 5, 296, 400), ("bb 32->64 k5s2", 32, 64, 5, 2, 5, 296, 400), ("bb 64->64", 64, 64, 3, 1, 5, 148, 200)]:
     x = torch.randn(b, h, w, ci, device=dev)
     wp = ops.pack_conv2d_weight(torch.randn(co, ci, k, k, device=dev) * 0.1)

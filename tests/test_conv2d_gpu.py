@@ -97,23 +97,35 @@ def test_refine_tail_in_one_launch(shape):
     np.testing.assert_allclose(got_raw.cpu().numpy(), two.cpu().numpy(), rtol=0, atol=4e-6)
 
 
-@pytest.mark.parametrize("shape", [(2, 26, 70), (1, 8, 32), (1, 64, 132), (3, 2, 2)])
-def test_k5s2_as_winograd_over_the_parity_images(shape, monkeypatch):
-    """Conv2d(16, 32, k5, s2, p2) run as a Winograd 3x3 conv over the four parity images of its input (conv_lds.hip, LdsConvParams::s2d)
-    against the direct 25-tap kernel and torch: tiles that hang over the right / bottom edge, a map smaller than a tile."""
+@pytest.mark.parametrize("chans", [(16, 32), (8, 16)])
+@pytest.mark.parametrize("shape", [(2, 26, 70), (1, 8, 32), (1, 64, 132), (3, 2, 2), (2, 36, 196)])
+def test_k5s2_as_winograd_over_the_parity_images(shape, chans, monkeypatch):
+    """Conv2d(16, 32, k5, s2, p2) / Conv2d(8, 16, k5, s2, p2) run as a Winograd 3x3 conv over the four parity images of their input
+    (wino2d.hip S2D; conv_lds.hip LdsConvParams::s2d for 16 -> 32 with MDF_CONV_WINO2D=0) against the direct 25-tap kernel and torch: tiles
+    that hang over the right / bottom edge, a map smaller than a tile, several tiles per block."""
     b, h, w = shape
+    cin, cout = chans
     rng = np.random.RandomState(h * 7 + w)
-    x = T(rng.randn(b, 16, h, w).astype(np.float32))
-    wt = T((rng.randn(32, 16, 5, 5) / 20).astype(np.float32))
-    al, be = T(rng.uniform(0.5, 1.5, 32).astype(np.float32)), T(rng.randn(32).astype(np.float32) * 0.1)
+    x = T(rng.randn(b, cin, h, w).astype(np.float32))
+    wt = T((rng.randn(cout, cin, 5, 5) / 20).astype(np.float32))
+    al, be = T(rng.uniform(0.5, 1.5, cout).astype(np.float32)), T(rng.randn(cout).astype(np.float32) * 0.1)
     exp = F.relu(F.conv2d(x, wt, None, 2, 2) * al.view(1, -1, 1, 1) + be.view(1, -1, 1, 1))
     xd, wp = ops.to_nhwc(x.to(DEV)), ops.pack_conv2d_weight(wt.to(DEV))
+    run = lambda: ops.from_nhwc(ops.conv2d_nhwc(xd, wp, cin, cout, 5, 2, al.to(DEV), be.to(DEV), True)).cpu()
+    from mdfnet_hip import lib
     monkeypatch.setenv("MDF_CONV_K5_WINOGRAD", "1")
-    got = ops.from_nhwc(ops.conv2d_nhwc(xd, wp, 16, 32, 5, 2, al.to(DEV), be.to(DEV), True)).cpu()
+    got = run()
+    assert lib().mdf_last_launch().decode().startswith("wino2d_kernel")
+    monkeypatch.setenv("MDF_CONV_WINO2D", "0")
+    old = run()                                             # conv_lds.hip's form (16 -> 32) / the direct kernel (8 -> 16)
     monkeypatch.setenv("MDF_CONV_K5_WINOGRAD", "0")
-    direct = ops.from_nhwc(ops.conv2d_nhwc(xd, wp, 16, 32, 5, 2, al.to(DEV), be.to(DEV), True)).cpu()
+    direct = run()
+    assert lib().mdf_last_launch().decode().startswith("conv_lds_kernel")
     np.testing.assert_allclose(got.numpy(), exp.numpy(), rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(got.numpy(), direct.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(got.numpy(), old.numpy(), rtol=1e-4, atol=2e-5)
+    if chans == (16, 32):
+        assert torch.equal(got, old)        # same fragments, same MFMA order per accumulator: the two Winograd kernels agree bit for bit
 
 
 def test_backbone_and_refine_vs_reference_golden(golden, seeded_sd):
