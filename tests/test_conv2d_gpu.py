@@ -158,12 +158,13 @@ def test_conv_with_fused_pixel_shuffle(shape):
     np.testing.assert_allclose(y.permute(0, 3, 1, 2).cpu().numpy(), exp.numpy(), rtol=1e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize("shape", [(1, 8, 16), (2, 13, 37), (1, 40, 136), (3, 9, 131), (2, 64, 62), (1, 65, 63), (1, 200, 190), (5, 296, 400)])
-def test_conv2d_pair_equals_the_two_layers(shape):
-    """mdf_conv2d_pair_fwd (conv_pair.hip: FPN_4Scales.conv01, both full-resolution ConvBNReLU layers in one launch with rolling
-    LDS windows) against the two single-layer launches it replaces: same packed weights, tap order and epilogue arithmetic, so
-    BIT-IDENTICAL -- strips narrower / wider than 62 pixels, row counts around the 8-row steps and the segment boundaries -- and
-    against torch on the CPU."""
+@pytest.mark.parametrize("shape", [(1, 8, 16), (2, 13, 37), (1, 40, 136), (3, 9, 131), (2, 64, 62), (1, 65, 63), (1, 200, 190), (5, 296, 400), (1, 3, 1), (2, 1, 70)])
+def test_conv2d_pair_equals_the_two_layers(shape, monkeypatch):
+    """mdf_conv2d_pair_fwd (conv_pair.hip: FPN_4Scales.conv01, both full-resolution ConvBNReLU layers in one launch) against the two
+    single-layer launches it replaces and against torch on the CPU -- strips narrower / wider than 62 pixels, row counts around the
+    segment boundaries, maps of one row / one column.  The MFMA form (MDF_CONV_PAIR_VALU=0: rolling LDS windows, same packed weights,
+    tap order and epilogue arithmetic as the single-layer kernels) is BIT-IDENTICAL to them; the default vector-ALU form (every
+    multiply-add a useful one, sums in tap order per lane) agrees to fp32 rounding."""
     n, h, w = shape
     rng = np.random.RandomState(n * 100 + h + w)
     x = T(rng.rand(n, 3, h, w).astype(np.float32))
@@ -175,9 +176,15 @@ def test_conv2d_pair_equals_the_two_layers(shape):
     wp1, wp2 = ops.pack_conv2d_weight(w1.to(DEV)), ops.pack_conv2d_weight(w2.to(DEV))
     t1 = ops.conv2d_nhwc(xd, wp1, 3, 8, 3, 1, a1.to(DEV), b1.to(DEV), True, planar_in=True)
     two = ops.conv2d_nhwc(t1, wp2, 8, 8, 3, 1, a2.to(DEV), b2.to(DEV), True)
+    from mdfnet_hip import lib
     one = ops.conv2d_pair_planar(xd, wp1, a1.to(DEV), b1.to(DEV), wp2, a2.to(DEV), b2.to(DEV))
-    assert one.shape == two.shape == (n, h, w, 8)
-    assert torch.equal(one, two), float((one - two).abs().max())
+    assert lib().mdf_last_launch().decode().startswith("conv_pair_valu_kernel")
+    monkeypatch.setenv("MDF_CONV_PAIR_VALU", "0")
+    mfma = ops.conv2d_pair_planar(xd, wp1, a1.to(DEV), b1.to(DEV), wp2, a2.to(DEV), b2.to(DEV))
+    assert lib().mdf_last_launch().decode().startswith("conv_pair_kernel")
+    assert one.shape == two.shape == (n, h, w, 8) and not bool(torch.isnan(one).any())
+    assert torch.equal(mfma, two), float((mfma - two).abs().max())
+    np.testing.assert_allclose(one.cpu().numpy(), two.cpu().numpy(), rtol=2e-5, atol=2e-6)
     m1 = F.relu(F.conv2d(x, w1, None, 1, 1) * a1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1))
     exp = F.relu(F.conv2d(m1, w2, None, 1, 1) * a2.view(1, -1, 1, 1) + b2.view(1, -1, 1, 1))
     np.testing.assert_allclose(ops.from_nhwc(one).cpu().numpy(), exp.numpy(), rtol=1e-4, atol=2e-5)
