@@ -60,7 +60,7 @@ def family(name, tag):
         return "conv3d (regulariser): conv_lds_kernel / conv3d_kernel, fp32 MFMA implicit GEMM"
     if name in ("mdf_conv2d_fwd", "mdf_conv2d_pair_fwd", "mdf_conv2d_res_pair_fwd", "mdf_conv1x1_heads_fwd", "mdf_refine_tail_fwd", "mdf_prob_fused_fwd"):
         # (the one-launch prob head stays in this family: it is the prob-head partial-sum conv with the softmax behind it)
-        return ("conv2d (feature pyramid + refine + prob-head partial sums): conv_lds_kernel / conv_pair_kernel / conv1x1_kernel / "
+        return ("conv2d (feature pyramid + refine + prob-head partial sums): conv_lds_kernel / conv_pair_valu_kernel / conv1x1_kernel / "
                 "res_pair_kernel / refine_tail_kernel / prob_fused_kernel, fp32 MFMA implicit GEMM")
     if name == "mdf_warp_aggregate_vec_fwd":
         return "warp_kernel<kVec> (fused warp+aggregate)"
@@ -276,7 +276,7 @@ def rocprof_conv_family():
     ns, forwards, launches = 0, 0, 0
     with open(path) as f:
         for r in csv.DictReader(f):
-            if KF.function_name(r["Name"]) == "conv_pair_kernel":
+            if KF.function_name(r["Name"]) in ("conv_pair_kernel", "conv_pair_valu_kernel"):
                 forwards = int(r["Calls"])                      # exactly one launch per forward
             if KF.family(r["Name"]) == KF.MFMA_CONV:
                 ns += int(r["TotalDurationNs"])
@@ -945,7 +945,7 @@ def main():
                 ms = sum(k["ms_per_step"] for k in mf)
                 gf = sum(k["algorithmic_gflop_per_step"] for k in mf)
                 ach = gf / ms
-                rec["roofline"] = {"kernel": "fp32-MFMA implicit-GEMM conv family (conv_lds_kernel + wino3d_kernel + wino2d_kernel + conv3d_kernel + convtr_all_kernel + conv_pair_kernel + res_pair_kernel + conv1x1_kernel + conv1x1_heads_kernel + refine_tail_kernel + prob_fused_kernel)", "bound": "mfma",
+                rec["roofline"] = {"kernel": "fp32-MFMA implicit-GEMM conv family (conv_lds_kernel + wino3d_kernel + wino2d_kernel + conv3d_kernel + convtr_all_kernel + conv_pair_valu_kernel + res_pair_kernel + conv1x1_kernel + conv1x1_heads_kernel + refine_tail_kernel + prob_fused_kernel)", "bound": "mfma",
                                    "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                                    "traffic": (round(traffic["mfma_conv"]["hbm_bytes_per_forward"]) if "mfma_conv" in traffic else None),

@@ -63,7 +63,7 @@ def test_committed_profiles_have_no_unclassified_kernel_of_ours():
         fn = KF.function_name(r["Name"])
         if fn in found:
             assert KF.family(r["Name"]) is not None, fn
-    fwd = [int(r["Calls"]) for r in rows if KF.function_name(r["Name"]) == "conv_pair_kernel"]
+    fwd = [int(r["Calls"]) for r in rows if KF.function_name(r["Name"]) in ("conv_pair_kernel", "conv_pair_valu_kernel")]
     assert len(fwd) == 1
     launches = sum(int(r["Calls"]) for r in rows if KF.family(r["Name"]) == KF.MFMA_CONV)
     assert launches % fwd[0] == 0, (launches, fwd[0])
