@@ -21,16 +21,29 @@ What has to hold for a recording to stay valid, and how each point is met:
   * the parameters change through raw pointers inside the graph, so after every replay the version counters of parameters and
     buffers are bumped on the host: any cache keyed on them (eval-mode folded weights) sees the update.
 
+Stage-parallel backward (default; MDF_TRAIN_GRAPH_SPLIT=0 records the step as ONE graph): the backward chains of the three stages
+(regulariser + aggregation, ~60 % of the step's launches, many of them small-volume layers that fill a fraction of the chip) share
+nothing until they meet at the feature pyramid.  A hipGraph with parallel branches does not help -- the runtime replays it node
+by node from the host (6.5 ms of host time per cfg3 step, slower than the chain) -- so the step is recorded as FIVE chain-shaped
+graphs: F (forward, loss, loss backward down to each stage's depth), S0 / S1 / S2 (one stage's backward chain each, recorded on
+the stage's own stream into its own memory pool), C (feature pyramid + trunk backward, weight-gradient sums, bucket gather, Adam).
+A replay is F, then the three S graphs side by side on three streams, then C.  The cuts are made by CoreNet's forward
+(layers.StageCuts); the gradients are those of the one-piece backward pass (no sum crosses a cut).
+
 Data parallelism: with more than one rank the gradient all-reduce stays OUTSIDE the graphs -- recording A ends with the bucket
 gather, the collective runs eagerly on the same stream (RCCL), recording B is the Adam launch.
 
 The recorded step equals the eager step on the same inputs up to the summation order of the floating-point atomics that both
 use (tests/test_train_graph_gpu.py: three steps with different cameras and images per step, both ways).
 """
+import os
+
 import torch
 from torch.autograd import graph as _graph
 
-from . import controlplane, hostmirror
+from . import controlplane, hostmirror, layers
+
+SPLIT_BACKWARD = bool(int(os.environ.get("MDF_TRAIN_GRAPH_SPLIT", "1")))      # dev A/B: 0 = the whole step as one graph
 
 
 class GraphedTrainStep:
@@ -50,6 +63,7 @@ class GraphedTrainStep:
             # after one eager optimizer step does a step START with "the weights have moved", which is what every replay must do
             raise ValueError("GraphedTrainStep needs warmup >= 1: a step recorded before any optimizer step would never re-pack weights")
         self.model, self.crit, self.bucket, self.opt = model, criterion, bucket, optimizer
+        self.split = SPLIT_BACKWARD
         dev = imgs.device
         self.device = dev
         self.world = bucket.world
@@ -96,8 +110,43 @@ class GraphedTrainStep:
         self.bucket.gather()
         return loss.detach()
 
+    # the same step in pieces (module docstring): F, one chain per stage, C
+    def _piece_f(self):
+        with controlplane.staged(self.staging), layers.stage_cuts() as cuts:
+            out = self.model(self.imgs, self.extr, self.intr, self.dr)
+        if len(cuts.depth) == 0 or cuts.streams is None:
+            raise RuntimeError("GraphedTrainStep: the model's forward made no stage cuts (not the HIP training path?)")
+        loss = self.crit(out, self.gt, self.dr)
+        self.bucket.zero_grad()
+        loss.backward()                                     # loss -> d depth of every stage; the refinement net's parameters
+        return loss.detach(), cuts
+
+    @staticmethod
+    def _piece_stage(cuts, s):
+        depth, cut = cuts.depth[s]
+        if cut.grad is not None:
+            torch.autograd.backward([depth], [cut.grad])    # regulariser + aggregation of stage s -> d features, parameters
+
+    def _piece_c(self, cuts):
+        roots = [(y, yc.grad) for pairs in cuts.feat for (y, yc) in pairs if yc.grad is not None]
+        torch.autograd.backward([r[0] for r in roots], [r[1] for r in roots])      # feature pyramid + trunk
+        self.bucket.gather()
+
     def _eager_step(self):
-        loss = self._forward_backward()
+        if self.split:
+            # the warm-up takes the step in the pieces the recording will (same streams: autograd runs a node's backward on
+            # the stream of its forward, and the recording of stage s must find its whole chain on stream s)
+            cur = torch.cuda.current_stream(self.device)
+            loss, cuts = self._piece_f()
+            for s, st in enumerate(cuts.streams):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    self._piece_stage(cuts, s)
+            for st in cuts.streams:
+                cur.wait_stream(st)
+            self._piece_c(cuts)
+        else:
+            loss = self._forward_backward()
         self.bucket.allreduce_gradients()
         self.opt.step(hyper=self.hyper)
         self.opt.steps += 1
@@ -111,10 +160,27 @@ class GraphedTrainStep:
         self._pool = train_ops.step_pool(dev)               # its buffer's address is in the recording: not replaced while this
         self._pool.held_by_recording += 1                   # object lives (ZeroPool.take raises instead)
         self.graph_a = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_a, stream=self.stream):
-            self.loss = self._forward_backward()
-            if self.world <= 1:
-                self.opt.step(hyper=self.hyper)
+        self.graph_s, self.graph_c, self.side = [], None, None
+        if self.split:
+            with torch.cuda.graph(self.graph_a, stream=self.stream):
+                self.loss, cuts = self._piece_f()
+            self.side = list(cuts.streams)
+            for s, st in enumerate(self.side):              # a pool of its own each: the three replay at the same time
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st):
+                    self._piece_stage(cuts, s)
+                self.graph_s.append(g)
+            self.graph_c = torch.cuda.CUDAGraph()           # replayed after everything else: may reuse what F's pool has freed
+            with torch.cuda.graph(self.graph_c, stream=self.stream, pool=self.graph_a.pool()):
+                self._piece_c(cuts)
+                if self.world <= 1:
+                    self.opt.step(hyper=self.hyper)
+            del cuts
+        else:
+            with torch.cuda.graph(self.graph_a, stream=self.stream):
+                self.loss = self._forward_backward()
+                if self.world <= 1:
+                    self.opt.step(hyper=self.hyper)
         if self.world > 1:
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b, stream=self.stream, pool=self.graph_a.pool()):
@@ -144,6 +210,15 @@ class GraphedTrainStep:
             self.dr.copy_(depth_range if depth_range.is_cuda else dr_h, non_blocking=True)
         self._upload(extr_h, intr_h, dr_h)
         self.graph_a.replay()
+        if self.graph_c is not None:
+            cur = torch.cuda.current_stream(self.device)
+            for st, g in zip(self.side, self.graph_s):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    g.replay()
+            for st in self.side:
+                cur.wait_stream(st)
+            self.graph_c.replay()
         if self.world > 1:
             self.bucket.allreduce_gradients()
             self.graph_b.replay()

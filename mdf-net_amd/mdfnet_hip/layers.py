@@ -96,6 +96,31 @@ _REHEARSAL = None        # the stock-op backend module once rehearsal.enable() w
 _mode = threading.local()
 
 
+class StageCuts:
+    """Where a recorded training step (graphstep.GraphedTrainStep) splits its backward pass: CoreNet's training forward replaces
+    every stage's feature tensor and every stage's depth by a detached copy that requires grad and notes the pairs here.  The
+    gradient is the same, but it can then be taken in pieces -- loss -> d depth per stage | one stage's regulariser + aggregation
+    (three chains that share nothing: the hypotheses are built under no_grad, depthhypos.py:40,188) | feature pyramid + trunk --
+    and each piece recorded as a hipGraph of its own, the three stage chains replayed side by side on three streams."""
+
+    def __init__(self):
+        self.feat, self.depth, self.streams = [], [], None      # [stage] -> [(tensor, cut)], (depth, cut); the stages' streams
+
+
+@contextlib.contextmanager
+def stage_cuts():
+    prev = getattr(_mode, "cuts", None)
+    _mode.cuts = StageCuts()
+    try:
+        yield _mode.cuts
+    finally:
+        _mode.cuts = prev
+
+
+def active_cuts():
+    return getattr(_mode, "cuts", None)
+
+
 @contextlib.contextmanager
 def model_mode(training):
     """CoreNet.forward announces its mode so that the plain-function slots (depth_regression, homo_warping, ...) follow the

@@ -165,14 +165,15 @@ def _flush_wgrad_sums(dev_index):
         # kernel instantiation -- the ~45 small layers of a cfg3 step as a handful of launches (mdf_wgrad_batch_flush)
         lib().mdf_wgrad_batch_begin()
         flops = nbytes = 0.0
+        st_now = ctypes.c_void_p(cur.cuda_stream)
         try:
             for fn in deferred:
-                job, fl, by = fn()
+                job, fl, by = fn(st_now)
                 jobs.append(job)
                 flops += fl
                 nbytes += by
         finally:
-            _abi("mdf_wgrad_batch_flush", (deferred[0].stream,), tag=f"{len(deferred)} weight gradients",
+            _abi("mdf_wgrad_batch_flush", (st_now,), tag=f"{len(deferred)} weight gradients",
                  work={"flops": flops, "bytes": nbytes, "bound": "mfma"})
     sum_wgrad_jobs(jobs)
 
@@ -230,11 +231,13 @@ class _DeferredWgrad:
 
     def __init__(self, entry, args_of, small, big, dw, work, flops):
         self.entry, self.args_of, self.small, self.big, self.work, self.flops = entry, args_of, small, big, work, flops
-        self.dw_ptr, self.dw_numel, self.stream = dw.data_ptr(), dw.numel(), _stream(dw)
+        self.dw_ptr, self.dw_numel = dw.data_ptr(), dw.numel()
 
-    def __call__(self):
+    def __call__(self, st):
+        """st: the stream of the FLUSH (the backward pass's caller stream, which has joined every stream a stage's chain ran on) --
+        not the stream that was current when the launch was put off."""
         nslab = ctypes.c_int(0)
-        check(getattr(lib(), self.entry)(*self.args_of(nslab)), self.entry)
+        check(getattr(lib(), self.entry)(*self.args_of(nslab, st)), self.entry)
         return (self.work, self.dw_ptr, nslab.value, self.dw_numel), self.flops, 4.0 * (self.small.numel() + self.big.numel())
 
 
@@ -250,14 +253,13 @@ def conv3d_wgrad(small, big, stride, out_shape, param=None):
     dw = torch.empty(out_shape, device=small.device, dtype=torch.float32)
     assert dw.numel() == a * bc * 27
     if BATCH_WGRAD and _can_defer(param):
-        st = _stream(dw)
         ent = _pending_entry(dw.device.index, True)
         cur = torch.cuda.current_stream(dw.device)
         if cur not in ent[0]:
             ent[0].append(cur)
         dwp = dw.data_ptr()         # (the closure must not capture dw itself)
-        ent[2].append(_DeferredWgrad("mdf_conv3d_wgrad_partial", lambda ns: (small.data_ptr(), big.data_ptr(), dwp, work.data_ptr(), b, ds, hs, ws,
-                                                                             a, bc, stride, ctypes.byref(ns), st),
+        ent[2].append(_DeferredWgrad("mdf_conv3d_wgrad_partial", lambda ns, st: (small.data_ptr(), big.data_ptr(), dwp, work.data_ptr(), b, ds, hs, ws,
+                                                                                 a, bc, stride, ctypes.byref(ns), st),
                                      small, big, dw, work, 2.0 * 27 * a * bc * b * ds * hs * ws))
         return dw
     nslab = ctypes.c_int(0)
@@ -565,14 +567,13 @@ def conv2d_wgrad(small, big, ksize, stride, out_shape, param=None, hold=None):
     work = torch.empty(n, device=small.device, dtype=torch.float32)
     dw = torch.empty((a, bc, ksize, ksize), device=small.device, dtype=torch.float32)
     if BATCH_WGRAD and hold is None and tuple(out_shape) == tuple(dw.shape) and _can_defer(param):
-        st = _stream(dw)
         ent = _pending_entry(dw.device.index, True)
         cur = torch.cuda.current_stream(dw.device)
         if cur not in ent[0]:
             ent[0].append(cur)
         dwp = dw.data_ptr()         # (the closure must not capture dw itself)
-        ent[2].append(_DeferredWgrad("mdf_conv2d_wgrad_partial", lambda ns: (small.data_ptr(), big.data_ptr(), dwp, work.data_ptr(), b, hs, ws, a, bc,
-                                                                             ksize, stride, ctypes.byref(ns), st),
+        ent[2].append(_DeferredWgrad("mdf_conv2d_wgrad_partial", lambda ns, st: (small.data_ptr(), big.data_ptr(), dwp, work.data_ptr(), b, hs, ws, a, bc,
+                                                                                 ksize, stride, ctypes.byref(ns), st),
                                      small, big, dw, work, 2.0 * ksize * ksize * a * bc * b * hs * ws))
         return dw
     nslab = ctypes.c_int(0)

@@ -5,6 +5,58 @@ import torch
 from mdfnet_hip import controlplane, hostmirror, layers, ops
 
 
+import contextlib
+import os as _os
+
+_STAGE_STREAMS = bool(int(_os.environ.get("MDF_TRAIN_STAGE_STREAMS", "1")))      # dev A/B: 0 = the whole training step on one stream
+_SIDE = {}
+
+
+def _stage_streams(device, n):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), n)
+    if key not in _SIDE:
+        _SIDE[key] = [torch.cuda.Stream(device) for _ in range(n)]
+    return _SIDE[key]
+
+
+@contextlib.contextmanager
+def _on_stage_stream(side, stage, main, feats):
+    """Issue the body on side[stage]: forked from `main` before, joined into it after (inside a hipGraph recording both edges are
+    recorded).  The feature maps were allocated on `main` and are read on the stage's stream."""
+    if not side:
+        yield
+        return
+    st = side[stage]
+    st.wait_stream(main)
+    for f in feats:
+        base = getattr(f, "_mdf_parent", None)
+        (base[0] if base is not None else f).record_stream(st)
+    with torch.cuda.stream(st):
+        yield
+    main.wait_stream(st)
+
+
+def _cut_features(feats, cuts):
+    """One stage's per-view feature maps -> detached copies that require grad (leaves of the stage's backward chain), noted in
+    `cuts`.  The views of one view-major tensor (FPN_4Scales.forward_views) stay slices of ONE cut tensor, so the aggregation slot
+    still takes it -- and returns its gradient -- whole."""
+    parents = [getattr(f, "_mdf_parent", None) for f in feats]
+    pairs = []
+    if all(p is not None and p[0] is parents[0][0] and p[1] == i and p[2] == len(feats) for i, p in enumerate(parents)):
+        y = parents[0][0]
+        yc = y.detach().requires_grad_(True)
+        b = y.shape[0] // len(feats)
+        out = [yc[g * b:(g + 1) * b] for g in range(len(feats))]
+        for g, t in enumerate(out):
+            t._mdf_parent = (yc, g, len(feats))
+        pairs.append((y, yc))
+    else:
+        out = [f.detach().requires_grad_(True) for f in feats]
+        pairs.extend(zip(feats, out))
+    cuts.feat.append(pairs)
+    return out
+
+
 class CoreNet(torch.nn.Module):
     def __init__(self, Backbone, Depth_hypos, scale, Homoaggre, Regular, Regress, Refine):
         """Backbone: img -> 3 feature maps; Depth_hypos/Homoaggre/Regular: ModuleLists (one per stage);
@@ -76,19 +128,47 @@ class CoreNet(torch.nn.Module):
         pyramids = self._pyramids(origin_imgs.float(), feature_cache, view_keys)
         depth = hypos = prob = None
         depths = []
+        # Training on the HIP kernels: every stage's aggregation + regulariser is issued on a stream of its own.  The forward pass
+        # gains nothing (stage s+1 needs stage s's depth: the streams are chained by events), but autograd runs a node's backward
+        # on the stream of its forward, and the three stages' backward chains do not depend on each other -- the hypotheses are
+        # built under no_grad (depthhypos.py:40,188) and the refinement net detaches its input (refine.py:29) -- so they run side
+        # by side until they meet at the feature pyramid: the small-volume launches of one stage fill the CUs another leaves idle.
+        side = cuts = None
+        if self.training and origin_imgs.is_cuda and torch.is_grad_enabled() and layers.hip_train(self, origin_imgs):
+            cuts = layers.active_cuts()      # a recorded step that takes the backward pass in pieces (layers.StageCuts)
+            # (a hipGraph with parallel branches is replayed node by node by the host -- 6.5 ms per cfg3 step --, so a recording
+            #  keeps one stream unless it cuts the stage chains out into graphs of their own)
+            if cuts is not None or (_STAGE_STREAMS and not torch.cuda.is_current_stream_capturing()):
+                side = _stage_streams(origin_imgs.device, len(self.Regular))
+                main = torch.cuda.current_stream(origin_imgs.device)
+                if cuts is not None:
+                    cuts.streams = side
         for stage, (make_hypos, aggregate, regular) in enumerate(zip(self.Depth_hypos, self.Homoaggre, self.Regular)):
             feats = [p[stage] for p in pyramids]
+            if cuts is not None:
+                feats = _cut_features(feats, cuts)
             ref_proj, src_projs = self.scale(intrinsics, extrinsics, stage)
-            hypos = make_hypos(depth, depth_range, prob, hypos, upsample=True)
-            cost = aggregate(feats, ref_proj, src_projs, hypos)
-            if ((not self.training or cost.is_cuda) and getattr(regular, "fused_regress", False)
-                    and getattr(self.Depth_regress, "mdf_builtin", False)):
-                # both slots are the built-in ones: the soft-argmin (core.py:64) rides in the regulariser's softmax kernel
-                # (same arithmetic as the standalone slot, asserted equal in tests/test_regular_gpu.py)
-                prob, depth = regular(cost, hypos)
-            else:
-                prob = regular(cost)
-                depth = self.Depth_regress(prob, hypos)
+            with _on_stage_stream(side, stage, main if side else None, feats):
+                hypos = make_hypos(depth, depth_range, prob, hypos, upsample=True)
+                cost = aggregate(feats, ref_proj, src_projs, hypos)
+                if ((not self.training or cost.is_cuda) and getattr(regular, "fused_regress", False)
+                        and getattr(self.Depth_regress, "mdf_builtin", False)):
+                    # both slots are the built-in ones: the soft-argmin (core.py:64) rides in the regulariser's softmax kernel
+                    # (same arithmetic as the standalone slot, asserted equal in tests/test_regular_gpu.py)
+                    prob, depth = regular(cost, hypos)
+                else:
+                    prob = regular(cost)
+                    depth = self.Depth_regress(prob, hypos)
+            if side:
+                # produced on the stage's stream; read by the next stage's stream and by the caller's (loss, refinement net)
+                for t in (hypos, prob, depth):
+                    t.record_stream(main)
+                    if stage + 1 < len(side):
+                        t.record_stream(side[stage + 1])
+            if cuts is not None:
+                cut = depth.detach().requires_grad_(True)
+                cuts.depth.append((depth, cut))
+                depth = cut
             depths.append(depth)
         depth = self.Refine(depth, depth_range)
         depths.append(depth)

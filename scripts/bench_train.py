@@ -10,6 +10,7 @@ from mdfnet_hip import synth, ddp, ops
 from net import loss as loss_mod
 dev = torch.device('cuda', 0)
 W, H, V = (int(x) for x in os.environ.get("MDF_TRAIN_SHAPE", "768,576,5").split(","))
+NB = int(os.environ.get("MDF_TRAIN_BATCH", "1"))          # dev: a larger batch makes the eager step GPU-bound (stream A/Bs)
 model = bench.build(dev).train()
 bucket = ddp.FlatBucket(model)
 if os.environ.get("MDF_TRAIN_STOCK") == "1":
@@ -20,8 +21,8 @@ else:
     from mdfnet_hip.optim import FlatAdam
     opt = FlatAdam(bucket, lr=1e-3)
 crit = loss_mod.Loss().to(dev)
-imgs, extr, intr, dr = (t.to(dev) for t in synth.make_scene(W, H, V, batch=1, rot_deg=2.0, seed=3))
-gt = {str(k): (torch.rand(1, H >> k, W >> k, device=dev) * 400 + 480) for k in (3, 2, 1, 0)}   # dtutrain.py:55-58 key order
+imgs, extr, intr, dr = (t.to(dev) for t in synth.make_scene(W, H, V, batch=NB, rot_deg=2.0, seed=3))
+gt = {str(k): (torch.rand(NB, H >> k, W >> k, device=dev) * 400 + 480) for k in (3, 2, 1, 0)}   # dtutrain.py:55-58 key order
 def step():
     out = model(imgs, extr, intr, dr)
     loss = crit(out, gt, dr)
