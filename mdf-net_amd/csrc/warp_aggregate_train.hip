@@ -233,7 +233,10 @@ __global__ __launch_bounds__(kThreads) void warp_train_kernel(const TrainParams 
 // accumulated there with LDS atomics and the window is flushed once with DENSE global atomics (whole rows of the
 // window are contiguous in the NHWC gradient map) -- each texel is sent to memory once per chunk instead of once per
 // tap; a block whose footprint does not fit (strong rotation, very wide depth range) scatters to memory directly.
-constexpr int kWinFloats = 8192;   // 32 KiB
+#ifndef MDF_BWD_WIN_FLOATS
+#define MDF_BWD_WIN_FLOATS 4096
+#endif
+constexpr int kWinFloats = MDF_BWD_WIN_FLOATS;   // 16 KiB: with the tap table (16-32 KiB) four blocks per CU
 
 // LDS float add through an address-space-3 pointer: `ds_add_f32` (with a generic pointer next to the global fallback the
 // compiler merges both branches into one `flat_atomic_add_f32` on a selected 64-bit address).
@@ -252,12 +255,20 @@ __device__ __forceinline__ void lds_add(float* p, float v) {
 // instructions in order): the pixel whose id survived adds non-atomically; the others on that texel and every pixel with
 // clamped corners use atomic adds, in a separate basic block.
 template <int C>
+struct BwdTile {      // pixels of a scatter tile: 16 x 4 (C = 16), 8 x 4 (C = 32), 4 x 4 (C = 64)
+  static constexpr int PPB = kThreads / (C / 4);
+  static constexpr int TH = 4, TW = PPB / TH;
+};
+
+template <int C>
 __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p) {
   constexpr int LPP = C / 4;            // lanes per pixel over the whole block
   constexpr int PPB = kThreads / LPP;   // pixels per tile = pixels per wave (every wave sees all of them)
   constexpr int LW = LPP / 4;           // lanes per pixel inside one wave (4 channels each)
   constexpr int G = C / 2;
+  constexpr int TW = BwdTile<C>::TW, TH = BwdTile<C>::TH;
   static_assert(PPB * LW == 64, "a wave holds every pixel of the tile");
+  static_assert(TW * TH == PPB, "tile shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   TapXY* tab = reinterpret_cast<TapXY*>(smem);
   float* win = reinterpret_cast<float*>(smem + (size_t)p.dchunk * p.n_src * PPB * sizeof(TapXY));
@@ -269,12 +280,15 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
   const int W = p.g.w;
   const int b = blockIdx.y;
   const int tile = (int)mdf::xcd_remap(blockIdx.x, p.nblk_x);
-  const int pix0 = tile * PPB;
+  // a tile is BwdTile<C>::TW x TH pixels, not a run of a row: its taps' bounding box in a source map is (TW+1) x (TH+1) texels plus the
+  // depth sweep instead of a slanted (PPB+1)-texel line's box -- half the window texels to zero and flush, and a window that fits
+  const int tiles_x = (W + TW - 1) / TW;
+  const int tile_y0 = (tile / tiles_x) * TH, tile_x0 = (tile % tiles_x) * TW;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int pl = lane / LW, sub = wave * LW + lane % LW;    // pixel of the tile, 4-channel slot of the pixel
-  const int pix = min(pix0 + pl, hw - 1);
-  const bool live = (pix0 + pl) < hw;
+  const bool live = (tile_x0 + pl % TW) < W && (tile_y0 + pl / TW) < p.g.h;
+  const int pix = min(tile_y0 + pl / TW, p.g.h - 1) * W + min(tile_x0 + pl % TW, W - 1);
   volatile unsigned char* my_claim = claim[wave];
 
   float r[4];
@@ -311,8 +325,9 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
       const int epl = e % PPB;
       const int ev = v_lo + (e / PPB) % nv;
       const int ed = e / (PPB * nv);
-      const int epix = min(pix0 + epl, hw - 1);
-      const int yy = epix / W, xx = epix - yy * W;
+      const bool elive = (tile_x0 + epl % TW) < W && (tile_y0 + epl / TW) < p.g.h;
+      const int yy = min(tile_y0 + epl / TW, p.g.h - 1), xx = min(tile_x0 + epl % TW, W - 1);
+      const int epix = yy * W + xx;
       const float* m = p.proj + ((size_t)ev * p.B + b) * 12;
       const int d = d0 + ed;
       const float dep = p.hypos_per_pixel ? p.hypos[((size_t)b * p.D + d) * hw + epix] : p.hypos[(size_t)b * p.D + d];
@@ -321,7 +336,7 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
       TapXY t;
       tap_weights_corners(ix, iy, p.g, t.wt, t.xa, t.xb, t.ya, t.yb);
       tab[e] = t;
-      if ((pix0 + epl) < hw) {
+      if (elive) {
         const bool a = (t.wt[0] != 0.0f) || (t.wt[2] != 0.0f), bq = (t.wt[1] != 0.0f) || (t.wt[3] != 0.0f);   // column xa / xb live
         const bool cq = (t.wt[0] != 0.0f) || (t.wt[1] != 0.0f), dq = (t.wt[2] != 0.0f) || (t.wt[3] != 0.0f);  // row ya / yb live
         if (a || bq) {
@@ -486,8 +501,7 @@ __global__ __launch_bounds__(kThreads) void warp_bwd_kernel(const TrainParams p)
 // A block walks its pixels over the planes one (plane, view) at a time, each step a dependent gather: with the few blocks of a
 // cfg3-sized map (432 at 72x96x64ch) the chip holds < 2 waves per SIMD and the kernel is latency-bound.  Cut the depth range
 // into slices (gridDim.z) until there are a few thousand blocks; per-pixel results that span the planes (d ref) meet through atomics.
-int depth_slices(TrainParams& p, int& dch) {
-  static const int target = [] { const char* e = getenv("MDF_WARP_TRAIN_BLOCKS"); return (e && atoi(e) > 0) ? atoi(e) : 2048; }();   // dev A/B
+int depth_slices(TrainParams& p, int& dch, int target) {
   const long long blocks = (long long)p.nblk_x * p.B;
   int nz = (int)((target + blocks - 1) / blocks);
   if (nz > p.D / 4) nz = p.D / 4;          // >= 4 planes per slice: a slice re-reads the reference features and the tap setup
@@ -502,11 +516,19 @@ int depth_slices(TrainParams& p, int& dch) {
 
 int launch_bwd(TrainParams& p, int C, hipStream_t st) {
   const int lpp = C / 4, ppb = kThreads / lpp;
-  const int hw = p.g.h * p.g.w;
-  p.nblk_x = (hw + ppb - 1) / ppb;
-  int dch = 512 / (p.n_src * ppb);
+  const int th = 4, tw = ppb / th;            // BwdTile<C>
+  p.nblk_x = ((p.g.w + tw - 1) / tw) * ((p.g.h + th - 1) / th);
+  // tap-table entries per block: uniform hypotheses (stage 0) sweep an epipolar segment and amortise a view's window over more
+  // planes; per-pixel hypotheses take a whole view's planes anyway
+  static const int tab_env = [] { const char* e = getenv("MDF_WARP_BWD_TAB"); return (e && atoi(e) > 0) ? atoi(e) : 0; }();   // dev A/B
+  const int tab_entries = tab_env ? tab_env : (p.hypos_per_pixel ? 512 : 1024);
+  int dch = tab_entries / (p.n_src * ppb);
   if (dch < 1) dch = 1;
-  const int nz = depth_slices(p, dch);
+  // depth slices of the scatter: with per-pixel hypotheses a pixel's planes hit the same few texels, and their tap sums stay in
+  // registers across ALL the planes a block walks -- slicing the depth range costs more than the extra blocks bring (cfg3 stage 2:
+  // 178 us unsliced, 284 in two slices); uniform hypotheses (stage 0, 432 blocks at cfg3) take three slices (162 us; 192 in two)
+  static const int target_env = [] { const char* e = getenv("MDF_WARP_BWD_BLOCKS"); return (e && atoi(e) > 0) ? atoi(e) : 0; }();   // dev A/B
+  const int nz = depth_slices(p, dch, target_env ? target_env : (p.hypos_per_pixel ? 768 : 1024));
   p.dchunk = dch;
   const char* dbg = getenv("MDF_WARP_BWD_ATOMIC");      // read per call: tests flip it inside one process
   p.all_atomic = (dbg && atoi(dbg) > 0) ? atoi(dbg) : 0;     // bit 0: all-atomic window updates; bit 1: timing experiment without the flush
@@ -528,7 +550,8 @@ int launch_train(TrainParams& p, int C, hipStream_t st) {
   p.nblk_x = (hw + ppb - 1) / ppb;
   int dch = 512 / (p.n_src * ppb);
   if (dch < 1) dch = 1;
-  const int nz = depth_slices(p, dch);
+  static const int target_env = [] { const char* e = getenv("MDF_WARP_TRAIN_BLOCKS"); return (e && atoi(e) > 0) ? atoi(e) : 0; }();   // dev A/B
+  const int nz = depth_slices(p, dch, target_env ? target_env : (p.hypos_per_pixel ? 1024 : 2048));
   p.dchunk = dch;
   const size_t lds = (size_t)dch * p.n_src * ppb * sizeof(TapEntry);
   dim3 grid(p.nblk_x, p.B, nz), block(kThreads);

@@ -24,10 +24,10 @@ What has to hold for a recording to stay valid, and how each point is met:
 Stage-parallel backward (default; MDF_TRAIN_GRAPH_SPLIT=0 records the step as ONE graph): the backward chains of the three stages
 (regulariser + aggregation, ~60 % of the step's launches, many of them small-volume layers that fill a fraction of the chip) share
 nothing until they meet at the feature pyramid.  A hipGraph with parallel branches does not help -- the runtime replays it node
-by node from the host (6.5 ms of host time per cfg3 step, slower than the chain) -- so the step is recorded as FIVE chain-shaped
-graphs: F (forward, loss, loss backward down to each stage's depth), S0 / S1 / S2 (one stage's backward chain each, recorded on
-the stage's own stream into its own memory pool), C (feature pyramid + trunk backward, weight-gradient sums, bucket gather, Adam).
-A replay is F, then the three S graphs side by side on three streams, then C.  The cuts are made by CoreNet's forward
+by node from the host (6.5 ms of host time per cfg3 step, slower than the chain) -- so the step is recorded as SIX chain-shaped
+graphs: F (forward, loss, the loss's own backward), S0 / S1 / S2 (one stage's backward chain each, recorded on the stage's own
+stream into its own memory pool), R (the refinement net's backward: parameters only), C (feature pyramid + trunk backward,
+weight-gradient sums, bucket gather, Adam).  A replay is F, then the three S graphs on three streams with R beside them, then C.  The cuts are made by CoreNet's forward
 (layers.StageCuts); the gradients are those of the one-piece backward pass (no sum crosses a cut).
 
 Data parallelism: with more than one rank the gradient all-reduce stays OUTSIDE the graphs -- recording A ends with the bucket
@@ -127,6 +127,11 @@ class GraphedTrainStep:
         if cut.grad is not None:
             torch.autograd.backward([depth], [cut.grad])    # regulariser + aggregation of stage s -> d features, parameters
 
+    @staticmethod
+    def _piece_r(cuts):
+        if cuts.refine is not None and cuts.refine[1].grad is not None:
+            torch.autograd.backward([cuts.refine[0]], [cuts.refine[1].grad])      # the refinement net's parameter gradients
+
     def _piece_c(self, cuts):
         roots = [(y, yc.grad) for pairs in cuts.feat for (y, yc) in pairs if yc.grad is not None]
         torch.autograd.backward([r[0] for r in roots], [r[1] for r in roots])      # feature pyramid + trunk
@@ -142,6 +147,7 @@ class GraphedTrainStep:
                 st.wait_stream(cur)
                 with torch.cuda.stream(st):
                     self._piece_stage(cuts, s)
+            self._piece_r(cuts)
             for st in cuts.streams:
                 cur.wait_stream(st)
             self._piece_c(cuts)
@@ -160,7 +166,7 @@ class GraphedTrainStep:
         self._pool = train_ops.step_pool(dev)               # its buffer's address is in the recording: not replaced while this
         self._pool.held_by_recording += 1                   # object lives (ZeroPool.take raises instead)
         self.graph_a = torch.cuda.CUDAGraph()
-        self.graph_s, self.graph_c, self.side = [], None, None
+        self.graph_s, self.graph_c, self.graph_r, self.side = [], None, None, None
         if self.split:
             with torch.cuda.graph(self.graph_a, stream=self.stream):
                 self.loss, cuts = self._piece_f()
@@ -170,6 +176,10 @@ class GraphedTrainStep:
                 with torch.cuda.graph(g, stream=st):
                     self._piece_stage(cuts, s)
                 self.graph_s.append(g)
+            if cuts.refine is not None and cuts.refine[1].grad is not None:
+                self.graph_r = torch.cuda.CUDAGraph()       # on the caller's stream, while the stage chains run on theirs
+                with torch.cuda.graph(self.graph_r, stream=self.stream):
+                    self._piece_r(cuts)
             self.graph_c = torch.cuda.CUDAGraph()           # replayed after everything else: may reuse what F's pool has freed
             with torch.cuda.graph(self.graph_c, stream=self.stream, pool=self.graph_a.pool()):
                 self._piece_c(cuts)
@@ -216,6 +226,8 @@ class GraphedTrainStep:
                 st.wait_stream(cur)
                 with torch.cuda.stream(st):
                     g.replay()
+            if self.graph_r is not None:
+                self.graph_r.replay()
             for st in self.side:
                 cur.wait_stream(st)
             self.graph_c.replay()

@@ -105,6 +105,7 @@ class StageCuts:
 
     def __init__(self):
         self.feat, self.depth, self.streams = [], [], None      # [stage] -> [(tensor, cut)], (depth, cut); the stages' streams
+        self.refine = None                                      # (refined depth, cut)
 
 
 @contextlib.contextmanager

@@ -171,6 +171,10 @@ class CoreNet(torch.nn.Module):
                 depth = cut
             depths.append(depth)
         depth = self.Refine(depth, depth_range)
+        if cuts is not None and depth.requires_grad:
+            cut = depth.detach().requires_grad_(True)       # the refinement net's backward (parameters only: refine.py:29 detaches
+            cuts.refine = (depth, cut)                      # its input) is a piece of its own, replayed beside the stage chains
+            depth = cut
         depths.append(depth)
         if self.training:
             return {"depth": depths}

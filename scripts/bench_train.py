@@ -45,6 +45,20 @@ if os.environ.get("MDF_TRAIN_GRAPH") == "1":       # the same step recorded once
     torch.cuda.synchronize(); dtg = (time.perf_counter() - t0) / n
     print(f"train step {W}x{H}x{V} B=1 [one hipGraph replay per step]: {dtg*1e3:.2f} ms ({1/dtg:.2f} samples/s; host {t_issue*1e3:.2f} ms per step), "
           f"loss {float(lg):.3f}, recording {trec:.2f} s, eager {dt*1e3:.2f} ms", flush=True)
+    if gstep.graph_c is not None and os.environ.get("MDF_TRAIN_PIECES") == "1":
+        # the five graphs of the split recording, each replayed ALONE (synchronised on both sides): what runs beside what
+        def timed(g, st=None):
+            ts = []
+            for _ in range(10):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                if st is None: g.replay()
+                else:
+                    with torch.cuda.stream(st): g.replay()
+                torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+            return sorted(ts)[len(ts) // 2] * 1e3
+        gstep._upload(*[__import__("mdfnet_hip").hostmirror.get(t) for t in (extr, intr, dr)])
+        parts = [("F", timed(gstep.graph_a))] + [(f"S{i}", timed(g, st)) for i, (g, st) in enumerate(zip(gstep.graph_s, gstep.side))] + ([("R", timed(gstep.graph_r))] if gstep.graph_r is not None else []) + [("C", timed(gstep.graph_c))]
+        print("pieces alone (ms): " + ", ".join(f"{k} {v:.2f}" for k, v in parts) + f"; sum {sum(v for _, v in parts):.2f}", flush=True)
 mode = "stock PyTorch-ROCm autograd" if os.environ.get("MDF_TRAIN_STOCK") == "1" else "HIP training kernels"
 print(f"train step {W}x{H}x{V} B=1 [{mode}]: {dt*1e3:.1f} ms  ({1/dt:.2f} samples/s), loss {float(l):.3f}, peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
 if os.environ.get("MDF_TRAIN_STOCK") != "1" and not os.environ.get("MDF_TRAIN_NOPROFILE"):
