@@ -47,13 +47,12 @@ __global__ __launch_bounds__(kThreads) void warp_kernel(const Params p) {
 
   const int hw = p.g.h * p.g.w;
   const int b = blockIdx.y;
-  const int tile = (int)mdf::xcd_remap(blockIdx.x, p.nblk_x);
-  const int pix0 = tile * PPB;
+  const PixTile<PPB> pt((int)mdf::xcd_remap(blockIdx.x, p.nblk_x), p.g.w);
   const int tid = threadIdx.x;
   const int pl = tid / LPP;   // pixel inside the block tile
   const int sub = tid % LPP;  // which 4-channel slice of the pixel
-  const int pix = min(pix0 + pl, hw - 1);
-  const bool live = (pix0 + pl) < hw;
+  bool live;
+  const int pix = pt.pix(pl, p.g.w, p.g.h, live);
   const int G = C / 2;
 
   // per-lane constants
@@ -86,7 +85,8 @@ __global__ __launch_bounds__(kThreads) void warp_kernel(const Params p) {
   const bool fixed_pair = (kThreads % npair) == 0;
   const int pa_pair = tid % npair, pa_grp = tid / npair, pa_ngrp = kThreads / npair;
   const int pa_pl = pa_pair % PPB, pa_v = pa_pair / PPB;
-  const int pa_pix = min(pix0 + pa_pl, hw - 1);
+  bool pa_live;
+  const int pa_pix = pt.pix(pa_pl, p.g.w, p.g.h, pa_live);
   PixelRay ray{};
   if (fixed_pair) {
     const int yy = pa_pix / p.g.w, xx = pa_pix - yy * p.g.w;
@@ -112,7 +112,8 @@ __global__ __launch_bounds__(kThreads) void warp_kernel(const Params p) {
         const int epl = e % PPB;
         const int ev = (e / PPB) % p.n_src;
         const int ed = e / (PPB * p.n_src);
-        const int epix = min(pix0 + epl, hw - 1);
+        bool elive;
+        const int epix = pt.pix(epl, p.g.w, p.g.h, elive);
         const int yy = epix / p.g.w, xx = epix - yy * p.g.w;
         const float* m = p.proj + ((size_t)ev * p.B + b) * 12;
         const int d = d0 + ed;
@@ -239,12 +240,11 @@ __global__ __launch_bounds__(kThreads, MDF_VEC8_MIN_BLOCKS) void warp_vec8_kerne
   TapEntry* tab = reinterpret_cast<TapEntry*>(smem);
   const int hw = p.g.h * p.g.w;
   const int b = blockIdx.y;
-  const int tile = (int)mdf::xcd_remap(blockIdx.x, p.nblk_x);
-  const int pix0 = tile * PPB;
+  const PixTile<PPB> pt((int)mdf::xcd_remap(blockIdx.x, p.nblk_x), p.g.w);
   const int tid = threadIdx.x;
   const int pl = tid / LPP, sub = tid % LPP;
-  const int pix = min(pix0 + pl, hw - 1);
-  const bool live = (pix0 + pl) < hw;
+  bool live;
+  const int pix = pt.pix(pl, p.g.w, p.g.h, live);
 
   float rd[2][2], r1[2][2], cw[2][2];          // [half j = 4-channel slice 2*sub + j][group]: r0 - r1, r1 of the reference softmax; conv weights
 #pragma unroll
@@ -273,7 +273,8 @@ __global__ __launch_bounds__(kThreads, MDF_VEC8_MIN_BLOCKS) void warp_vec8_kerne
   for (int k = 0; k < 2; ++k) {
     const int pair = (few ? tid % npair : tid) + k * kThreads;
     pa_pl[k] = pair % PPB; pa_v[k] = min(pair / PPB, p.n_src - 1);
-    pa_pix[k] = min(pix0 + pa_pl[k], hw - 1);
+    bool pa_live;
+    pa_pix[k] = pt.pix(pa_pl[k], p.g.w, p.g.h, pa_live);
     const int yy = pa_pix[k] / p.g.w, xx = pa_pix[k] - yy * p.g.w;
     ray[k] = warp_ray(p.proj + ((size_t)pa_v[k] * p.B + b) * 12, (float)xx, (float)yy);
   }
@@ -300,7 +301,8 @@ __global__ __launch_bounds__(kThreads, MDF_VEC8_MIN_BLOCKS) void warp_vec8_kerne
         const int epl = e % PPB;
         const int ev = (e / PPB) % p.n_src;
         const int ed = e / (PPB * p.n_src);
-        const int epix = min(pix0 + epl, hw - 1);
+        bool elive;
+        const int epix = pt.pix(epl, p.g.w, p.g.h, elive);
         const int yy = epix / p.g.w, xx = epix - yy * p.g.w;
         const float* m = p.proj + ((size_t)ev * p.B + b) * 12;
         const int d = d0 + ed;
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(kThreads, MDF_VEC8_MIN_BLOCKS) void warp_vec8_kerne
 template <int C>
 int launch_vec8(Params& p, hipStream_t st) {
   constexpr int ppb = kThreads / (C / 8);
-  p.nblk_x = (p.g.h * p.g.w + ppb - 1) / ppb;
+  p.nblk_x = PixTile<ppb>::blocks(p.g.w, p.g.h);
   int dch = MDF_VEC8_TAB / (p.n_src * ppb);  // ~32 KiB of tap table per block (twice the pixels of warp_kernel's tile, the same planes)
   if (dch < 1) dch = 1;
   if (dch > p.D) dch = p.D;
@@ -580,8 +582,7 @@ __global__ void corner_index_kernel(const float* __restrict__ proj, const float*
 template <int MODE>
 int launch(Params& p, int C, hipStream_t st) {
   const int lpp = C / 4, ppb = kThreads / lpp;
-  const int hw = p.g.h * p.g.w;
-  p.nblk_x = (hw + ppb - 1) / ppb;
+  p.nblk_x = (C == 64) ? PixTile<16>::blocks(p.g.w, p.g.h) : (C == 32) ? PixTile<32>::blocks(p.g.w, p.g.h) : PixTile<64>::blocks(p.g.w, p.g.h);
   int dch = 512 / (p.n_src * ppb);  // ~16 KiB of tap table per block
   if (dch < 1) dch = 1;
   if (dch > p.D) dch = p.D;

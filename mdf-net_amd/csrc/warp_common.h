@@ -8,6 +8,42 @@ namespace {
 
 constexpr int kThreads = 256;
 
+// Pixels of a block's tile.  TH = 0: a run of PPB consecutive pixels in row-major order (wraps over row ends); TH > 0: a
+// (PPB / TH) x TH rectangle -- the taps of vertically neighbouring pixels share source texels inside ONE block's L1 working set
+// instead of across blocks, and a tile's footprint in a source map is a compact box instead of a slanted line.
+#ifndef MDF_WARP_TILE_H
+#define MDF_WARP_TILE_H 0
+#endif
+template <int PPB, int TH = MDF_WARP_TILE_H>
+struct PixTile {
+  static constexpr int TW = (TH > 0) ? PPB / TH : PPB;
+  static_assert(TH == 0 || TW * TH == PPB, "tile shape");
+  int x0, y0, lin0;
+  __device__ __forceinline__ PixTile(int tile, int W) {
+    if constexpr (TH > 0) {
+      const int tx = (W + TW - 1) / TW;
+      y0 = (tile / tx) * TH; x0 = (tile % tx) * TW; lin0 = 0;
+    } else {
+      x0 = y0 = 0; lin0 = tile * PPB;
+    }
+  }
+  // -> linear pixel index (clamped into the map), live = the tile slot is a pixel of the map
+  __device__ __forceinline__ int pix(int pl, int W, int H, bool& live) const {
+    if constexpr (TH > 0) {
+      const int x = x0 + pl % TW, y = y0 + pl / TW;
+      live = (x < W) && (y < H);
+      return min(y, H - 1) * W + min(x, W - 1);
+    } else {
+      live = (lin0 + pl) < W * H;
+      return min(lin0 + pl, W * H - 1);
+    }
+  }
+  static int blocks(int W, int H) {
+    if constexpr (TH > 0) return ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+    else return (W * H + PPB - 1) / PPB;
+  }
+};
+
 struct Geom {
   float half_w, half_h;  // f32((w-1)/2), f32((h-1)/2)       base.py:117-118
   float sw, sh;          // f32(w/2), f32(h/2)               ATen unnormalise scale
