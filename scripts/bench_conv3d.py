@@ -14,9 +14,12 @@ L = [("s0.conv01.0", 32, 16, "s1", 48, 148, 200), ("s0.conv01.1", 16, 16, "s1", 
      ("s1.conv01", 16, 8, "s1", 24, 296, 400), ("s1.conv12.0", 8, 16, "s2", 24, 296, 400),
      ("s1.conv12.1", 16, 16, "s1", 12, 148, 200), ("s1.conv23.1", 32, 32, "s1", 6, 74, 100),
      ("s1.trconv21T", 16, 8, "tr", 12, 148, 200),
-     ("s2.conv01", 8, 8, "s1", 8, 592, 800), ("s2.conv12.1", 16, 16, "s1", 4, 296, 400), ("s2.trconv21T", 16, 8, "tr", 4, 296, 400)]
+     ("s2.conv01", 8, 8, "s1", 8, 592, 800), ("s2.conv12.0", 8, 16, "s2", 8, 592, 800), ("s2.conv12.1", 16, 16, "s1", 4, 296, 400),
+     ("s2.trconv21T", 16, 8, "tr", 4, 296, 400)]
 if "--tr" in sys.argv:
     L = [l for l in L if l[3] == "tr"]
+if "--s2" in sys.argv:
+    L = [l for l in L if l[3] == "s2"]
 dev = "cuda:0"
 check = "--check" in sys.argv
 tot_ms = tot_fl = 0.0
