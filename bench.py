@@ -306,8 +306,9 @@ def train_family(name, tag):
         return "conv3d forward + input gradients (regulariser): conv_lds_kernel / conv3d_kernel, fp32 MFMA"
     if name in ("mdf_conv2d_fwd", "mdf_conv2d_train_fwd"):
         return "conv2d forward + input gradients (feature pyramid, refine, prob partial sums): conv_lds_kernel, fp32 MFMA"
-    if name in ("mdf_conv3d_wgrad", "mdf_conv3d_wgrad_partial", "mdf_wgrad_sum_batch"):
-        return "wgrad3d: wgrad_lds_kernel / wgrad_kernel (weight gradients, split-K fp32 MFMA)"
+    if name in ("mdf_conv3d_wgrad", "mdf_conv3d_wgrad_partial", "mdf_wgrad_sum_batch", "mdf_wgrad_batch_flush"):
+        # (mdf_wgrad_batch_flush: the step's deferred weight gradients, 3-D and 2-D, as one job-table launch per kernel form)
+        return "wgrad3d: wgrad_lds_kernel / wgrad_lds_batch_kernel / wgrad_kernel (weight gradients, split-K fp32 MFMA; the batched launch carries the 2-D layers' too)"
     if name in ("mdf_conv2d_wgrad", "mdf_conv2d_wgrad_partial"):
         return "wgrad2d: wgrad_lds_kernel / wgrad2d_kernel (weight gradients, split-K fp32 MFMA)"
     if name.startswith("mdf_bn_"):
@@ -359,7 +360,14 @@ def training_block(dev, steps, blocks, stock_steps):
         times.append((time.perf_counter() - t0) / steps)
     med = statistics.median(times)
     assert torch.isfinite(last).item()
-    recs, info = bracketed_launches(step, 3)
+    # per-launch brackets on ONE stream: with the stages' backward chains on streams of their own (net/core.py) three launches run
+    # side by side and every bracket would read the time of all of them
+    from net import core as _core
+    streams_on, _core._STAGE_STREAMS = _core._STAGE_STREAMS, False
+    try:
+        recs, info = bracketed_launches(step, 3)
+    finally:
+        _core._STAGE_STREAMS = streams_on
     kernels = family_table(recs, 3, train_family)
     traffic, source = measured_traffic("train")
     gflop = sum(k.get("algorithmic_gflop_per_step", 0.0) for k in kernels)
