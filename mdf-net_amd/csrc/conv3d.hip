@@ -910,8 +910,14 @@ static int conv3d_entry(const float* x, const float* wpack, const float* alpha, 
   if (m == kTr && !stat) {   // large transposed layers: all four parity classes per tile (convtr_all_kernel)
     const long long tr_min = [] { const char* e = getenv("MDF_CONVTR_ALL_MIN_VOXELS"); return e ? atoll(e) : 100000LL; }();   // dev A/B (read per call); -1 = never
     if (tr_min >= 0 && p.m_total >= tr_min) {
-      if (Cin == 16 && Cout == 8) return launch_convtr_all<16, 8, 2>(p, (hipStream_t)stream);
-      if (Cin == 32 && Cout == 16) return launch_convtr_all<32, 16, 2>(p, (hipStream_t)stream);
+      // One 16-voxel m-tile per wave (r05; two until then): these layers' time is MFMA time PLUS streaming time (skip + output), and the
+      // smaller accumulator set lets 4-5 waves per SIMD instead of 3-4 overlap one block's streaming with another's MFMAs:
+      // 32->16 @24x74x100 89.2 -> 69.3 us, 16->8 @12x148x200 51.2 -> 47.4, @4x296x400 79.4 -> 74.7 (four tiles: 88 / 67 / 97)
+      const int mt = [] { const char* e = getenv("MDF_CONVTR_MT"); return e ? atoi(e) : 1; }();   // dev A/B (read per call)
+      if (Cin == 16 && Cout == 8 && mt == 2) return launch_convtr_all<16, 8, 2>(p, (hipStream_t)stream);
+      if (Cin == 32 && Cout == 16 && mt == 2) return launch_convtr_all<32, 16, 2>(p, (hipStream_t)stream);
+      if (Cin == 16 && Cout == 8) return launch_convtr_all<16, 8, 1>(p, (hipStream_t)stream);
+      if (Cin == 32 && Cout == 16) return launch_convtr_all<32, 16, 1>(p, (hipStream_t)stream);
       if (Cin == 64 && Cout == 32) return launch_convtr_all<64, 32, 1>(p, (hipStream_t)stream);
     }
   }
