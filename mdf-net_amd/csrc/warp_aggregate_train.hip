@@ -548,7 +548,8 @@ int launch_train(TrainParams& p, int C, hipStream_t st) {
   const int lpp = C / 4, ppb = kThreads / lpp;
   const int hw = p.g.h * p.g.w;
   p.nblk_x = (hw + ppb - 1) / ppb;
-  int dch = 512 / (p.n_src * ppb);
+  static const int tab_env = [] { const char* e = getenv("MDF_WARP_TRAIN_TAB"); return (e && atoi(e) > 0) ? atoi(e) : 512; }();   // dev A/B
+  int dch = tab_env / (p.n_src * ppb);
   if (dch < 1) dch = 1;
   static const int target_env = [] { const char* e = getenv("MDF_WARP_TRAIN_BLOCKS"); return (e && atoi(e) > 0) ? atoi(e) : 0; }();   // dev A/B
   const int nz = depth_slices(p, dch, target_env ? target_env : (p.hypos_per_pixel ? 1024 : 2048));
