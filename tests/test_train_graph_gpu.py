@@ -147,3 +147,42 @@ def test_replayed_training_tracks_eager_training():
         a = mg(imgs.to(DEV), extr.to(DEV), intr.to(DEV), dr.to(DEV))["depth"]
         b = fresh(imgs.to(DEV), extr.to(DEV), intr.to(DEV), dr.to(DEV))["depth"]
     assert torch.equal(a, b)
+
+
+def test_split_recording_equals_the_one_graph_recording():
+    """The step recorded as six chain-shaped graphs (forward | the three stages' backward chains on their own streams, the refinement
+    net's beside them | pyramid + trunk, bucket, Adam: layers.StageCuts cuts the autograd graph at every stage's features and depth)
+    against the same step recorded as ONE graph: no sum crosses a cut, so losses and gradients agree to the summation order of the
+    atomics both use, on inputs neither recording has seen."""
+    from mdfnet_hip import graphstep
+    crit = Loss().to(DEV)
+    s0 = _scene(0)
+    example = tuple(t.to(DEV) for t in s0[:4]) + ({k: v.to(DEV) for k, v in s0[4].items()},)
+    steps, buckets = [], []
+    for split in (True, False):
+        m = _model()
+        b = ddp.FlatBucket(m)
+        o = FlatAdam(b, lr=0.0)
+        graphstep.SPLIT_BACKWARD = split
+        try:
+            st = GraphedTrainStep(m, crit, b, o, example, warmup=2)
+        finally:
+            graphstep.SPLIT_BACKWARD = True
+        steps.append(st)
+        buckets.append(b)
+    sp, one = steps
+    assert sp.split and len(sp.graph_s) == 3 and sp.graph_r is not None and sp.graph_c is not None and len(set(sp.side)) == 3
+    assert not one.split and one.graph_c is None and not one.graph_s
+    for k in (2, 1, 3):
+        sc = _scene(k)
+        la, lb = float(sp(*sc)), float(one(*sc))
+        ga, gb = buckets[0].flat, buckets[1].flat
+        print(f"\nscene {k}: loss split {la:.6f} one graph {lb:.6f}; gradient L2 rel {_l2(ga, gb):.2e}")
+        assert abs(la - lb) <= 2e-5 * abs(lb)
+        assert torch.isfinite(ga).all() and _l2(ga, gb) < 1e-3
+        # every parameter received a gradient through the cuts (a cut that lost a branch would leave zeros behind)
+        off = 0
+        for p in buckets[0].params:
+            n = p.numel()
+            assert float(ga[off:off + n].abs().max()) > 0 or float(gb[off:off + n].abs().max()) == 0, "a parameter lost its gradient"
+            off += n
