@@ -259,6 +259,7 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(const WgradLdsParams p) 
 constexpr int kWgradBatchMax = 22;
 struct WgradBatch {
   int njobs;
+  int zfast;     // block order inside a job: 1 = the gz blocks of one (bx, by) next to each other and on ONE XCD (below), 0 = z slowest
   int first[kWgradBatchMax + 1];
   int gx[kWgradBatchMax], gy[kWgradBatchMax];
   WgradLdsParams job[kWgradBatchMax];
@@ -272,8 +273,29 @@ __global__ __launch_bounds__(256) void wgrad_lds_batch_kernel(const WgradBatch t
   while (j + 1 < tb.njobs && b >= tb.first[j + 1]) ++j;           // (wave-uniform: scalar unit)
   const int local = b - tb.first[j];
   const int gx = tb.gx[j], gy = tb.gy[j];
-  const int gz = (tb.first[j + 1] - tb.first[j]) / (gx * gy);
-  wgrad_lds_body<KH, KW, MODE3D, R, TH>(tb.job[j], VBlock{local % gx, (local / gx) % gy, local / (gx * gy), gx, gy, gz});
+  const int G = gx * gy;
+  const int gz = (tb.first[j + 1] - tb.first[j]) / G;
+  if (!tb.zfast) {
+    wgrad_lds_body<KH, KW, MODE3D, R, TH>(tb.job[j], VBlock{local % gx, (local / gx) % gy, local / G, gx, gy, gz});
+    return;
+  }
+  // The gz blocks of one (bx, by) -- the kd (3-D) / kh (2-D) slices of the same tiles -- stage the SAME `small` segments and
+  // overlapping `big` patches.  With z slowest they ran a third of the launch apart and every re-read came from the fabric (PMC:
+  // 6.3 GB per cfg3 step for 2.3 algorithmic); here they are issued 8 block ids apart -- workgroups go round-robin over the 8 XCDs,
+  // so on the SAME XCD and at the same time: the second and third read hit that XCD's L2.  Groups of 8 (bx, by) x gz; the tail
+  // (G % 8 blocks) keeps z fastest without the XCD alignment.  A pure renumbering: every block computes what it computed before.
+  const int full = G & ~7;
+  int bxy, bz;
+  if (local < full * gz) {
+    const int t = local / (8 * gz), w = local - t * 8 * gz;
+    bz = w >> 3;
+    bxy = t * 8 + (w & 7);
+  } else {
+    const int v = local - full * gz, m = G - full;
+    bz = v / m;
+    bxy = full + v - bz * m;
+  }
+  wgrad_lds_body<KH, KW, MODE3D, R, TH>(tb.job[j], VBlock{bxy % gx, bxy / gx, bz, gx, gy, gz});
 }
 
 // voxel stride (floats) such that q and q+1 (voxels `step` apart) land 16 banks apart: stride*step = 16 (mod 32)
@@ -334,6 +356,7 @@ extern "C" int mdf_wgrad_batch_flush(void* stream) {
   for (size_t i = 0; i < jobs.size(); ++i) {
     if (done[i]) continue;
     WgradBatch tb{};
+    tb.zfast = [] { const char* e = getenv("MDF_WGRAD_ZFAST"); return e ? atoi(e) : 1; }();   // dev A/B (read per flush)
     int blocks = 0;
     size_t lds = 0;
     for (size_t k = i; k < jobs.size() && tb.njobs < kWgradBatchMax; ++k) {

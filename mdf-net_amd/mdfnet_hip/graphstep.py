@@ -24,10 +24,11 @@ What has to hold for a recording to stay valid, and how each point is met:
 Stage-parallel backward (default; MDF_TRAIN_GRAPH_SPLIT=0 records the step as ONE graph): the backward chains of the three stages
 (regulariser + aggregation, ~60 % of the step's launches, many of them small-volume layers that fill a fraction of the chip) share
 nothing until they meet at the feature pyramid.  A hipGraph with parallel branches does not help -- the runtime replays it node
-by node from the host (6.5 ms of host time per cfg3 step, slower than the chain) -- so the step is recorded as SIX chain-shaped
-graphs: F (forward, loss, the loss's own backward), S0 / S1 / S2 (one stage's backward chain each, recorded on the stage's own
-stream into its own memory pool), R (the refinement net's backward: parameters only), C (feature pyramid + trunk backward,
-weight-gradient sums, bucket gather, Adam).  A replay is F, then the three S graphs on three streams with R beside them, then C.  The cuts are made by CoreNet's forward
+by node from the host (6.5 ms of host time per cfg3 step, slower than the chain) -- so the step is recorded as EIGHT chain-shaped
+graphs: F (forward, loss, the loss's own backward) | S0 / S1 / S2 (one stage's input-gradient chain each, recorded on the stage's own
+stream into its own memory pool) and R (the refinement net's backward: parameters only) side by side | C (feature pyramid + trunk
+backward: a chain of small launches) and W (the three stages' weight gradients, kept back from the stage chains by
+train_ops.hold_wgrad_flush: a few chip-filling launches) side by side | D (bucket gather, Adam).  The cuts are made by CoreNet's forward
 (layers.StageCuts); the gradients are those of the one-piece backward pass (no sum crosses a cut).
 
 Data parallelism: with more than one rank the gradient all-reduce stays OUTSIDE the graphs -- recording A ends with the bucket
@@ -125,17 +126,23 @@ class GraphedTrainStep:
     def _piece_stage(cuts, s):
         depth, cut = cuts.depth[s]
         if cut.grad is not None:
-            torch.autograd.backward([depth], [cut.grad])    # regulariser + aggregation of stage s -> d features, parameters
+            from . import train_ops
+            with train_ops.hold_wgrad_flush():              # the stage's weight gradients are launched by piece W, beside piece C
+                torch.autograd.backward([depth], [cut.grad])    # regulariser + aggregation of stage s -> d features, parameters
+
+    def _piece_w(self):
+        from . import train_ops
+        train_ops.flush_held(self.device)                   # the three stages' weight gradients: a few chip-filling launches
 
     @staticmethod
     def _piece_r(cuts):
         if cuts.refine is not None and cuts.refine[1].grad is not None:
             torch.autograd.backward([cuts.refine[0]], [cuts.refine[1].grad])      # the refinement net's parameter gradients
 
-    def _piece_c(self, cuts):
+    @staticmethod
+    def _piece_c(cuts):
         roots = [(y, yc.grad) for pairs in cuts.feat for (y, yc) in pairs if yc.grad is not None]
-        torch.autograd.backward([r[0] for r in roots], [r[1] for r in roots])      # feature pyramid + trunk
-        self.bucket.gather()
+        torch.autograd.backward([r[0] for r in roots], [r[1] for r in roots])      # feature pyramid + trunk (a chain of small launches)
 
     def _eager_step(self):
         if self.split:
@@ -151,6 +158,8 @@ class GraphedTrainStep:
             for st in cuts.streams:
                 cur.wait_stream(st)
             self._piece_c(cuts)
+            self._piece_w()
+            self.bucket.gather()
         else:
             loss = self._forward_backward()
         self.bucket.allreduce_gradients()
@@ -166,7 +175,7 @@ class GraphedTrainStep:
         self._pool = train_ops.step_pool(dev)               # its buffer's address is in the recording: not replaced while this
         self._pool.held_by_recording += 1                   # object lives (ZeroPool.take raises instead)
         self.graph_a = torch.cuda.CUDAGraph()
-        self.graph_s, self.graph_c, self.graph_r, self.side = [], None, None, None
+        self.graph_s, self.graph_c, self.graph_r, self.graph_w, self.graph_d, self.side = [], None, None, None, None, None
         if self.split:
             with torch.cuda.graph(self.graph_a, stream=self.stream):
                 self.loss, cuts = self._piece_f()
@@ -180,9 +189,20 @@ class GraphedTrainStep:
                 self.graph_r = torch.cuda.CUDAGraph()       # on the caller's stream, while the stage chains run on theirs
                 with torch.cuda.graph(self.graph_r, stream=self.stream):
                     self._piece_r(cuts)
-            self.graph_c = torch.cuda.CUDAGraph()           # replayed after everything else: may reuse what F's pool has freed
+            # C (pyramid + trunk backward: a chain of small launches) and W (the stages' weight gradients: a few chip-filling
+            # launches) replay side by side.  C is recorded FIRST, while W's operands are still referenced by the queued launches:
+            # nothing C allocates from F's pool can alias an activation W reads.  D (bucket gather, Adam) closes the step.
+            self.graph_c = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_c, stream=self.stream, pool=self.graph_a.pool()):
                 self._piece_c(cuts)
+            from . import train_ops
+            if train_ops.has_held(self.device):
+                self.graph_w = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_w, stream=self.side[0]):
+                    self._piece_w()
+            self.graph_d = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_d, stream=self.stream, pool=self.graph_a.pool()):
+                self.bucket.gather()
                 if self.world <= 1:
                     self.opt.step(hyper=self.hyper)
             del cuts
@@ -230,7 +250,15 @@ class GraphedTrainStep:
                 self.graph_r.replay()
             for st in self.side:
                 cur.wait_stream(st)
+            w_st = self.side[0]
+            if self.graph_w is not None:
+                w_st.wait_stream(cur)                       # W starts when EVERY stage chain is done (it reads all their operands)
+                with torch.cuda.stream(w_st):
+                    self.graph_w.replay()
+            # (C on a high-priority stream beside W: the replay takes 13.8 ms instead of 6.9 -- measured, dropped)
             self.graph_c.replay()
+            cur.wait_stream(w_st)
+            self.graph_d.replay()
         if self.world > 1:
             self.bucket.allreduce_gradients()
             self.graph_b.replay()

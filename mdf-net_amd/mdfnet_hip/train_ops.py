@@ -151,14 +151,44 @@ def sum_wgrad_jobs(jobs):
          work={"bytes": 4.0 * sum(j[2] * j[3] for j in jobs), "bound": "hbm"})
 
 
-def _flush_wgrad_sums(dev_index):
-    ent = _PENDING_SUMS.pop(dev_index, None)
+_HOLD_FLUSH = [False]
+
+
+class hold_wgrad_flush:
+    """Inside: the deferred weight gradients of the backward passes that run are NOT launched when a pass ends; they stay queued
+    (operands alive) until `flush_held`.  The recorded training step uses it to take the three stages' weight gradients out of the
+    stage chains and launch them beside the pyramid / trunk backward chain (graphstep.py)."""
+
+    def __enter__(self):
+        self.prev, _HOLD_FLUSH[0] = _HOLD_FLUSH[0], True
+
+    def __exit__(self, *exc):
+        _HOLD_FLUSH[0] = self.prev
+
+
+def flush_held(device):
+    """Launch what `hold_wgrad_flush` kept back, on the current stream.  The caller has ordered that stream behind the backward
+    passes whose gradients are queued (no stream joins are issued here: inside a recording the chains' streams are not capturing)."""
+    _flush_wgrad_sums(device.index if device.index is not None else torch.cuda.current_device(), force=True, join=False, held=True)
+
+
+def has_held(device):
+    ent = _PENDING_SUMS.get(("held", device.index if device.index is not None else torch.cuda.current_device()))
+    return bool(ent and (ent[1] or ent[2]))
+
+
+def _flush_wgrad_sums(dev_index, force=False, join=True, held=False):
+    """held: the queue `hold_wgrad_flush` filled (its own key: a backward pass that runs OUTSIDE the hold while that queue waits --
+    the pyramid / trunk piece of the recorded step -- queues and flushes its weight gradients as usual)."""
+    if _HOLD_FLUSH[0] and not force:
+        return
+    ent = _PENDING_SUMS.pop(("held", dev_index) if held else dev_index, None)
     if not ent or not (ent[1] or ent[2]):
         return
     streams, jobs, deferred = ent
     cur = torch.cuda.current_stream(torch.device("cuda", dev_index))
     for st in streams:          # partial tiles may have been launched on other streams: join them
-        if st != cur:
+        if st != cur and join:
             cur.wait_stream(st)
     if deferred:
         # the weight gradients whose LAUNCH was deferred too (BATCH_WGRAD): recorded by the library, then launched grouped by
@@ -186,6 +216,7 @@ def drop_stale_wgrad_sums(dev_index=None):
         _PENDING_SUMS.clear()
     else:
         _PENDING_SUMS.pop(dev_index, None)
+        _PENDING_SUMS.pop(("held", dev_index), None)
 
 
 def _can_defer(param):
@@ -196,8 +227,9 @@ def _can_defer(param):
 
 
 # (r04, measured and dropped: the deferred weight gradients on a SIDE stream that forks from the backward chain per layer and joins
-#  before the one sum launch -- eager step 8.5 -> 9.4-9.6 ms, recorded step 8.44 -> 8.70 ms with 6.4 ms of host time per replay: the
-#  weight-gradient kernels fill the chip, so running them beside the input-gradient chain only slows that chain.  HISTORY.md.)
+#  before the one sum launch -- eager step 8.5 -> 9.4-9.6 ms, recorded step 8.44 -> 8.70 ms with 6.4 ms of host time per replay.  r05
+#  found the cause: a hipGraph with parallel branches is replayed node by node from the host.  The recorded step now keeps every
+#  graph a chain and launches the stages' weight gradients as a graph of their own beside the trunk's backward chain: graphstep.py.)
 
 
 def _sum_later(work, dw, nslab, n, param):
@@ -212,14 +244,15 @@ def _sum_later(work, dw, nslab, n, param):
         ent[0].append(cur)
     ent[1].append((work, dw.data_ptr(), nslab, n))
     if not defer:
-        _flush_wgrad_sums(dev)
+        _flush_wgrad_sums(dev, force=True)
 
 
 def _pending_entry(dev, defer):
-    ent = _PENDING_SUMS.get(dev)
+    key = ("held", dev) if (_HOLD_FLUSH[0] and defer) else dev
+    ent = _PENDING_SUMS.get(key)
     if ent is None:
-        ent = _PENDING_SUMS[dev] = [[], [], []]       # streams, sum jobs, deferred launches
-        if defer:
+        ent = _PENDING_SUMS[key] = [[], [], []]       # streams, sum jobs, deferred launches
+        if defer and key == dev:
             torch.autograd.Variable._execution_engine.queue_callback(lambda d=dev: _flush_wgrad_sums(d))
     return ent
 

@@ -57,7 +57,22 @@ if os.environ.get("MDF_TRAIN_GRAPH") == "1":       # the same step recorded once
                 torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
             return sorted(ts)[len(ts) // 2] * 1e3
         gstep._upload(*[__import__("mdfnet_hip").hostmirror.get(t) for t in (extr, intr, dr)])
-        parts = [("F", timed(gstep.graph_a))] + [(f"S{i}", timed(g, st)) for i, (g, st) in enumerate(zip(gstep.graph_s, gstep.side))] + ([("R", timed(gstep.graph_r))] if gstep.graph_r is not None else []) + [("C", timed(gstep.graph_c))]
+        parts = [("F", timed(gstep.graph_a))] + [(f"S{i}", timed(g, st)) for i, (g, st) in enumerate(zip(gstep.graph_s, gstep.side))] + ([("R", timed(gstep.graph_r))] if gstep.graph_r is not None else []) + [("C", timed(gstep.graph_c))] + ([("W", timed(gstep.graph_w, gstep.side[0]))] if gstep.graph_w is not None else []) + [("D", timed(gstep.graph_d))]
+        def timed_group(pairs):          # [(graph, stream or None)] replayed side by side
+            ts = []
+            cur = torch.cuda.current_stream(dev)
+            for _ in range(10):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for g, st in pairs:
+                    if st is None: g.replay()
+                    else:
+                        st.wait_stream(cur)
+                        with torch.cuda.stream(st): g.replay()
+                torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+            return sorted(ts)[len(ts) // 2] * 1e3
+        sreg = timed_group([(g, st) for g, st in zip(gstep.graph_s, gstep.side)] + ([(gstep.graph_r, None)] if gstep.graph_r is not None else []))
+        cw = timed_group(([(gstep.graph_w, gstep.side[0])] if gstep.graph_w is not None else []) + [(gstep.graph_c, None)])
+        print(f"side by side (ms): S0 | S1 | S2 | R {sreg:.2f}; C | W {cw:.2f}", flush=True)
         print("pieces alone (ms): " + ", ".join(f"{k} {v:.2f}" for k, v in parts) + f"; sum {sum(v for _, v in parts):.2f}", flush=True)
 mode = "stock PyTorch-ROCm autograd" if os.environ.get("MDF_TRAIN_STOCK") == "1" else "HIP training kernels"
 print(f"train step {W}x{H}x{V} B=1 [{mode}]: {dt*1e3:.1f} ms  ({1/dt:.2f} samples/s), loss {float(l):.3f}, peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
