@@ -420,7 +420,7 @@ def primary_training_figure(rec):
     rec["eager"]["note"] = "the same step issued launch by launch from Python (host-bound on boxes with a slow host share)"
     if "ms_per_step" in g:
         rec["ms_per_step"], rec["samples_per_s"], rec["ms_per_step_blocks"] = g["ms_per_step"], g["samples_per_s"], g["ms_per_step_blocks"]
-        rec["mode"] = "replayed from its hipGraph recording (mdfnet_hip/graphstep.py: six chain-shaped graphs, the stages' backward chains side by side; train.py: MDF_TRAIN_HIPGRAPH=1); launch-by-launch figures under `eager`"
+        rec["mode"] = "replayed from its hipGraph recording (mdfnet_hip/graphstep.py: eight chain-shaped graphs, the stages' backward chains side by side; train.py: MDF_TRAIN_HIPGRAPH=1); launch-by-launch figures under `eager`"
         rec["whole_step_frac_of_fp32_mfma_peak"] = round(rec["mfma_algorithmic_gflop_per_step"] / g["ms_per_step"] / PEAK_FP32_MFMA_TFLOPS, 4)
     else:
         rec["mode"] = "launch by launch (the recorded-step variant did not run: see graph_replay)"
@@ -473,7 +473,7 @@ def training_graph_child(steps, blocks):
                       "host_ms_per_step": round(1e3 * statistics.median(hosts), 3), "recording_s": round(t_rec, 2),
                       "loss_first": round(first, 3), "loss_last": round(float(last), 3),
                       "note": "forward + loss + backward + bucket + Adam recorded once (torch.cuda.graph over the hand-written launches) and "
-                              "replayed per step -- as six chain-shaped graphs, the three stages' backward chains side by side on three streams "
+                              "replayed per step -- as eight chain-shaped graphs, the three stages' backward chains side by side on three streams, their weight gradients beside the trunk's chain "
                               "(mdfnet_hip/graphstep.py); per step the host uploads the packed control plane + Adam's scalars and issues the "
                               "replays (host_ms_per_step), the GPU executes the same launches as the eager step"}), flush=True)
 
