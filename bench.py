@@ -168,6 +168,8 @@ def family_table(recs, steps, family_of):
             continue
         f = agg.setdefault(fam, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0,
                                  "bound": work.get("bound", "hbm"), "top": {}})
+        if work.get("bound") == "mfma":           # (a family that mixes MFMA launches with their small sum / control launches is MFMA-bound)
+            f["bound"] = "mfma"
         f["ms"] += ms
         f["flops"] += work.get("flops", 0.0)
         f["bytes"] += work.get("bytes", 0.0)

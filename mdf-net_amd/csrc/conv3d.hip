@@ -746,10 +746,23 @@ int launch_conv_mt(ConvParams& p, hipStream_t st) {
   // (8 -> 16 stride 2 at 24x296x400: 51.5 us with 4 m-tiles per wave, 47.8 with 2, 56.1 with 1; the other stride-2 / transposed layers
   //  are best at their MTMAX or indifferent)
   if (MODE == kS2 && CIN == 8 && ST == 0 && tiles_big >= 1024) return launch_conv<CIN, COUT, MODE, 2, 1, ST>(p, st);
-  if (tiles_big >= 1024) return launch_conv<CIN, COUT, MODE, MTMAX, 1, ST>(p, st);
+  {   // dev A/B: two m-tiles per wave for the mid-size one-tile layers (half the weight bytes through L1 per voxel)
+    const long long mt2_min = [] { const char* e = getenv("MDF_CONV3D_MT2_MIN_TILES"); return e ? atoll(e) : -1LL; }();
+    if (ST == 0 && MODE != kTr && mt2_min >= 0 && tiles_big < 1024 && tiles_big >= mt2_min && !(CIN >= 32 && p.m_total / 16 < 4096))
+      return launch_conv<CIN, COUT, MODE, 2, 1, ST>(p, st);
+  }
+  const long long mt_min = [] { const char* e = getenv("MDF_CONV3D_MT_MIN_TILES"); return e ? atoll(e) : 1024LL; }();   // dev A/B (read per call)
+  if (tiles_big >= mt_min) return launch_conv<CIN, COUT, MODE, MTMAX, 1, ST>(p, st);
   // few tiles and a deep K (27*CIN >= 864): split the taps over the block's waves
   const long long tiles_1 = p.m_total / 16 * (MODE == kTr ? 4 : 1);
-  if (MODE != kTr && CIN >= 32 && tiles_1 < 4096) return launch_conv<CIN, COUT, MODE, 1, 4, ST>(p, st);  // (transposed classes have only 2-8 taps)
+  if (MODE != kTr && CIN >= 32 && tiles_1 < 4096) {   // (transposed classes have only 2-8 taps)
+    // m-tiles per split-K block: with ONE 16-voxel tile a block streams the layer's whole weight set (442 KB at 64 -> 64) through its
+    // L1 for 16 voxels -- 1388 blocks x 442 KB = 0.6 GB from the L2s per launch at 12x37x50; two tiles halve that
+    const int sk_mt = [] { const char* e = getenv("MDF_CONV3D_SK_MT"); return e ? atoi(e) : 1; }();   // dev A/B (read per call)
+    if (ST == 0 && sk_mt == 2 && tiles_1 >= 512) return launch_conv<CIN, COUT, MODE, 2, 4, ST>(p, st);
+    if (ST == 0 && sk_mt == 4 && tiles_1 >= 1024) return launch_conv<CIN, COUT, MODE, (COUT > 32 ? 2 : 4), 4, ST>(p, st);
+    return launch_conv<CIN, COUT, MODE, 1, 4, ST>(p, st);
+  }
   return launch_conv<CIN, COUT, MODE, 1, 1, ST>(p, st);
 }
 

@@ -18,6 +18,10 @@ L = [("s0.conv01.0", 32, 16, "s1", 48, 148, 200), ("s0.conv01.1", 16, 16, "s1", 
      ("s2.trconv21T", 16, 8, "tr", 4, 296, 400)]
 if "--tr" in sys.argv:
     L = [l for l in L if l[3] == "tr"]
+if "--small" in sys.argv:     # the small-volume levels of the three U-Nets (split-K / one-tile kernels)
+    L = [("s0.conv232.1", 64, 64, "s1", 12, 37, 50), ("s0.conv232.0", 32, 64, "s2", 24, 74, 100), ("s1.conv23.1", 32, 32, "s1", 6, 74, 100),
+         ("s1.conv34.0", 32, 64, "s2", 6, 74, 100), ("s1.conv34.1", 64, 64, "s1", 3, 37, 50), ("s2.conv23.1", 32, 32, "s1", 2, 148, 200),
+         ("s2.conv34.0", 32, 64, "s2", 2, 148, 200), ("s2.conv34.1", 64, 64, "s1", 1, 74, 100)]
 if "--s2" in sys.argv:
     L = [l for l in L if l[3] == "s2"]
 dev = "cuda:0"
