@@ -747,7 +747,8 @@ int launch_conv_mt(ConvParams& p, hipStream_t st) {
   //  are best at their MTMAX or indifferent)
   if (MODE == kS2 && CIN == 8 && ST == 0 && tiles_big >= 1024) return launch_conv<CIN, COUT, MODE, 2, 1, ST>(p, st);
   {   // dev A/B: two m-tiles per wave for the mid-size one-tile layers (half the weight bytes through L1 per voxel)
-    const long long mt2_min = [] { const char* e = getenv("MDF_CONV3D_MT2_MIN_TILES"); return e ? atoll(e) : -1LL; }();
+    // (r05: 16 -> 32 stride 2 at 48x148x200 -- 693 four-tile blocks' worth -- 68.6 -> 62.6 us; below ~500 the grid is too small)
+    const long long mt2_min = [] { const char* e = getenv("MDF_CONV3D_MT2_MIN_TILES"); return e ? atoll(e) : 512LL; }();
     if (ST == 0 && MODE != kTr && mt2_min >= 0 && tiles_big < 1024 && tiles_big >= mt2_min && !(CIN >= 32 && p.m_total / 16 < 4096))
       return launch_conv<CIN, COUT, MODE, 2, 1, ST>(p, st);
   }
@@ -758,9 +759,10 @@ int launch_conv_mt(ConvParams& p, hipStream_t st) {
   if (MODE != kTr && CIN >= 32 && tiles_1 < 4096) {   // (transposed classes have only 2-8 taps)
     // m-tiles per split-K block: with ONE 16-voxel tile a block streams the layer's whole weight set (442 KB at 64 -> 64) through its
     // L1 for 16 voxels -- 1388 blocks x 442 KB = 0.6 GB from the L2s per launch at 12x37x50; two tiles halve that
-    const int sk_mt = [] { const char* e = getenv("MDF_CONV3D_SK_MT"); return e ? atoi(e) : 1; }();   // dev A/B (read per call)
-    if (ST == 0 && sk_mt == 2 && tiles_1 >= 512) return launch_conv<CIN, COUT, MODE, 2, 4, ST>(p, st);
-    if (ST == 0 && sk_mt == 4 && tiles_1 >= 1024) return launch_conv<CIN, COUT, MODE, (COUT > 32 ? 2 : 4), 4, ST>(p, st);
+    // (r05, 64 output channels at ~1400 tiles: 64 -> 64 @12x37x50 62 -> 57 us, 32 -> 64 s2 @24x74x100 35 -> 31; the 32 -> 32 layers and
+    //  the volumes under ~500 tiles are indifferent or lose: they keep one tile)
+    const int sk_mt = [] { const char* e = getenv("MDF_CONV3D_SK_MT"); return e ? atoi(e) : 0; }();   // dev A/B (read per call): 0 = the rule
+    if (ST == 0 && (sk_mt == 2 || (sk_mt == 0 && COUT >= 64)) && tiles_1 >= 1024) return launch_conv<CIN, COUT, MODE, 2, 4, ST>(p, st);
     return launch_conv<CIN, COUT, MODE, 1, 4, ST>(p, st);
   }
   return launch_conv<CIN, COUT, MODE, 1, 1, ST>(p, st);
