@@ -421,7 +421,8 @@ int mdf_wgrad_lds_dispatch(const float* small_, const float* big, float* workspa
       const int WB = tv * stride + KW - 1;
       if ((tv + hal) * (A / 4) > ns * 256 || WB * (Bc / 4) > npr * 256) break;    // register staging capacity
       const size_t lds = (size_t)(th * (tv + hal) * p.AS + (nbr * WB + 1) * p.BS) * sizeof(float);
-      if (lds > (th == 1 ? 72 : 80) * 1024) break;   // two blocks per CU
+      static const int lds_kb = [] { const char* e = getenv("MDF_WGRAD_LDS_KB"); return (e && atoi(e) > 0) ? atoi(e) : 0; }();   // dev A/B
+      if (lds > (size_t)(lds_kb ? lds_kb : (th == 1 ? 72 : 80)) * 1024) break;   // two blocks per CU
       const int rounds = (th * (tv / 16) + p.split - 1) / p.split;                 // chunks of the busiest wave
       const long long tiles = (long long)((Hs + th - 1) / th) * ((Ws + hal + tv - 1) / tv);
       const long long cost = tiles * (rounds * p.split * 16 + 24);                 // + ~24 voxel-times of fixed cost per tile
