@@ -17,7 +17,8 @@ COMBOS = [(32, 16, "s1"), (16, 16, "s1"), (32, 32, "s1"), (64, 64, "s1"), (16, 8
 
 
 @pytest.mark.parametrize("cin,cout,mode", COMBOS)
-@pytest.mark.parametrize("shape", [(1, 4, 6, 8), (2, 5, 7, 9), (1, 8, 20, 36)])
+@pytest.mark.parametrize("shape", [(1, 4, 6, 8), (2, 5, 7, 9), (1, 8, 20, 36),
+                                   (1, 1, 9, 37), (2, 2, 7, 33), (2, 3, 5, 21)])     # 1-3 planes: depth taps no voxel of a wave has are skipped (r05)
 def test_conv3d_layer(cin, cout, mode, shape):
     b, d, h, w = shape
     rng = np.random.RandomState(cin * 131 + cout + d)
