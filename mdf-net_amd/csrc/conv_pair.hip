@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, MDF_PAIRV_BLOCKS) void conv_pair_valu_kernel(c
   // iteration i: input row m0 + i + 1 arrives, intermediate row m0 + i is formed, output row r0 + i - 2 leaves (i >= 2)
   auto step = [&](auto pc, int i) {
     constexpr int P = decltype(pc)::value;                       // i % 3
-    constexpr int S0 = P % 3, S1 = (P + 1) % 3, S2 = (P + 2) % 3;   // input rows m-1, m, m+1 / intermediate rows m-2, m-1, m live in slots S0.. (see below)
+    [[maybe_unused]] constexpr int S0 = P % 3, S1 = (P + 1) % 3, S2 = (P + 2) % 3;   // input rows m-1, m, m+1 / intermediate rows m-2, m-1, m live in slots S0.. (see below)
     const int m = m0 + i;
     // ---- layer 1, row m: rows m-1, m, m+1 are in slots S0, S1, S2
     f32x2v acc1[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void wgrad_a1_valu_kernel(const WgradParams p)
   zero_slice(p.zero_out, p.zero_n);
   constexpr int NQ = BC / 4;               // channel quads per voxel = lanes per voxel
   constexpr int VPB = 256 / NQ;            // voxels per block and iteration
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const int cq = tid % NQ;
   const int nvox = p.B * p.Ds * p.Hs * p.Ws;            // (the entry point has checked that the operands fit 32-bit offsets)
   float acc[27][4];
