@@ -286,6 +286,16 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
   {
     const int js = (SPLITK > 1) ? SPLITK : 1;
     int j = (SPLITK > 1) ? wave : 0;
+    if constexpr (MODE == kTr) {
+      // shallow volumes: a class with output parity pd = 1 has the depth taps kd = 0 (input plane d + 1) and kd = 2 (plane d); on the last
+      // plane -- the only one at Di = 1 -- the kd = 0 half multiplies zeros.  kd is the slowest tap index: skipping it is a later start.
+      if (p.kd_skip && pd && !__any((int)(vmask[0] & 1u))) {
+        bool none = true;
+#pragma unroll
+        for (int t = 1; t < MT; ++t) none = none && !__any((int)(vmask[t] & 1u));
+        if (none) j = __builtin_amdgcn_readfirstlane(nkh * 2);
+      }
+    }
     if constexpr (kPipeTaps) {
       TapRegs ra, rb;
       if (j < ntaps) load_tap(j, ra);
@@ -932,7 +942,7 @@ static int conv3d_entry(const float* x, const float* wpack, const float* alpha, 
   p.B = B; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.relu = relu;
   if (stat) { p.stat_mode = stat->mode; p.stat_y = stat->y; p.stat_aux = stat->aux; p.stat_out = stat->out; p.stat_slices = stat->nslices; }
   const int m = transposed ? kTr : (stride == 2 ? kS2 : kS1);
-  p.kd_skip = [] { const char* e = getenv("MDF_CONV3D_KDSKIP"); return e ? atoi(e) : 1; }() && !transposed && Di <= 3;   // dev A/B (read per call)
+  p.kd_skip = [] { const char* e = getenv("MDF_CONV3D_KDSKIP"); return e ? atoi(e) : 1; }() && Di <= 3;   // dev A/B (read per call)
   if (m == kS1) { p.Do = Di; p.Ho = Hi; p.Wo = Wi; }
   else if (m == kS2) { p.Do = (Di - 1) / 2 + 1; p.Ho = (Hi - 1) / 2 + 1; p.Wo = (Wi - 1) / 2 + 1; }
   else { p.Do = 2 * Di; p.Ho = 2 * Hi; p.Wo = 2 * Wi; }
