@@ -115,9 +115,11 @@ __device__ __forceinline__ void wgrad_lds_body(const WgradLdsParams& p, const VB
     int n, od, oh, ow0;
     decode(tile, n, od, oh, ow0);             // wave-uniform (scalar unit)
     const int s_lo = max(0, hal - ow0) * c4a, s_hi = min(p.tv + hal, p.Ws - ow0 + hal) * c4a;     // staged slot 0 = voxel ow0 - hal
+    const int id_s = MODE3D ? od * s + z - p.pad : 0;
+    const bool plane_ok = !MODE3D || (id_s >= 0 && id_s < p.Db);     // (3-D: this kd's plane of `big` exists; else the tile adds nothing and is not multiplied, below)
 #pragma unroll
     for (int r = 0; r < TH; ++r) {
-      const bool srow_ok = (oh + r) < p.Hs;                                                      // wave-uniform
+      const bool srow_ok = plane_ok && (oh + r) < p.Hs;                                          // wave-uniform
       const float4* srow = reinterpret_cast<const float4*>(p.small_) + ((((long long)n * p.Ds + od) * p.Hs + (oh + r)) * p.Ws + (ow0 - hal)) * c4a;
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
@@ -162,6 +164,15 @@ __device__ __forceinline__ void wgrad_lds_body(const WgradLdsParams& p, const VB
   const float* la = sm_small + (q + hal - sa) * p.AS + ac;
   const float* lb = sm_big + (q * s + sb) * p.BS + bc;
 
+  // 3-D, shallow volumes (the innermost levels are 1-2 planes deep): the tiles whose kd plane lies outside the volume -- two of three
+  // at Ds = 1 -- staged zeros and multiplied them; they are passed over (the barriers stay: the pipeline's shape does not change)
+  auto tile_live = [&](long long t) {
+    if constexpr (!MODE3D) return true;
+    int n, od, oh, ow0;
+    decode(t, n, od, oh, ow0);
+    const int id = od * s + z - p.pad;
+    return id >= 0 && id < p.Db;
+  };
   long long tile = vb.bx;
   if (tile < p.n_tiles) stage(tile);
   while (tile < p.n_tiles) {
@@ -169,7 +180,8 @@ __device__ __forceinline__ void wgrad_lds_body(const WgradLdsParams& p, const VB
     __syncthreads();
     const long long next = tile + vb.gx;
     if (next < p.n_tiles) stage(next);         // in flight during the MFMAs below
-    for (int cq = 0; cq < nchunk; ++cq) {
+    const int nchunk_t = tile_live(tile) ? nchunk : 0;
+    for (int cq = 0; cq < nchunk_t; ++cq) {
       const int c = part + cq * p.split;
       const int r = (TH == 1) ? 0 : c / cpr;        // row of the tile
       const int v0 = (c - r * cpr) * 16;            // first voxel of the chunk inside the row
