@@ -413,10 +413,15 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
 // classes per w offset = the same 18 MFMA groups): 8 input fetches instead of 18, four times the MFMAs behind every fetch, and
 // the 2 x 2 (d, h) output neighbourhood of a tile written by one block.  Positions run (od, oh) = (1,1), (1,0), (0,1), (0,0), so
 // every class accumulates its taps in the order of conv3d_kernel<kTr>: bit-identical results.
-template <int CIN, int COUT, int MT>
+// NS > 1 (small volumes: fewer m-tiles than the chip has SIMDs): the n-tiles of an m-tile are dealt out to NS waves (blockIdx.y = first
+// n-tile, stride NS), each fetching the input fragments itself -- NS times the waves at 1/NS of the MFMAs and weight bytes each.  With
+// NS = 2 and four n-tiles a wave holds one tile of each output w-parity, so the two halves carry the same work.
+template <int CIN, int COUT, int MT, int NS>
 __global__ __launch_bounds__(256) void convtr_all_kernel(const ConvParams p) {
   constexpr int KPL = (CIN >= 16) ? 4 : 2, CK = 4 * KPL, NCH = CIN / CK;
-  constexpr int ROWS = 2 * COUT, NT = (ROWS + 15) / 16;
+  constexpr int ROWS = 2 * COUT, NTA = (ROWS + 15) / 16, NT = NTA / NS;     // NTA n-tiles in all, NT of them in this wave
+  static_assert(NTA % NS == 0, "the n-tiles must divide over the NS waves");
+  const int nt0 = (NS > 1) ? (int)blockIdx.y : 0;                          // this wave's n-tiles: nt0 + i * NS
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, n16 = lane & 15;
   const unsigned tile_blk = mdf::xcd_remap(blockIdx.x, p.nblk);
@@ -447,7 +452,7 @@ __global__ __launch_bounds__(256) void convtr_all_kernel(const ConvParams p) {
   float4 ep_al[NT], ep_be[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int r0 = nt * 16 + 4 * q, c0 = r0 % COUT;
+    const int r0 = (nt0 + nt * NS) * 16 + 4 * q, c0 = r0 % COUT;
     ep_al[nt] = make_float4(1.f, 1.f, 1.f, 1.f);
     ep_be[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r0 < ROWS && p.alpha) {
@@ -457,11 +462,20 @@ __global__ __launch_bounds__(256) void convtr_all_kernel(const ConvParams p) {
   }
   const float* xq = p.x + KPL * q;
   const float* wl = p.wpack + (size_t)lane * KPL;
+  bool no_next_plane = false;
+  if (p.kd_skip) {
+    unsigned m_or = 0u;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) m_or |= vmask[t];
+    no_next_plane = !__any((int)(m_or & 1u));
+  }
 #pragma unroll
   for (int pos = 0; pos < 8; ++pos) {
     const int od = 1 - (pos >> 2), oh = 1 - ((pos >> 1) & 1), ow = pos & 1;
     const unsigned need = 8u | (od ? 1u : 0u) | (oh ? 2u : 0u) | (ow ? 4u : 0u);
     const int tapoff = ((od * p.Hi + oh) * p.Wi + ow) * CIN;
+    if (NS == NTA && NTA > 1 && ow == 1 && (nt0 + 1) * 16 <= COUT) continue;   // one n-tile per wave, of parity pw = 0: nothing to do at offset +1
+    if (od == 1 && no_next_plane) continue;             // shallow volumes: no voxel of the wave has plane d + 1 (see conv3d_kernel: kd_skip)
     Frag<KPL> bf[NCH][MT];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch)
@@ -476,19 +490,21 @@ __global__ __launch_bounds__(256) void convtr_all_kernel(const ConvParams p) {
       const int pd = cls >> 1, ph = cls & 1;
       if (od > pd || oh > ph) continue;                   // parity 0 has its one tap at offset 0
       const int kd = pd ? (od ? 0 : 2) : 1, kh = ph ? (oh ? 0 : 2) : 1;
-      const float* wt = wl + (size_t)((kd * 3 + kh) * 2 + ow) * (NCH * NT * 64 * KPL);
+      const float* wt = wl + (size_t)((kd * 3 + kh) * 2 + ow) * (NCH * NTA * 64 * KPL);
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) {
         Frag<KPL> af[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) af[nt].load(wt + (size_t)(ch * NT + nt) * (64 * KPL));
+        for (int nt = 0; nt < NT; ++nt) af[nt].load(wt + (size_t)(ch * NTA + nt0 + nt * NS) * (64 * KPL));
 #pragma unroll
         for (int s = 0; s < KPL; ++s)
 #pragma unroll
           for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-              if (ow == 1 && (nt + 1) * 16 <= COUT) continue;   // offset +1 feeds parity pw = 1 only: those n-tiles are structurally zero
+              // offset +1 feeds parity pw = 1 only: the n-tiles of pw = 0 are structurally zero (NS = 2 of 4 tiles: the wave's first; else wave-uniform)
+              const bool pw0_tile = (NS == 2 && NTA == 4) ? (nt == 0) : ((nt0 + nt * NS + 1) * 16 <= COUT);
+              if (ow == 1 && pw0_tile) continue;
               acc[cls][t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[nt].v[s], bf[ch][t].v[s], acc[cls][t][nt], 0, 0, 0);
             }
       }
@@ -499,7 +515,7 @@ __global__ __launch_bounds__(256) void convtr_all_kernel(const ConvParams p) {
     const int pd = cls >> 1, ph = cls & 1;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int r0 = nt * 16 + 4 * q;
+      const int r0 = (nt0 + nt * NS) * 16 + 4 * q;
       if (r0 >= ROWS) continue;
       const int pw_out = r0 / COUT, c0 = r0 % COUT;
       const float4 al = ep_al[nt], be = ep_be[nt];
@@ -523,10 +539,10 @@ __global__ __launch_bounds__(256) void convtr_all_kernel(const ConvParams p) {
   }
 }
 
-template <int CIN, int COUT, int MT>
+template <int CIN, int COUT, int MT, int NS = 1>
 int launch_convtr_all(ConvParams& p, hipStream_t st) {
   p.nblk = (unsigned)((p.m_total + 4LL * MT * 16 - 1) / (4LL * MT * 16));
-  hipLaunchKernelGGL((convtr_all_kernel<CIN, COUT, MT>), dim3(p.nblk), dim3(256), 0, st, p);
+  hipLaunchKernelGGL((convtr_all_kernel<CIN, COUT, MT, NS>), dim3(p.nblk, NS), dim3(256), 0, st, p);
   return mdf::check_launch("convtr_all_kernel");
 }
 
@@ -956,8 +972,9 @@ static int conv3d_entry(const float* x, const float* wpack, const float* alpha, 
     if (rc != MDF_EUNSUPPORTED) return rc;
   }
   if (m == kTr && !stat) {   // large transposed layers: all four parity classes per tile (convtr_all_kernel)
-    const long long tr_min = [] { const char* e = getenv("MDF_CONVTR_ALL_MIN_VOXELS"); return e ? atoll(e) : 100000LL; }();   // dev A/B (read per call); -1 = never
-    if (tr_min >= 0 && p.m_total >= tr_min) {
+    const long long tr_min = [] { const char* e = getenv("MDF_CONVTR_ALL_MIN_VOXELS"); return e ? atoll(e) : 40000LL; }();   // dev A/B (read per call); -1 = never  (r05: 100000 -> 40000, 32->16 @2x148x200 36.7 -> 30.2 us, @6x74x100 29.2 -> 24.7)
+    const int ns = [] { const char* e = getenv("MDF_CONVTR_NS"); return e ? atoi(e) : 0; }();   // dev A/B and the equality test (read per call): 0 = the rule, 1 = off
+    if (tr_min >= 0 && p.m_total >= tr_min && !(Cin == 64 && Cout == 32 && ns > 1)) {
       // One 16-voxel m-tile per wave (r05; two until then): these layers' time is MFMA time PLUS streaming time (skip + output), and the
       // smaller accumulator set lets 4-5 waves per SIMD instead of 3-4 overlap one block's streaming with another's MFMAs:
       // 32->16 @24x74x100 89.2 -> 69.3 us, 16->8 @12x148x200 51.2 -> 47.4, @4x296x400 79.4 -> 74.7 (four tiles: 88 / 67 / 97)
@@ -967,6 +984,13 @@ static int conv3d_entry(const float* x, const float* wpack, const float* alpha, 
       if (Cin == 16 && Cout == 8) return launch_convtr_all<16, 8, 1>(p, (hipStream_t)stream);
       if (Cin == 32 && Cout == 16) return launch_convtr_all<32, 16, 1>(p, (hipStream_t)stream);
       if (Cin == 64 && Cout == 32) return launch_convtr_all<64, 32, 1>(p, (hipStream_t)stream);
+    }
+    // The innermost 64 -> 32 layers (1388 / 347 / 463 m-tiles at cfg2: fewer waves than the chip has SIMDs, each with 864 MFMAs behind 27
+    // weight taps): the four n-tiles of an m-tile over two or four waves
+    // (r05, against conv3d_kernel<kTr>: @12x37x50 53.9 -> 40.5 us over two waves, 38.7 over four; @3x37x50 21.4 -> 16.8 over four)
+    if (tr_min >= 0 && Cin == 64 && Cout == 32 && ns != 1 && (p.m_total < tr_min || ns > 1)) {
+      if (ns == 2) return launch_convtr_all<64, 32, 1, 2>(p, (hipStream_t)stream);
+      return launch_convtr_all<64, 32, 1, 4>(p, (hipStream_t)stream);
     }
   }
   // stride 1 (every Cin x Cout the nets use)

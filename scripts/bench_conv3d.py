@@ -23,7 +23,8 @@ if "--small" in sys.argv:     # the small-volume levels of the three U-Nets (spl
          ("s1.conv34.0", 32, 64, "s2", 6, 74, 100), ("s1.conv34.1", 64, 64, "s1", 3, 37, 50), ("s2.conv23.1", 32, 32, "s1", 2, 148, 200),
          ("s2.conv34.0", 32, 64, "s2", 2, 148, 200), ("s2.conv34.1", 64, 64, "s1", 1, 74, 100)]
 if "--smalltr" in sys.argv:   # the shallow transposed layers (stage 2's innermost levels)
-    L = [("s2.tr43", 64, 32, "tr", 1, 74, 100), ("s2.tr32", 32, 16, "tr", 2, 148, 200), ("s1.tr43", 64, 32, "tr", 3, 37, 50)]
+    L = [("s2.tr43", 64, 32, "tr", 1, 74, 100), ("s2.tr32", 32, 16, "tr", 2, 148, 200), ("s1.tr43", 64, 32, "tr", 3, 37, 50),
+         ("s1.tr32", 32, 16, "tr", 6, 74, 100), ("s0.tr32", 64, 32, "tr", 12, 37, 50)]
 if "--s2" in sys.argv:
     L = [l for l in L if l[3] == "s2"]
 dev = "cuda:0"

@@ -232,8 +232,12 @@ def test_transposed_conv_all_classes_kernel_equals_the_per_class_kernel(cin, cou
     al, be = (torch.rand(cout, generator=g) + 0.5).to(DEV), (torch.randn(cout, generator=g) * 0.1).to(DEV)
     res = torch.randn(b, 2 * d, 2 * h, 2 * w, cout, generator=g).to(DEV)
     for kw in (dict(), dict(alpha=al, beta=be, relu=True, res=res)):
-        monkeypatch.setenv("MDF_CONVTR_ALL_MIN_VOXELS", "0")
-        got = ops.conv3d_ndhwc(x, wp, cin, cout, 2, True, **kw)
         monkeypatch.setenv("MDF_CONVTR_ALL_MIN_VOXELS", "-1")
         exp = ops.conv3d_ndhwc(x, wp, cin, cout, 2, True, **kw)
-        assert torch.equal(got, exp)
+        monkeypatch.setenv("MDF_CONVTR_ALL_MIN_VOXELS", "0")
+        # MDF_CONVTR_NS (64 -> 32 only): 1 = every n-tile of an m-tile in one wave, 2 / 4 = dealt out to two / four waves (small volumes)
+        for ns in (("1", "2", "4") if cin == 64 else ("1",)):
+            monkeypatch.setenv("MDF_CONVTR_NS", ns)
+            got = ops.conv3d_ndhwc(x, wp, cin, cout, 2, True, **kw)
+            assert torch.equal(got, exp), ns
+        monkeypatch.delenv("MDF_CONVTR_NS")
