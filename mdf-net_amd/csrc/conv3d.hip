@@ -770,6 +770,201 @@ __global__ void pack_batch_kernel(const PackJob* __restrict__ jobs, const int* _
   for (int k = 0; k < kPackPerBlock / 256; ++k) pack_job_elem(j, base + k * 256 + threadIdx.x);
 }
 
+// ---- small and mid-size stride-1 / stride-2 layers whose whole packed weight set fits LDS (16 -> 32: 55 KB, 32 -> 32: 110 KB) ---------
+// conv3d_kernel streams every weight fragment through the vector L1 for ONE 16-voxel tile (a fragment is used by 1-2 MFMAs per m-tile
+// and n-tile: 512 B per MFMA at 32 -> 32, the whole L1 rate), and its one-tile blocks come in a ragged 1.3-2.7 rounds.  Here a block is
+// the 16 waves one CU holds: the weight set is copied to LDS once per block, every wave walks m-tiles (stride = the grid's waves) and
+// reads its A fragments with ds_read_b128; the B fragments of the next tap are requested before the MFMAs of the current one.
+// Per accumulator the MFMA order is conv3d_kernel's without split-K (tap, cin chunk, k).  Eval only (no epilogue sums).
+template <int CIN, int COUT, int MODE, int MT>
+__global__ __launch_bounds__(1024) void conv3d_wlds_kernel(const ConvParams p) {
+  constexpr int KPL = (CIN >= 16) ? 4 : 2, CK = 4 * KPL, NCH = CIN / CK, NT = (COUT + 15) / 16;
+  constexpr int TAPF = NCH * NT * 64 * KPL;             // floats per tap in the packed set
+  static_assert(MODE == kS1 || MODE == kS2, "stride-1 / stride-2 layers");
+  extern __shared__ float wsm[];
+  {
+    const float4* src = reinterpret_cast<const float4*>(p.wpack);
+    float4* dst = reinterpret_cast<float4*>(wsm);
+    for (int i = threadIdx.x; i < 27 * TAPF / 4; i += 1024) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, n16 = lane & 15;
+  float4 ep_al[NT], ep_be[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int r0 = nt * 16 + 4 * q;
+    ep_al[nt] = make_float4(1.f, 1.f, 1.f, 1.f);
+    ep_be[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 < COUT && p.alpha) {
+      ep_al[nt] = *reinterpret_cast<const float4*>(p.alpha + r0);
+      ep_be[nt] = *reinterpret_cast<const float4*>(p.beta + r0);
+    }
+  }
+  const float* xq = p.x + KPL * q;
+  const float* wl = wsm + lane * KPL;
+  const int sd = (MODE == kS2) ? 2 : 1;
+  // m-tiles: XCD x (= blockIdx.x & 7) owns a contiguous eighth of them (neighbouring tiles' halos meet in one L2); inside it consecutive
+  // tiles go to consecutive blocks, so that every CU is busy whatever the tile count (nblk = number of m-tile groups of MT tiles)
+  const unsigned xcd = blockIdx.x & 7u, bx = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+  const unsigned cq = p.nblk >> 3, cr = p.nblk & 7u;
+  const unsigned c_start = (xcd < cr) ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq, c_len = cq + (xcd < cr ? 1u : 0u);
+  for (unsigned l = (unsigned)wave * nbx + bx; l < c_len; l += 16u * nbx) {
+    const long long m0 = (long long)(c_start + l) * (MT * 16);
+    int in_off[MT];
+    unsigned vmask[MT];                     // bits 0-2: kd valid, 3-5: kh valid, 6-8: kw valid
+    long long out_vox[MT];
+    bool live[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      long long m = m0 + t * 16 + n16;
+      live[t] = m < p.m_total;
+      if (!live[t]) m = p.m_total - 1;
+      const unsigned mu = (unsigned)m, r1 = mu / (unsigned)p.Wo, r2 = r1 / (unsigned)p.Ho;
+      const int mw = (int)(mu - r1 * (unsigned)p.Wo), mh = (int)(r1 - r2 * (unsigned)p.Ho);
+      const int b = (int)(r2 / (unsigned)p.Do), md = (int)(r2 - (unsigned)b * (unsigned)p.Do);
+      const int bd = sd * md, bh = sd * mh, bw = sd * mw;
+      unsigned vm = 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (bd + k - 1 >= 0 && bd + k - 1 < p.Di) vm |= 1u << k;
+        if (bh + k - 1 >= 0 && bh + k - 1 < p.Hi) vm |= 8u << k;
+        if (bw + k - 1 >= 0 && bw + k - 1 < p.Wi) vm |= 64u << k;
+      }
+      vmask[t] = live[t] ? vm : 0u;
+      in_off[t] = (int)((((long long)b * p.Di + bd) * p.Hi + bh) * p.Wi + bw) * CIN;
+      out_vox[t] = m;
+    }
+    // depth taps no voxel of this wave has (volumes 1-3 planes deep): skipped, as in conv3d_kernel (kd_any)
+    unsigned kd_any = 7u;
+    if (p.kd_skip) {
+      unsigned m_or = 0u;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) m_or |= vmask[t];
+      kd_any = (__any((int)(m_or & 1u)) ? 1u : 0u) | (__any((int)(m_or & 2u)) ? 2u : 0u) | (__any((int)(m_or & 4u)) ? 4u : 0u);
+      kd_any = (unsigned)__builtin_amdgcn_readfirstlane((int)kd_any);
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto load_b = [&](int kd, int kh, int kw, Frag<KPL> (&bf)[NCH][MT]) {
+      const int tapoff = (((kd - 1) * p.Hi + (kh - 1)) * p.Wi + (kw - 1)) * CIN;
+      const unsigned need = (1u << kd) | (8u << kh) | (64u << kw);
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {      // (branch-free: see conv3d_kernel)
+          const bool ok = (vmask[t] & need) == need;
+          bf[ch][t].load(xq + in_off[t] + (ok ? tapoff : 0) + ch * CK);      // (zeroed in mul_tap: a multiply here would wait for the load)
+        }
+    };
+    auto mul_tap = [&](int tap, int kd, int kh, int kw, Frag<KPL> (&bf)[NCH][MT]) {
+      const float* wt = wl + tap * TAPF;
+      const unsigned need = (1u << kd) | (8u << kh) | (64u << kw);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const float okf = ((vmask[t] & need) == need) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) bf[ch][t].scale(okf);
+      }
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        Frag<KPL> af[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) af[nt].load(wt + (ch * NT + nt) * (64 * KPL));
+#pragma unroll
+        for (int s = 0; s < KPL; ++s)
+#pragma unroll
+          for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[nt].v[s], bf[ch][t].v[s], acc[t][nt], 0, 0, 0);
+      }
+    };
+    // rows (kd, kh) of three taps; the next row's B fragments are requested before the current row's MFMAs (two register sets)
+    struct RowRegs { Frag<KPL> b[3][NCH][MT]; };
+    auto load_row = [&](int r, RowRegs& rr) {
+      const int kd = r / 3, kh = r - 3 * kd;
+      load_b(kd, kh, 0, rr.b[0]);
+      load_b(kd, kh, 1, rr.b[1]);
+      load_b(kd, kh, 2, rr.b[2]);
+    };
+    auto mul_row = [&](int r, RowRegs& rr) {
+      const int kd = r / 3, kh = r - 3 * kd;
+      mul_tap(3 * r, kd, kh, 0, rr.b[0]);
+      mul_tap(3 * r + 1, kd, kh, 1, rr.b[1]);
+      mul_tap(3 * r + 2, kd, kh, 2, rr.b[2]);
+    };
+    auto next_row = [&](int r) {
+      ++r;
+      while (r < 9 && !((kd_any >> (r / 3)) & 1u)) ++r;
+      return r;
+    };
+    {
+      RowRegs ra, rb;
+      int r = next_row(-1);
+      if (r < 9) load_row(r, ra);
+      while (r < 9) {
+        int rn = next_row(r);
+        if (rn < 9) load_row(rn, rb);
+        __builtin_amdgcn_sched_barrier(0);       // (the requests stay ahead of the MFMAs)
+        mul_row(r, ra);
+        r = rn;
+        if (r >= 9) break;
+        rn = next_row(r);
+        if (rn < 9) load_row(rn, ra);
+        __builtin_amdgcn_sched_barrier(0);
+        mul_row(r, rb);
+        r = rn;
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int r0 = nt * 16 + 4 * q;
+      if (r0 >= COUT) continue;
+      const float4 al = ep_al[nt], be = ep_be[nt];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        if (!live[t]) continue;
+        float4 o;
+        o.x = acc[t][nt][0] * al.x + be.x;
+        o.y = acc[t][nt][1] * al.y + be.y;
+        o.z = acc[t][nt][2] * al.z + be.z;
+        o.w = acc[t][nt][3] * al.w + be.w;
+        if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        const size_t oi = (size_t)out_vox[t] * COUT + r0;
+        if (p.res) {
+          const float4 rr = *reinterpret_cast<const float4*>(p.res + oi);
+          o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+        }
+        *reinterpret_cast<float4*>(p.y + oi) = o;
+      }
+    }
+  }
+}
+
+template <int CIN, int COUT, int MODE, int MT>
+int launch_conv_wlds(ConvParams& p, hipStream_t st) {
+  constexpr int KPL = (CIN >= 16) ? 4 : 2, NCH = CIN / (4 * KPL), NT = (COUT + 15) / 16;
+  constexpr size_t kLds = (size_t)27 * NCH * NT * 64 * KPL * sizeof(float);
+  static_assert(kLds <= 160 * 1024, "the packed weight set must fit LDS");
+  auto kern = &conv3d_wlds_kernel<CIN, COUT, MODE, MT>;
+  static bool attr_done_dev[64] = {};     // (per-device function attribute: see conv_lds.hip)
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  bool& attr_done = attr_done_dev[(dev_id >= 0 && dev_id < 64) ? dev_id : 0];
+  if (!attr_done || dev_id >= 64) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+    if (e != hipSuccess) return mdf::fail(MDF_EHIP, "hipFuncSetAttribute(dynamic LDS %zu): %s", kLds, hipGetErrorString(e));
+    attr_done = true;
+  }
+  p.nblk = (unsigned)((p.m_total + MT * 16 - 1) / (MT * 16));      // wave tiles
+  hipLaunchKernelGGL(kern, dim3(256), dim3(1024), kLds, st, p);     // one block (16 waves) per CU
+  return mdf::check_launch("conv3d_wlds_kernel");
+}
+
 template <int CIN, int COUT, int MODE, int MT, int SPLITK, int ST>
 int launch_conv(ConvParams& p, hipStream_t st) {
   const long long per_blk = (SPLITK > 1 ? 1LL : 4LL) * MT * 16;
@@ -991,6 +1186,14 @@ static int conv3d_entry(const float* x, const float* wpack, const float* alpha, 
     if (tr_min >= 0 && Cin == 64 && Cout == 32 && ns != 1 && (p.m_total < tr_min || ns > 1)) {
       if (ns == 2) return launch_convtr_all<64, 32, 1, 2>(p, (hipStream_t)stream);
       return launch_convtr_all<64, 32, 1, 4>(p, (hipStream_t)stream);
+    }
+  }
+  // weights-in-LDS form for the small and mid-size layers whose packed set fits (eval)
+  if (!stat) {
+    const int wl = [] { const char* e = getenv("MDF_CONV3D_WLDS"); return e ? atoi(e) : 1; }();   // dev A/B (read per call): 0 = off
+    if (wl == 1) {     // (two m-tiles per wave were measured and lose: 32 -> 32 @6x74x100 35 -> 64 us, 16 -> 32 s2 @48x148x200 61 -> 76)
+      if (Cin == 32 && Cout == 32 && m == kS1) return launch_conv_wlds<32, 32, kS1, 1>(p, (hipStream_t)stream);
+      if (Cin == 16 && Cout == 32 && m == kS2) return launch_conv_wlds<16, 32, kS2, 1>(p, (hipStream_t)stream);
     }
   }
   // stride 1 (every Cin x Cout the nets use)

@@ -21,7 +21,8 @@ if "--tr" in sys.argv:
 if "--small" in sys.argv:     # the small-volume levels of the three U-Nets (split-K / one-tile kernels)
     L = [("s0.conv232.1", 64, 64, "s1", 12, 37, 50), ("s0.conv232.0", 32, 64, "s2", 24, 74, 100), ("s1.conv23.1", 32, 32, "s1", 6, 74, 100),
          ("s1.conv34.0", 32, 64, "s2", 6, 74, 100), ("s1.conv34.1", 64, 64, "s1", 3, 37, 50), ("s2.conv23.1", 32, 32, "s1", 2, 148, 200),
-         ("s2.conv34.0", 32, 64, "s2", 2, 148, 200), ("s2.conv34.1", 64, 64, "s1", 1, 74, 100)]
+         ("s2.conv34.0", 32, 64, "s2", 2, 148, 200), ("s2.conv34.1", 64, 64, "s1", 1, 74, 100),
+         ("s0.conv12.0", 16, 32, "s2", 48, 148, 200), ("s1.conv23.0", 16, 32, "s2", 12, 148, 200), ("s2.conv23.0", 16, 32, "s2", 4, 296, 400)]
 if "--smalltr" in sys.argv:   # the shallow transposed layers (stage 2's innermost levels)
     L = [("s2.tr43", 64, 32, "tr", 1, 74, 100), ("s2.tr32", 32, 16, "tr", 2, 148, 200), ("s1.tr43", 64, 32, "tr", 3, 37, 50),
          ("s1.tr32", 32, 16, "tr", 6, 74, 100), ("s0.tr32", 64, 32, "tr", 12, 37, 50)]
