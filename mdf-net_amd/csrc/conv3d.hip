@@ -416,16 +416,45 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const ConvParams p) {
 // NS > 1 (small volumes: fewer m-tiles than the chip has SIMDs): the n-tiles of an m-tile are dealt out to NS waves (blockIdx.y = first
 // n-tile, stride NS), each fetching the input fragments itself -- NS times the waves at 1/NS of the MFMAs and weight bytes each.  With
 // NS = 2 and four n-tiles a wave holds one tile of each output w-parity, so the two halves carry the same work.
-template <int CIN, int COUT, int MT, int NS>
-__global__ __launch_bounds__(256) void convtr_all_kernel(const ConvParams p) {
+// WL (r05; = waves per block): the packed weight set (18 tap slots; 72 KB at 32 -> 16, 18 KB at 16 -> 8) in LDS, one 12- or 16-wave block per CU walking the m-tiles
+// (XCD-chunked, as conv3d_wlds_kernel): the per-class kernel streams 27 KB (16 -> 8) / 55 KB (32 -> 16) of weight fragments through the
+// vector L1 for every 16 input voxels -- 3-6 times the bytes of the skip + output stream those voxels cause in HBM.
+template <int CIN, int COUT, int MT, int NS, int WL>
+__global__ __launch_bounds__(WL ? WL * 64 : 256) void convtr_all_kernel(const ConvParams p) {
   constexpr int KPL = (CIN >= 16) ? 4 : 2, CK = 4 * KPL, NCH = CIN / CK;
   constexpr int ROWS = 2 * COUT, NTA = (ROWS + 15) / 16, NT = NTA / NS;     // NTA n-tiles in all, NT of them in this wave
   static_assert(NTA % NS == 0, "the n-tiles must divide over the NS waves");
   const int nt0 = (NS > 1) ? (int)blockIdx.y : 0;                          // this wave's n-tiles: nt0 + i * NS
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, n16 = lane & 15;
-  const unsigned tile_blk = mdf::xcd_remap(blockIdx.x, p.nblk);
-  const long long m0 = ((long long)tile_blk * 4 + wave) * (MT * 16);
+  extern __shared__ float wsm[];
+  float4 ep_al[NT], ep_be[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int r0 = (nt0 + nt * NS) * 16 + 4 * q, c0 = r0 % COUT;
+    ep_al[nt] = make_float4(1.f, 1.f, 1.f, 1.f);
+    ep_be[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 < ROWS && p.alpha) {
+      ep_al[nt] = *reinterpret_cast<const float4*>(p.alpha + c0);
+      ep_be[nt] = *reinterpret_cast<const float4*>(p.beta + c0);
+    }
+  }
+  const float* xq = p.x + KPL * q;
+  const float* wl = (WL ? wsm : p.wpack) + (size_t)lane * KPL;
+  unsigned l_first = 0u, l_end = 1u, l_step = 1u, c_start = 0u;
+  if constexpr (WL != 0) {
+    static_assert(NS == 1, "the LDS-weights form keeps an m-tile's n-tiles in one wave");
+    const float4* src = reinterpret_cast<const float4*>(p.wpack);
+    float4* dst = reinterpret_cast<float4*>(wsm);
+    for (int i = threadIdx.x; i < 18 * NCH * NTA * 64 * KPL / 4; i += WL * 64) dst[i] = src[i];
+    __syncthreads();
+    const unsigned xcd = blockIdx.x & 7u, bx = blockIdx.x >> 3, nbx = gridDim.x >> 3;      // (p.nblk = wave tiles here)
+    const unsigned cq = p.nblk >> 3, cr = p.nblk & 7u;
+    c_start = (xcd < cr) ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
+    l_first = (unsigned)wave * nbx + bx; l_end = cq + (xcd < cr ? 1u : 0u); l_step = (unsigned)WL * nbx;
+  }
+  for (unsigned l = l_first; l < l_end; l += l_step) {
+  const long long m0 = WL ? (long long)(c_start + l) * (MT * 16) : ((long long)mdf::xcd_remap(blockIdx.x, p.nblk) * 4 + wave) * (MT * 16);
 
   int in_off[MT];
   long long out_vox[MT];      // output voxel (2d, 2h, 2w) of the lane's input voxel
@@ -449,19 +478,6 @@ __global__ __launch_bounds__(256) void convtr_all_kernel(const ConvParams p) {
     for (int t = 0; t < MT; ++t)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[c][t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float4 ep_al[NT], ep_be[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int r0 = (nt0 + nt * NS) * 16 + 4 * q, c0 = r0 % COUT;
-    ep_al[nt] = make_float4(1.f, 1.f, 1.f, 1.f);
-    ep_be[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r0 < ROWS && p.alpha) {
-      ep_al[nt] = *reinterpret_cast<const float4*>(p.alpha + c0);
-      ep_be[nt] = *reinterpret_cast<const float4*>(p.beta + c0);
-    }
-  }
-  const float* xq = p.x + KPL * q;
-  const float* wl = p.wpack + (size_t)lane * KPL;
   bool no_next_plane = false;
   if (p.kd_skip) {
     unsigned m_or = 0u;
@@ -537,12 +553,33 @@ __global__ __launch_bounds__(256) void convtr_all_kernel(const ConvParams p) {
       }
     }
   }
+  }  // tile loop (one tile unless WL)
+}
+
+template <int CIN, int COUT, int MT, int NWV>
+int launch_convtr_all_wl(ConvParams& p, hipStream_t st) {
+  constexpr int KPL = (CIN >= 16) ? 4 : 2, NCH = CIN / (4 * KPL), NTA = (2 * COUT + 15) / 16;
+  constexpr size_t kLds = (size_t)18 * NCH * NTA * 64 * KPL * sizeof(float);
+  static_assert(kLds <= 160 * 1024, "the packed weight set must fit LDS");
+  auto kern = &convtr_all_kernel<CIN, COUT, MT, 1, NWV>;
+  static bool attr_done_dev[64] = {};     // (per-device function attribute: see conv_lds.hip)
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  bool& attr_done = attr_done_dev[(dev_id >= 0 && dev_id < 64) ? dev_id : 0];
+  if (!attr_done || dev_id >= 64) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+    if (e != hipSuccess) return mdf::fail(MDF_EHIP, "hipFuncSetAttribute(dynamic LDS %zu): %s", kLds, hipGetErrorString(e));
+    attr_done = true;
+  }
+  p.nblk = (unsigned)((p.m_total + MT * 16 - 1) / (MT * 16));      // wave tiles
+  hipLaunchKernelGGL(kern, dim3(256), dim3(NWV * 64), kLds, st, p);     // one block per CU
+  return mdf::check_launch("convtr_all_kernel");
 }
 
 template <int CIN, int COUT, int MT, int NS = 1>
 int launch_convtr_all(ConvParams& p, hipStream_t st) {
   p.nblk = (unsigned)((p.m_total + 4LL * MT * 16 - 1) / (4LL * MT * 16));
-  hipLaunchKernelGGL((convtr_all_kernel<CIN, COUT, MT, NS>), dim3(p.nblk, NS), dim3(256), 0, st, p);
+  hipLaunchKernelGGL((convtr_all_kernel<CIN, COUT, MT, NS, 0>), dim3(p.nblk, NS), dim3(256), 0, st, p);
   return mdf::check_launch("convtr_all_kernel");
 }
 
@@ -1174,6 +1211,11 @@ static int conv3d_entry(const float* x, const float* wpack, const float* alpha, 
       // smaller accumulator set lets 4-5 waves per SIMD instead of 3-4 overlap one block's streaming with another's MFMAs:
       // 32->16 @24x74x100 89.2 -> 69.3 us, 16->8 @12x148x200 51.2 -> 47.4, @4x296x400 79.4 -> 74.7 (four tiles: 88 / 67 / 97)
       const int mt = [] { const char* e = getenv("MDF_CONVTR_MT"); return e ? atoi(e) : 1; }();   // dev A/B (read per call)
+      const int twl = [] { const char* e = getenv("MDF_CONVTR_WLDS"); return e ? atoi(e) : 0; }();   // dev A/B (read per call): weights in LDS, m-tiles per wave
+      if (Cin == 16 && Cout == 8 && twl == 1) return launch_convtr_all_wl<16, 8, 1, 16>(p, (hipStream_t)stream);
+      if (Cin == 16 && Cout == 8 && twl == 2) return launch_convtr_all_wl<16, 8, 2, 12>(p, (hipStream_t)stream);
+      if (Cin == 32 && Cout == 16 && twl == 1) return launch_convtr_all_wl<32, 16, 1, 12>(p, (hipStream_t)stream);
+      if (Cin == 32 && Cout == 16 && twl == 2) return launch_convtr_all_wl<32, 16, 1, 8>(p, (hipStream_t)stream);
       if (Cin == 16 && Cout == 8 && mt == 2) return launch_convtr_all<16, 8, 2>(p, (hipStream_t)stream);
       if (Cin == 32 && Cout == 16 && mt == 2) return launch_convtr_all<32, 16, 2>(p, (hipStream_t)stream);
       if (Cin == 16 && Cout == 8) return launch_convtr_all<16, 8, 1>(p, (hipStream_t)stream);
@@ -1194,6 +1236,13 @@ static int conv3d_entry(const float* x, const float* wpack, const float* alpha, 
     if (wl == 1) {     // (two m-tiles per wave were measured and lose: 32 -> 32 @6x74x100 35 -> 64 us, 16 -> 32 s2 @48x148x200 61 -> 76)
       if (Cin == 32 && Cout == 32 && m == kS1) return launch_conv_wlds<32, 32, kS1, 1>(p, (hipStream_t)stream);
       if (Cin == 16 && Cout == 32 && m == kS2) return launch_conv_wlds<16, 32, kS2, 1>(p, (hipStream_t)stream);
+    }
+    const int wl8 = [] { const char* e = getenv("MDF_CONV3D_WLDS8"); return e ? atoi(e) : 2; }();   // dev A/B (read per call): m-tiles per wave, 0 = off
+    // (8 -> 16 stride 2, the gather-heavy layers: @24x296x400 50.4 us -> 46.5 / 43.5 / 49.7 with 1 / 2 / 4 m-tiles per wave, @8x592x800 66.0 -> 60.1 / 55.0 / 64.8)
+    if (Cin == 8 && Cout == 16 && m == kS2) {
+      if (wl8 == 1) return launch_conv_wlds<8, 16, kS2, 1>(p, (hipStream_t)stream);
+      if (wl8 == 2) return launch_conv_wlds<8, 16, kS2, 2>(p, (hipStream_t)stream);
+      if (wl8 == 4) return launch_conv_wlds<8, 16, kS2, 4>(p, (hipStream_t)stream);
     }
   }
   // stride 1 (every Cin x Cout the nets use)

@@ -241,3 +241,9 @@ def test_transposed_conv_all_classes_kernel_equals_the_per_class_kernel(cin, cou
             got = ops.conv3d_ndhwc(x, wp, cin, cout, 2, True, **kw)
             assert torch.equal(got, exp), ns
         monkeypatch.delenv("MDF_CONVTR_NS")
+        # MDF_CONVTR_WLDS (16 -> 8, 32 -> 16): the weight set in LDS, one persistent block per CU walking the m-tiles
+        for wl in (("1", "2") if cin < 64 else ()):
+            monkeypatch.setenv("MDF_CONVTR_WLDS", wl)
+            got = ops.conv3d_ndhwc(x, wp, cin, cout, 2, True, **kw)
+            assert torch.equal(got, exp), ("wlds", wl)
+        monkeypatch.delenv("MDF_CONVTR_WLDS", raising=False)
