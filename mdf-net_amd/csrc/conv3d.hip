@@ -813,7 +813,7 @@ __global__ void pack_batch_kernel(const PackJob* __restrict__ jobs, const int* _
 // the 16 waves one CU holds: the weight set is copied to LDS once per block, every wave walks m-tiles (stride = the grid's waves) and
 // reads its A fragments with ds_read_b128; the B fragments of the next tap are requested before the MFMAs of the current one.
 // Per accumulator the MFMA order is conv3d_kernel's without split-K (tap, cin chunk, k).  Eval only (no epilogue sums).
-template <int CIN, int COUT, int MODE, int MT>
+template <int CIN, int COUT, int MODE, int MT, int ST>
 __global__ __launch_bounds__(1024) void conv3d_wlds_kernel(const ConvParams p) {
   constexpr int KPL = (CIN >= 16) ? 4 : 2, CK = 4 * KPL, NCH = CIN / CK, NT = (COUT + 15) / 16;
   constexpr int TAPF = NCH * NT * 64 * KPL;             // floats per tap in the packed set
@@ -823,6 +823,16 @@ __global__ __launch_bounds__(1024) void conv3d_wlds_kernel(const ConvParams p) {
     const float4* src = reinterpret_cast<const float4*>(p.wpack);
     float4* dst = reinterpret_cast<float4*>(wsm);
     for (int i = threadIdx.x; i < 27 * TAPF / 4; i += 1024) dst[i] = src[i];
+  }
+  // ST (training): the block's fp64 table of the epilogue sums and the producing layer's (a, b, mean, invstd), as in conv3d_kernel
+  __shared__ double st_tab[ST ? 128 : 1];
+  __shared__ float st_aux[ST ? 256 : 1];
+  if constexpr (ST != 0) {
+    if (threadIdx.x < 128) st_tab[threadIdx.x] = 0.0;
+    if (p.stat_mode == 2 && threadIdx.x < 256) {
+      const int c = threadIdx.x & 63;
+      st_aux[threadIdx.x] = (c < COUT) ? p.stat_aux[(threadIdx.x >> 6) * COUT + c] : 0.f;
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -962,6 +972,7 @@ __global__ __launch_bounds__(1024) void conv3d_wlds_kernel(const ConvParams p) {
       const int r0 = nt * 16 + 4 * q;
       if (r0 >= COUT) continue;
       const float4 al = ep_al[nt], be = ep_be[nt];
+      float ps[4] = {0.f, 0.f, 0.f, 0.f}, pq[4] = {0.f, 0.f, 0.f, 0.f};   // ST: this lane's sums over its m-tiles
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         if (!live[t]) continue;
@@ -977,17 +988,44 @@ __global__ __launch_bounds__(1024) void conv3d_wlds_kernel(const ConvParams p) {
           o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
         }
         *reinterpret_cast<float4*>(p.y + oi) = o;
+        if constexpr (ST != 0) {
+          const float ov[4] = {o.x, o.y, o.z, o.w};
+          if (p.stat_mode == 1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { ps[c] += ov[c]; pq[c] = fmaf(ov[c], ov[c], pq[c]); }
+          } else {
+            const float4 yv4 = *reinterpret_cast<const float4*>(p.stat_y + oi);
+            const float yv[4] = {yv4.x, yv4.y, yv4.z, yv4.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float dr = (fmaf(yv[c], st_aux[r0 + c], st_aux[64 + r0 + c]) > 0.0f) ? ov[c] : 0.0f;
+              ps[c] += dr;
+              pq[c] = fmaf(dr, (yv[c] - st_aux[128 + r0 + c]) * st_aux[192 + r0 + c], pq[c]);
+            }
+          }
+        }
+      }
+      if constexpr (ST != 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float a1 = row16_sum(ps[c]), a2 = row16_sum(pq[c]);
+          if (n16 == 0) { lds_add_f64(&st_tab[r0 + c], (double)a1); lds_add_f64(&st_tab[64 + r0 + c], (double)a2); }
+        }
       }
     }
   }
+  if constexpr (ST != 0) {
+    __syncthreads();
+    mdf::conv_stat_send<COUT>(st_tab, p.stat_out, 2 * COUT, p.stat_slices, blockIdx.x);
+  }
 }
 
-template <int CIN, int COUT, int MODE, int MT>
+template <int CIN, int COUT, int MODE, int MT, int ST = 0>
 int launch_conv_wlds(ConvParams& p, hipStream_t st) {
   constexpr int KPL = (CIN >= 16) ? 4 : 2, NCH = CIN / (4 * KPL), NT = (COUT + 15) / 16;
   constexpr size_t kLds = (size_t)27 * NCH * NT * 64 * KPL * sizeof(float);
   static_assert(kLds <= 160 * 1024, "the packed weight set must fit LDS");
-  auto kern = &conv3d_wlds_kernel<CIN, COUT, MODE, MT>;
+  auto kern = &conv3d_wlds_kernel<CIN, COUT, MODE, MT, ST>;
   static bool attr_done_dev[64] = {};     // (per-device function attribute: see conv_lds.hip)
   int dev_id = 0;
   (void)hipGetDevice(&dev_id);
@@ -998,6 +1036,7 @@ int launch_conv_wlds(ConvParams& p, hipStream_t st) {
     attr_done = true;
   }
   p.nblk = (unsigned)((p.m_total + MT * 16 - 1) / (MT * 16));      // wave tiles
+  if (ST) p.stat_slices = mdf::conv_stat_slices(256, p.stat_slices);
   hipLaunchKernelGGL(kern, dim3(256), dim3(1024), kLds, st, p);     // one block (16 waves) per CU
   return mdf::check_launch("conv3d_wlds_kernel");
 }
@@ -1231,6 +1270,15 @@ static int conv3d_entry(const float* x, const float* wpack, const float* alpha, 
     }
   }
   // weights-in-LDS form for the small and mid-size layers whose packed set fits (eval)
+  if (stat) {    // training: the same form with the epilogue sums
+    const int wlt = [] { const char* e = getenv("MDF_CONV3D_WLDS_TRAIN"); return e ? atoi(e) : 1; }();   // dev A/B (read per call): 0 = off
+    if (wlt == 1) {
+      if (Cin == 32 && Cout == 32 && m == kS1) return launch_conv_wlds<32, 32, kS1, 1, 1>(p, (hipStream_t)stream);
+      if (Cin == 16 && Cout == 16 && m == kS1) return launch_conv_wlds<16, 16, kS1, 1, 1>(p, (hipStream_t)stream);
+      if (Cin == 16 && Cout == 32 && m == kS2) return launch_conv_wlds<16, 32, kS2, 1, 1>(p, (hipStream_t)stream);
+      if (Cin == 8 && Cout == 16 && m == kS2) return launch_conv_wlds<8, 16, kS2, 2, 1>(p, (hipStream_t)stream);
+    }
+  }
   if (!stat) {
     const int wl = [] { const char* e = getenv("MDF_CONV3D_WLDS"); return e ? atoi(e) : 1; }();   // dev A/B (read per call): 0 = off
     if (wl == 1) {     // (two m-tiles per wave were measured and lose: 32 -> 32 @6x74x100 35 -> 64 us, 16 -> 32 s2 @48x148x200 61 -> 76)
