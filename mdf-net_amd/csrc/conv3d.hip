@@ -478,6 +478,24 @@ __global__ __launch_bounds__(WL ? WL * 64 : 256) void convtr_all_kernel(const Co
     for (int t = 0; t < MT; ++t)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[c][t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // WL: the skip tensor's values are requested now, ahead of the tile's MFMAs (a persistent wave has no neighbour block to hide the
+  // epilogue's round trip behind)
+  constexpr bool kPreRes = (WL != 0);
+  float4 ep_res[kPreRes ? 4 : 1][kPreRes ? MT : 1][kPreRes ? NT : 1];
+  if constexpr (kPreRes) {
+    if (p.res) {
+#pragma unroll
+      for (int cls = 0; cls < 4; ++cls)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int r0 = (nt0 + nt * NS) * 16 + 4 * q;
+            const size_t oi = (size_t)(out_vox[t] + ((long long)(cls >> 1) * p.Ho + (cls & 1)) * p.Wo + r0 / COUT) * COUT + r0 % COUT;
+            ep_res[cls][t][nt] = (r0 < ROWS && (vmask[t] & 8u)) ? *reinterpret_cast<const float4*>(p.res + oi) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+    }
+  }
   bool no_next_plane = false;
   if (p.kd_skip) {
     unsigned m_or = 0u;
@@ -485,10 +503,32 @@ __global__ __launch_bounds__(WL ? WL * 64 : 256) void convtr_all_kernel(const Co
     for (int t = 0; t < MT; ++t) m_or |= vmask[t];
     no_next_plane = !__any((int)(m_or & 1u));
   }
+  // The fragments of PG positions are requested together and zeroed where they are used (one round trip per group instead of one per
+  // position: a persistent wave's tiles run back to back, nobody else hides them)
+#ifndef MDF_CONVTR_PG64
+#define MDF_CONVTR_PG64 0      // dev A/B (build_variant.sh): 1 = the one-tile 64 -> 32 kernels fetch four positions at a time too (measured: @12x37x50 49.9 -> 60.0 us, worse)
+#endif
+  constexpr int PG = (WL != 0 || (CIN >= 64 && MDF_CONVTR_PG64)) ? ((64 / (NCH * MT * KPL) >= 8) ? 8 : (64 / (NCH * MT * KPL) >= 4) ? 4 : 1) : 1;
+  Frag<KPL> bfa[PG][NCH][MT];
 #pragma unroll
   for (int pos = 0; pos < 8; ++pos) {
     const int od = 1 - (pos >> 2), oh = 1 - ((pos >> 1) & 1), ow = pos & 1;
     const unsigned need = 8u | (od ? 1u : 0u) | (oh ? 2u : 0u) | (ow ? 4u : 0u);
+    if constexpr (PG > 1) {
+      if (pos % PG == 0) {
+#pragma unroll
+        for (int p2 = pos; p2 < pos + PG; ++p2) {
+          const int od2 = 1 - (p2 >> 2), oh2 = 1 - ((p2 >> 1) & 1), ow2 = p2 & 1;
+          const unsigned need2 = 8u | (od2 ? 1u : 0u) | (oh2 ? 2u : 0u) | (ow2 ? 4u : 0u);
+          const int tapoff2 = ((od2 * p.Hi + oh2) * p.Wi + ow2) * CIN;
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) bfa[p2 - pos][ch][t].load(xq + in_off[t] + (((vmask[t] & need2) == need2) ? tapoff2 : 0) + ch * CK);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     const int tapoff = ((od * p.Hi + oh) * p.Wi + ow) * CIN;
     if (NS == NTA && NTA > 1 && ow == 1 && (nt0 + 1) * 16 <= COUT) continue;   // one n-tile per wave, of parity pw = 0: nothing to do at offset +1
     if (od == 1 && no_next_plane) continue;             // shallow volumes: no voxel of the wave has plane d + 1 (see conv3d_kernel: kd_skip)
@@ -498,7 +538,8 @@ __global__ __launch_bounds__(WL ? WL * 64 : 256) void convtr_all_kernel(const Co
 #pragma unroll
       for (int t = 0; t < MT; ++t) {   // (branch-free, as in conv3d_kernel: an absent neighbour reads the voxel itself and is zeroed)
         const bool ok = (vmask[t] & need) == need;
-        bf[ch][t].load(xq + in_off[t] + (ok ? tapoff : 0) + ch * CK);
+        if constexpr (PG > 1) bf[ch][t] = bfa[pos % PG][ch][t];
+        else bf[ch][t].load(xq + in_off[t] + (ok ? tapoff : 0) + ch * CK);
         bf[ch][t].scale(ok ? 1.0f : 0.0f);
       }
 #pragma unroll
@@ -546,7 +587,9 @@ __global__ __launch_bounds__(WL ? WL * 64 : 256) void convtr_all_kernel(const Co
         if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         const size_t oi = (size_t)(out_vox[t] + ((long long)pd * p.Ho + ph) * p.Wo + pw_out) * COUT + c0;
         if (p.res) {
-          const float4 rr = *reinterpret_cast<const float4*>(p.res + oi);
+          float4 rr;
+          if constexpr (kPreRes) rr = ep_res[cls][t][nt];
+          else rr = *reinterpret_cast<const float4*>(p.res + oi);
           o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
         }
         *reinterpret_cast<float4*>(p.y + oi) = o;
@@ -1250,7 +1293,8 @@ static int conv3d_entry(const float* x, const float* wpack, const float* alpha, 
       // smaller accumulator set lets 4-5 waves per SIMD instead of 3-4 overlap one block's streaming with another's MFMAs:
       // 32->16 @24x74x100 89.2 -> 69.3 us, 16->8 @12x148x200 51.2 -> 47.4, @4x296x400 79.4 -> 74.7 (four tiles: 88 / 67 / 97)
       const int mt = [] { const char* e = getenv("MDF_CONVTR_MT"); return e ? atoi(e) : 1; }();   // dev A/B (read per call)
-      const int twl = [] { const char* e = getenv("MDF_CONVTR_WLDS"); return e ? atoi(e) : 0; }();   // dev A/B (read per call): weights in LDS, m-tiles per wave
+      // LDS-weights persistent form (r05): 32->16 @24x74x100 69.5 -> 60.8 us, @2x148x200 29.9 -> 26.1, @6x74x100 24.2 -> 21.3; 16->8 @12x148x200 47.6 -> 44.9, @4x296x400 71.0 -> 59.3
+      const int twl = [] { const char* e = getenv("MDF_CONVTR_WLDS"); return e ? atoi(e) : 1; }();   // dev A/B and the equality test (read per call): 0 = off, 2 = fewer waves / two m-tiles
       if (Cin == 16 && Cout == 8 && twl == 1) return launch_convtr_all_wl<16, 8, 1, 16>(p, (hipStream_t)stream);
       if (Cin == 16 && Cout == 8 && twl == 2) return launch_convtr_all_wl<16, 8, 2, 12>(p, (hipStream_t)stream);
       if (Cin == 32 && Cout == 16 && twl == 1) return launch_convtr_all_wl<32, 16, 1, 12>(p, (hipStream_t)stream);
