@@ -973,28 +973,40 @@ __global__ __launch_bounds__(1024) void conv3d_wlds_kernel(const ConvParams p) {
               acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[nt].v[s], bf[ch][t].v[s], acc[t][nt], 0, 0, 0);
       }
     };
-    // rows (kd, kh) of three taps; the next row's B fragments are requested before the current row's MFMAs (two register sets)
-    struct RowRegs { Frag<KPL> b[3][NCH][MT]; };
+    // groups of RB rows (kd, kh) of three taps; the next group's B fragments are requested before the current group's MFMAs (two register
+    // sets).  (8 input channels, 2 registers per fragment: a whole kd plane of 9 taps per group was measured -- 8->16 s2 @24x296x400
+    // 44.7 -> 50.0 us, @8x592x800 58.7 -> 64.8: worse; dev: -DMDF_WLDS_RB8=3)
+#ifndef MDF_WLDS_RB8
+#define MDF_WLDS_RB8 1
+#endif
+    constexpr int RB = (CIN == 8) ? MDF_WLDS_RB8 : 1;
+    struct RowRegs { Frag<KPL> b[3 * RB][NCH][MT]; };
     auto load_row = [&](int r, RowRegs& rr) {
-      const int kd = r / 3, kh = r - 3 * kd;
-      load_b(kd, kh, 0, rr.b[0]);
-      load_b(kd, kh, 1, rr.b[1]);
-      load_b(kd, kh, 2, rr.b[2]);
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int kd = (r + i) / 3, kh = (r + i) - 3 * kd;
+        load_b(kd, kh, 0, rr.b[3 * i]);
+        load_b(kd, kh, 1, rr.b[3 * i + 1]);
+        load_b(kd, kh, 2, rr.b[3 * i + 2]);
+      }
     };
     auto mul_row = [&](int r, RowRegs& rr) {
-      const int kd = r / 3, kh = r - 3 * kd;
-      mul_tap(3 * r, kd, kh, 0, rr.b[0]);
-      mul_tap(3 * r + 1, kd, kh, 1, rr.b[1]);
-      mul_tap(3 * r + 2, kd, kh, 2, rr.b[2]);
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int kd = (r + i) / 3, kh = (r + i) - 3 * kd;
+        mul_tap(3 * (r + i), kd, kh, 0, rr.b[3 * i]);
+        mul_tap(3 * (r + i) + 1, kd, kh, 1, rr.b[3 * i + 1]);
+        mul_tap(3 * (r + i) + 2, kd, kh, 2, rr.b[3 * i + 2]);
+      }
     };
     auto next_row = [&](int r) {
-      ++r;
-      while (r < 9 && !((kd_any >> (r / 3)) & 1u)) ++r;
+      r += RB;
+      while (r < 9 && !((kd_any >> (r / 3)) & 1u)) r += RB;
       return r;
     };
     {
       RowRegs ra, rb;
-      int r = next_row(-1);
+      int r = next_row(-RB);
       if (r < 9) load_row(r, ra);
       while (r < 9) {
         int rn = next_row(r);
