@@ -45,6 +45,31 @@ def test_conv3d_layer(cin, cout, mode, shape):
     np.testing.assert_allclose(ops.from_ndhwc(y2).cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("cin,cout,stride,shape", [(32, 32, 1, (1, 7, 67, 151)), (32, 32, 1, (2, 3, 90, 131)), (16, 32, 2, (1, 18, 160, 211)),
+                                                   (8, 16, 2, (1, 12, 301, 399)), (8, 16, 2, (2, 9, 210, 300))])
+def test_conv3d_layer_lds_weights_kernel_more_tiles_than_waves(cin, cout, stride, shape, monkeypatch):
+    """conv3d_wlds_kernel (the layer's packed weight set in LDS, one persistent 16-wave block per CU): volumes with more m-tiles than the
+    4096 waves of the grid -- every wave walks several tiles, the XCD chunks have remainders, the last tile is ragged -- against torch,
+    and against conv3d_kernel (MDF_CONV3D_WLDS=0 / MDF_CONV3D_WLDS8=0) at the re-association level."""
+    b, d, h, w = shape
+    g = torch.Generator().manual_seed(cin * 10 + cout + w)
+    x = torch.randn(b, cin, d, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, 3, generator=g) / np.sqrt(27 * cin)
+    alpha, beta = torch.rand(cout, generator=g) + 0.5, torch.rand(cout, generator=g) * 0.4 - 0.2
+    ref = F.conv3d(x, wt, None, stride, 1)
+    assert ref.shape[2] * ref.shape[3] * ref.shape[4] * b > 4096 * 16 * (2 if cin == 8 else 1) and (stride == 2 or b * d * h * w < 150000)
+    res = torch.randn(ref.shape, generator=g)
+    exp = F.relu(ref * alpha.view(1, -1, 1, 1, 1) + beta.view(1, -1, 1, 1, 1)) + res
+    wp = ops.pack_conv3d_weight(wt.to(DEV), False)
+    xd, rd = ops.to_ndhwc(x.to(DEV)), ops.to_ndhwc(res.to(DEV))
+    y = ops.conv3d_ndhwc(xd, wp, cin, cout, stride, False, alpha.to(DEV), beta.to(DEV), True, rd)
+    np.testing.assert_allclose(ops.from_ndhwc(y).cpu().numpy(), exp.numpy(), rtol=1e-4, atol=2e-5)
+    monkeypatch.setenv("MDF_CONV3D_WLDS", "0")
+    monkeypatch.setenv("MDF_CONV3D_WLDS8", "0")
+    y0 = ops.conv3d_ndhwc(xd, wp, cin, cout, stride, False, alpha.to(DEV), beta.to(DEV), True, rd)
+    assert (y - y0).abs().max().item() < 2e-5      # (same MFMAs; the split-K form sums its four partial chains last)
+
+
 @pytest.mark.parametrize("cin,cout", [(32, 16), (16, 16), (32, 32), (16, 8), (8, 8), (16, 32), (8, 16)])
 @pytest.mark.parametrize("shape", [(1, 6, 130, 201), (2, 5, 125, 131), (1, 3, 260, 197), (1, 90, 5, 401), (1, 2, 3, 25001), (1, 1, 400, 400)])
 def test_conv3d_layer_lds_kernels(cin, cout, shape):
@@ -219,7 +244,7 @@ def test_prob_head_in_one_launch_equals_the_two_launch_route(cin, D, h, w, monke
 
 
 @pytest.mark.parametrize("cin,cout", [(16, 8), (32, 16), (64, 32)])
-@pytest.mark.parametrize("shape", [(1, 5, 37, 53), (2, 3, 20, 70), (1, 1, 9, 17)])
+@pytest.mark.parametrize("shape", [(1, 5, 37, 53), (2, 3, 20, 70), (1, 1, 9, 17), (1, 6, 101, 119)])     # the last: more m-tiles than the persistent form has waves
 def test_transposed_conv_all_classes_kernel_equals_the_per_class_kernel(cin, cout, shape, monkeypatch):
     """convtr_all_kernel (every input fragment fetched once, fed to all four (pd, ph) parity classes) against
     conv3d_kernel<kTr> (one block per class): the taps of a class are accumulated in the same order, so bit for bit --
