@@ -599,6 +599,147 @@ __global__ __launch_bounds__(WL ? WL * 64 : 256) void convtr_all_kernel(const Co
   }  // tile loop (one tile unless WL)
 }
 
+// ---- 64 -> 32 transposed layers: one parity class per persistent block, the class's tap slots in LDS ---------------------------------
+// The 64 -> 32 weight set (18 slots x 16 KB) does not fit LDS, and the all-classes kernel streams it through the vector L1 once per
+// 16 input voxels (0.6 GB from the L2s per launch at 12x37x50: that stream, not the MFMAs, is its time).  The slots of ONE (pd, ph) class
+// do fit (2 / 4 / 4 / 8 slots = 32-128 KB): the 256 blocks are shared out 32 : 56 : 56 : 112 over the four classes (their MFMA counts
+// are 1 : 2 : 2 : 4; multiples of 8, so every class has blocks on all XCDs), a block copies its class's slots to LDS once and its waves
+// walk ALL m-tiles for that class (XCD-chunked, as conv3d_wlds_kernel): A fragments by ds_read_b128, the B fragments of up to four
+// input positions and the skip values requested together.  Per accumulator the taps run in conv3d_kernel<kTr>'s order: bit-identical.
+template <int CIN, int COUT, int NWV, int PGMAX, int PD, int PH>
+__device__ __forceinline__ void convtr_cls_body(const ConvParams& p, float* wsm, unsigned cls_first, unsigned cls_blocks) {
+  constexpr int KPL = 4, CK = 16, NCH = CIN / CK, ROWS = 2 * COUT, NT = (ROWS + 15) / 16;
+  constexpr int SLOTF = NCH * NT * 64 * KPL;             // floats per tap slot
+  constexpr int NKH = 1 + PH, NCOMB = (1 + PD) * NKH, NPOS = 2 * NCOMB;
+  constexpr int PG = (NPOS < PGMAX) ? NPOS : PGMAX;      // positions fetched together (16 registers each at 64 input channels)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, n16 = lane & 15;
+  {   // the class's slots, in tap order: LDS slot (c, ow) = packed slot (kd*3 + kh)*2 + ow
+#pragma unroll
+    for (int c = 0; c < NCOMB; ++c) {
+      const int jd = c / NKH, jh = c % NKH;
+      const int kd = PD ? 2 * jd : 1, kh = PH ? 2 * jh : 1;
+      const float4* src = reinterpret_cast<const float4*>(p.wpack + (size_t)((kd * 3 + kh) * 2) * SLOTF);
+      float4* dst = reinterpret_cast<float4*>(wsm + (size_t)(c * 2) * SLOTF);
+      for (int i = threadIdx.x; i < 2 * SLOTF / 4; i += NWV * 64) dst[i] = src[i];
+    }
+  }
+  __syncthreads();
+  const float* xq = p.x + KPL * q;
+  const float* wl = wsm + lane * KPL;
+  const unsigned xcd = blockIdx.x & 7u, bx = (blockIdx.x - cls_first) >> 3, nbx = cls_blocks >> 3;
+  const unsigned cq = p.nblk >> 3, cr = p.nblk & 7u;                     // (p.nblk = m-tiles)
+  const unsigned c_start = (xcd < cr) ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq, c_len = cq + (xcd < cr ? 1u : 0u);
+  for (unsigned l = (unsigned)wave * nbx + bx; l < c_len; l += (unsigned)NWV * nbx) {
+    long long m = (long long)(c_start + l) * 16 + n16;
+    const bool live = m < p.m_total;
+    if (!live) m = p.m_total - 1;
+    const unsigned mu = (unsigned)m, r1 = mu / (unsigned)p.Wi, r2 = r1 / (unsigned)p.Hi;
+    const int mw = (int)(mu - r1 * (unsigned)p.Wi), mh = (int)(r1 - r2 * (unsigned)p.Hi);
+    const int b = (int)(r2 / (unsigned)p.Di), md = (int)(r2 - (unsigned)b * (unsigned)p.Di);
+    const unsigned vmask = live ? (8u | (md + 1 < p.Di ? 1u : 0u) | (mh + 1 < p.Hi ? 2u : 0u) | (mw + 1 < p.Wi ? 4u : 0u)) : 0u;
+    const int in_off = (int)((((long long)b * p.Di + md) * p.Hi + mh) * p.Wi + mw) * CIN;
+    const long long out_vox = (((long long)b * p.Do + 2 * md + PD) * p.Ho + 2 * mh + PH) * p.Wo + 2 * mw;
+    const bool no_next_plane = p.kd_skip && !__any((int)(vmask & 1u));
+    float4 ep_res[NT];
+    if (p.res) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int r0 = nt * 16 + 4 * q;
+        ep_res[nt] = (r0 < ROWS && live) ? *reinterpret_cast<const float4*>(p.res + (size_t)(out_vox + r0 / COUT) * COUT + r0 % COUT)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    Frag<KPL> bfa[PG][NCH];
+#pragma unroll
+    for (int pos = 0; pos < NPOS; ++pos) {     // pos = c*2 + ow: conv3d_kernel<kTr>'s tap order
+      if (pos % PG == 0) {
+#pragma unroll
+        for (int p2 = pos; p2 < pos + PG && p2 < NPOS; ++p2) {
+          const int c2 = p2 >> 1, ow2 = p2 & 1, jd2 = c2 / NKH, jh2 = c2 % NKH;
+          const int od2 = (PD && jd2 == 0) ? 1 : 0, oh2 = (PH && jh2 == 0) ? 1 : 0;
+          const unsigned need2 = 8u | (od2 ? 1u : 0u) | (oh2 ? 2u : 0u) | (ow2 ? 4u : 0u);
+          const int tapoff2 = ((od2 * p.Hi + oh2) * p.Wi + ow2) * CIN;
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch) bfa[p2 - pos][ch].load(xq + in_off + (((vmask & need2) == need2) ? tapoff2 : 0) + ch * CK);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const int c = pos >> 1, ow = pos & 1, jd = c / NKH, jh = c % NKH;
+      const int od = (PD && jd == 0) ? 1 : 0, oh = (PH && jh == 0) ? 1 : 0;
+      const unsigned need = 8u | (od ? 1u : 0u) | (oh ? 2u : 0u) | (ow ? 4u : 0u);
+      if (od == 1 && no_next_plane) continue;       // shallow volumes: no voxel of the wave has plane d + 1 (conv3d_kernel: kd_skip)
+      const float okf = ((vmask & need) == need) ? 1.0f : 0.0f;
+      const float* wt = wl + pos * SLOTF;
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        Frag<KPL> bf = bfa[pos % PG][ch];
+        bf.scale(okf);
+        Frag<KPL> af[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) af[nt].load(wt + (ch * NT + nt) * (64 * KPL));
+#pragma unroll
+        for (int s = 0; s < KPL; ++s)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            if (ow == 1 && (nt + 1) * 16 <= COUT) continue;   // offset +1 feeds parity pw = 1 only
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[nt].v[s], bf.v[s], acc[nt], 0, 0, 0);
+          }
+      }
+    }
+    if (!live) continue;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int r0 = nt * 16 + 4 * q;
+      if (r0 >= ROWS) continue;
+      const int pw_out = r0 / COUT, c0 = r0 % COUT;
+      float4 al = make_float4(1.f, 1.f, 1.f, 1.f), be = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.alpha) { al = *reinterpret_cast<const float4*>(p.alpha + c0); be = *reinterpret_cast<const float4*>(p.beta + c0); }
+      float4 o;
+      o.x = acc[nt][0] * al.x + be.x;
+      o.y = acc[nt][1] * al.y + be.y;
+      o.z = acc[nt][2] * al.z + be.z;
+      o.w = acc[nt][3] * al.w + be.w;
+      if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      if (p.res) { const float4 rr = ep_res[nt]; o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
+      *reinterpret_cast<float4*>(p.y + (size_t)(out_vox + pw_out) * COUT + c0) = o;
+    }
+  }
+}
+
+template <int CIN, int COUT, int NWV, int PGMAX>
+__global__ __launch_bounds__(NWV * 64) void convtr_cls_kernel(const ConvParams p) {
+  extern __shared__ float wsm[];
+  const unsigned bid = blockIdx.x;       // grid = 256 blocks
+  if (bid < 32u) convtr_cls_body<CIN, COUT, NWV, PGMAX, 0, 0>(p, wsm, 0u, 32u);
+  else if (bid < 88u) convtr_cls_body<CIN, COUT, NWV, PGMAX, 0, 1>(p, wsm, 32u, 56u);
+  else if (bid < 144u) convtr_cls_body<CIN, COUT, NWV, PGMAX, 1, 0>(p, wsm, 88u, 56u);
+  else convtr_cls_body<CIN, COUT, NWV, PGMAX, 1, 1>(p, wsm, 144u, 112u);
+}
+
+template <int CIN, int COUT, int NWV, int PGMAX>
+int launch_convtr_cls(ConvParams& p, hipStream_t st) {
+  constexpr int NCH = CIN / 16, NT = (2 * COUT + 15) / 16;
+  constexpr size_t kLds = (size_t)8 * NCH * NT * 64 * 4 * sizeof(float);      // the (1, 1) class: 8 slots
+  static_assert(kLds <= 160 * 1024, "a class's tap slots must fit LDS");
+  auto kern = &convtr_cls_kernel<CIN, COUT, NWV, PGMAX>;
+  static bool attr_done_dev[64] = {};     // (per-device function attribute: see conv_lds.hip)
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  bool& attr_done = attr_done_dev[(dev_id >= 0 && dev_id < 64) ? dev_id : 0];
+  if (!attr_done || dev_id >= 64) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+    if (e != hipSuccess) return mdf::fail(MDF_EHIP, "hipFuncSetAttribute(dynamic LDS %zu): %s", kLds, hipGetErrorString(e));
+    attr_done = true;
+  }
+  p.nblk = (unsigned)((p.m_total + 15) / 16);      // m-tiles
+  hipLaunchKernelGGL(kern, dim3(256), dim3(NWV * 64), kLds, st, p);
+  return mdf::check_launch("convtr_cls_kernel");
+}
+
 template <int CIN, int COUT, int MT, int NWV>
 int launch_convtr_all_wl(ConvParams& p, hipStream_t st) {
   constexpr int KPL = (CIN >= 16) ? 4 : 2, NCH = CIN / (4 * KPL), NTA = (2 * COUT + 15) / 16;
@@ -1300,6 +1441,13 @@ static int conv3d_entry(const float* x, const float* wpack, const float* alpha, 
   if (m == kTr && !stat) {   // large transposed layers: all four parity classes per tile (convtr_all_kernel)
     const long long tr_min = [] { const char* e = getenv("MDF_CONVTR_ALL_MIN_VOXELS"); return e ? atoll(e) : 40000LL; }();   // dev A/B (read per call); -1 = never  (r05: 100000 -> 40000, 32->16 @2x148x200 36.7 -> 30.2 us, @6x74x100 29.2 -> 24.7)
     const int ns = [] { const char* e = getenv("MDF_CONVTR_NS"); return e ? atoi(e) : 0; }();   // dev A/B and the equality test (read per call): 0 = the rule, 1 = off
+    // one class per persistent block with the class's slots in LDS (convtr_cls_kernel; r05: @12x37x50 42.6 -> 32.9 us, @3x37x50 19.0 -> 14.4;
+    // a single-plane volume halves the work of the pd = 1 classes and with it the block shares: @1x74x100 15.3 -> 16.6, so that one stays)
+    const int tcl = [] { const char* e = getenv("MDF_CONVTR_CLS"); return e ? atoi(e) : -1; }();   // dev A/B and the equality test (read per call): 0 = off
+    if (tr_min >= 0 && Cin == 64 && Cout == 32 && ns == 0) {
+      if (tcl == 1) return launch_convtr_cls<64, 32, 12, 4>(p, (hipStream_t)stream);
+      if (tcl == 2 || (tcl < 0 && Di >= 2)) return launch_convtr_cls<64, 32, 16, 2>(p, (hipStream_t)stream);
+    }
     if (tr_min >= 0 && p.m_total >= tr_min && !(Cin == 64 && Cout == 32 && ns > 1)) {
       // One 16-voxel m-tile per wave (r05; two until then): these layers' time is MFMA time PLUS streaming time (skip + output), and the
       // smaller accumulator set lets 4-5 waves per SIMD instead of 3-4 overlap one block's streaming with another's MFMAs:

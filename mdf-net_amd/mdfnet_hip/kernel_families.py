@@ -21,7 +21,7 @@ CONTROL = "control"                        # weight packing, Adam, loss, finalis
 
 KERNEL_FAMILY = {
     # conv_lds.hip / conv3d.hip / conv_pair.hip / conv1x1.hip / refine_tail.hip / prob_fused.hip
-    "conv_lds_kernel": MFMA_CONV, "conv3d_kernel": MFMA_CONV, "conv3d_wlds_kernel": MFMA_CONV, "convtr_all_kernel": MFMA_CONV, "conv_pair_kernel": MFMA_CONV, "conv_pair_valu_kernel": MFMA_CONV,   # (the pair on packed fp32 FMAs: same layers, same family)
+    "conv_lds_kernel": MFMA_CONV, "conv3d_kernel": MFMA_CONV, "conv3d_wlds_kernel": MFMA_CONV, "convtr_all_kernel": MFMA_CONV, "convtr_cls_kernel": MFMA_CONV, "conv_pair_kernel": MFMA_CONV, "conv_pair_valu_kernel": MFMA_CONV,   # (the pair on packed fp32 FMAs: same layers, same family)
     "conv1x1_kernel": MFMA_CONV, "conv1x1_heads_kernel": MFMA_CONV, "refine_tail_kernel": MFMA_CONV, "prob_fused_kernel": MFMA_CONV, "res_pair_kernel": MFMA_CONV,
     "wino3d_kernel": MFMA_CONV, "wino2d_kernel": MFMA_CONV,
     "pack_weights_kernel": CONTROL, "pack_batch_kernel": CONTROL,

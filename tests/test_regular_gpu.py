@@ -261,6 +261,7 @@ def test_transposed_conv_all_classes_kernel_equals_the_per_class_kernel(cin, cou
         exp = ops.conv3d_ndhwc(x, wp, cin, cout, 2, True, **kw)
         monkeypatch.setenv("MDF_CONVTR_ALL_MIN_VOXELS", "0")
         # MDF_CONVTR_NS (64 -> 32 only): 1 = every n-tile of an m-tile in one wave, 2 / 4 = dealt out to two / four waves (small volumes)
+        monkeypatch.setenv("MDF_CONVTR_CLS", "0")
         for ns in (("1", "2", "4") if cin == 64 else ("1",)):
             monkeypatch.setenv("MDF_CONVTR_NS", ns)
             got = ops.conv3d_ndhwc(x, wp, cin, cout, 2, True, **kw)
@@ -272,3 +273,9 @@ def test_transposed_conv_all_classes_kernel_equals_the_per_class_kernel(cin, cou
             got = ops.conv3d_ndhwc(x, wp, cin, cout, 2, True, **kw)
             assert torch.equal(got, exp), ("wlds", wl)
         monkeypatch.delenv("MDF_CONVTR_WLDS", raising=False)
+        # MDF_CONVTR_CLS (64 -> 32): one parity class per persistent block, the class's tap slots in LDS
+        for cl in (("1", "2") if cin == 64 else ()):
+            monkeypatch.setenv("MDF_CONVTR_CLS", cl)
+            got = ops.conv3d_ndhwc(x, wp, cin, cout, 2, True, **kw)
+            assert torch.equal(got, exp), ("cls", cl)
+        monkeypatch.delenv("MDF_CONVTR_CLS")
